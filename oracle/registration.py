@@ -1,0 +1,98 @@
+"""CPU restatement of weighted Procrustes + robust SE(3) refinement.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  **Pinned**: checked against the
+reference's own `core/registration.py` / `core/loss.py` (both import and run
+on CPU torch) by `tests/golden/make_golden.py`.
+
+* `weighted_procrustes`   follows `core/registration.py:91-113`
+* `rot6d_to_matrix`       follows `core/registration.py:16-64` (`ortho2rotation`)
+* `smooth_l1_highdim`     follows `core/loss.py:42-61` (`HighDimSmoothL1Loss`,
+                          including its discontinuity at s == 1)
+* `global_registration`   follows `core/registration.py:135-194`
+                          (`GlobalRegistration` with weights given)
+
+The optimiser is torch's own Adam / ExponentialLR driven by autograd, exactly
+like the reference, so the trajectory (and the discrete stopping logic) is the
+reference's up to floating-point summation order.
+"""
+import numpy as np
+import torch
+
+F32_EPS = float(np.finfo(np.float32).eps)   # core/loss.py:44
+
+
+def weighted_procrustes(X, Y, w, eps=F32_EPS):
+    """X,Y [N,3] f32, w [N,1] f32 -> R [3,3] f32, t [3] f32."""
+    X, Y, w = (torch.as_tensor(np.asarray(a), dtype=torch.float32) for a in (X, Y, w))
+    w = w.reshape(-1, 1)
+    wn = w / (w.abs().sum() + eps)
+    mx = (wn * X).sum(0, keepdim=True)
+    my = (wn * Y).sum(0, keepdim=True)
+    S = ((Y - my).t() @ (wn * (X - mx))).double()          # 3x3, SVD in f64 on the host
+    U, _, V = torch.svd(S)
+    sgn = torch.eye(3, dtype=torch.float64)
+    if torch.det(U) * torch.det(V) < 0:
+        sgn[2, 2] = -1
+    R = (U @ sgn @ V.t()).float()
+    t = (my.squeeze() - (R @ mx.t()).squeeze()).float()
+    return R, t
+
+
+def rot6d_to_matrix(p6):
+    """[B,6] -> [B,3,3]: Gram-Schmidt on the two 3-vectors, clamps at 1e-8."""
+    a, b = p6[:, 0:3], p6[:, 3:6]
+    x = a / torch.clamp(torch.sqrt((a ** 2).sum(1, keepdim=True)), min=1e-8)
+    coef = (x * b).sum(1, keepdim=True) / torch.clamp((x ** 2).sum(1, keepdim=True), min=1e-8)
+    u = b - coef * x
+    y = u / torch.clamp(torch.sqrt((u ** 2).sum(1, keepdim=True)), min=1e-8)
+    z = torch.stack((x[:, 1] * y[:, 2] - x[:, 2] * y[:, 1],
+                     x[:, 2] * y[:, 0] - x[:, 0] * y[:, 2],
+                     x[:, 0] * y[:, 1] - x[:, 1] * y[:, 0]), dim=1)
+    return torch.stack((x, y, z), dim=2)
+
+
+def smooth_l1_highdim(P, Q, w, wsum, q, eps=F32_EPS):
+    s = (((P - Q) / q) ** 2).sum(1, keepdim=True)
+    half = 0.5 * (s < 1).float()
+    per = (0.5 - half) * (torch.sqrt(s + eps) - 0.5) + half * s
+    if w is None:
+        return per.mean()
+    return (per * w).sum() / wsum
+
+
+def global_registration(X, Y, w, max_iter=1000, max_break_count=20,
+                        break_threshold_ratio=1e-5, quantization_size=1.0):
+    """Returns R [3,3], t [1,3] (float32 numpy) and the stats dict
+    {'iterations','loss','break_count'} of the reference."""
+    X, Y, w = (torch.as_tensor(np.asarray(a), dtype=torch.float32) for a in (X, Y, w))
+    w = w.reshape(-1, 1)
+    wsum = w.sum()
+    R0, t0 = weighted_procrustes(X, Y, w, F32_EPS)
+    rot6d = torch.nn.Parameter(torch.cat((R0[:, 0], R0[:, 1])).reshape(1, 6).clone())
+    trans = torch.nn.Parameter(t0.reshape(1, 3).clone())
+
+    def apply(P):
+        return P @ rot6d_to_matrix(rot6d)[0].t() + trans
+
+    opt = torch.optim.Adam([rot6d, trans], lr=1e-1)
+    sched = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=0.999)
+    loss_prev = smooth_l1_highdim(apply(X), Y, w, wsum, quantization_size).item()
+    breaks = 0
+    i = 0
+    loss = None
+    for i in range(max_iter):
+        loss = smooth_l1_highdim(apply(X), Y, w, wsum, quantization_size)
+        if loss.item() < 1e-7:
+            break
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        sched.step()
+        if abs(loss_prev - loss.item()) < loss_prev * break_threshold_ratio:
+            breaks += 1
+            if breaks >= max_break_count:
+                break
+        loss_prev = loss.item()
+    R = rot6d_to_matrix(rot6d.detach())[0]
+    return (R.numpy(), trans.detach().numpy(),
+            {'iterations': i, 'loss': float(loss.item()), 'break_count': breaks})

@@ -1,0 +1,68 @@
+"""Oracle (CPU restatement) vs the golden vectors generated from the reference's own
+modules (tests/golden/make_golden.py).  CPU only."""
+import ast
+
+import numpy as np
+import torch
+
+from oracle import knn as oknn
+from oracle import registration as oreg
+
+
+def test_knn_matches_reference(golden):
+    g = golden('knn')
+    for tag in 'abc':
+        F0, F1 = g[f'{tag}_F0'], g[f'{tag}_F1']
+        ic, dc = oknn.find_knn(F0, F1, nn_max_n=250, return_distance=True)
+        assert ic.shape == g[f'{tag}_idx_chunked'].shape
+        np.testing.assert_array_equal(ic, g[f'{tag}_idx_chunked'])
+        np.testing.assert_allclose(dc, g[f'{tag}_dist_chunked'], rtol=0, atol=1e-6)
+        iu, du = oknn.find_knn(F0, F1, nn_max_n=-1, return_distance=True)
+        np.testing.assert_array_equal(iu, g[f'{tag}_idx_unchunked'])
+        np.testing.assert_allclose(du, g[f'{tag}_dist_unchunked'], rtol=0, atol=1e-6)
+    it = oknn.find_knn(g['tie_F0'], g['tie_F1'], nn_max_n=250)
+    np.testing.assert_array_equal(it, g['tie_idx_chunked'])
+    assert (it < 20).all()          # first minimal index wins on exact duplicates
+
+
+def test_procrustes_matches_reference(golden):
+    g = golden('procrustes')
+    for tag in ('clean', 'noisy', 'zeros', 'reflect'):
+        R, t = oreg.weighted_procrustes(g[f'{tag}_X'], g[f'{tag}_Y'], g[f'{tag}_w'])
+        np.testing.assert_allclose(R.numpy(), g[f'{tag}_R'], atol=1e-6)
+        np.testing.assert_allclose(t.numpy(), g[f'{tag}_t'], atol=1e-6)
+        assert abs(np.linalg.det(R.numpy().astype(np.float64)) - 1) < 1e-5
+
+
+def test_refinement_matches_reference(golden):
+    g = golden('refine')
+    torch.set_num_threads(1)
+    for tag in ('clean', 'outliers70', 'exact', 'maxiter', 'default_q'):
+        kw = ast.literal_eval(str(g[f'{tag}_kw']))
+        R, t, st = oreg.global_registration(g[f'{tag}_X'], g[f'{tag}_Y'], g[f'{tag}_w'], **kw)
+        assert st['iterations'] == int(g[f'{tag}_iterations']), tag
+        assert st['break_count'] == int(g[f'{tag}_break_count']), tag
+        np.testing.assert_allclose(st['loss'], float(g[f'{tag}_loss']), rtol=1e-5, atol=1e-12)
+        np.testing.assert_allclose(R, g[f'{tag}_R'], atol=1e-6)
+        np.testing.assert_allclose(t, g[f'{tag}_t'], atol=1e-6)
+
+
+def test_loss_matches_reference(golden):
+    g = golden('loss')
+    X, Y, w, q = (torch.from_numpy(g['X']), torch.from_numpy(g['Y']), torch.from_numpy(g['w']),
+                  float(g['q']))
+    lw = oreg.smooth_l1_highdim(X, Y, w, w.sum(), q).item()
+    lu = oreg.smooth_l1_highdim(X, Y, None, None, q).item()
+    np.testing.assert_allclose(lw, float(g['loss_weighted']), rtol=1e-6)
+    np.testing.assert_allclose(lu, float(g['loss_unweighted']), rtol=1e-6)
+    per = [oreg.smooth_l1_highdim(X[i:i + 1], Y[i:i + 1], None, None, q).item() for i in range(len(X))]
+    np.testing.assert_allclose(per, g['per_point'], rtol=1e-6, atol=1e-9)
+    # the reference loss is discontinuous at s == 1 (0.5 vs 0.25): keep it
+    assert max(per) > 0.45 and min(p for p, s in zip(per, np.linalg.norm(g['X'] - g['Y'], axis=1) / q)
+                                   if s > 1.0) < 0.3
+
+
+def test_ortho6d_matches_reference(golden):
+    g = golden('ortho6d')
+    R = oreg.rot6d_to_matrix(torch.from_numpy(g['P'])).numpy()
+    np.testing.assert_allclose(R, g['R'], atol=1e-7)
