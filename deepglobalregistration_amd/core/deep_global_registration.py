@@ -1,0 +1,197 @@
+"""`DeepGlobalRegistration` with the reference's constructor / `register()` / stage-method
+surface (core/deep_global_registration.py:67-324), executed on one MI355X by libdgr_hip.so.
+
+Scope: steps 0-5 "case 0" of `register()` -- voxelisation, FCGF features,
+feature matching, 6-D inlier network, confidence gate, weighted Procrustes + robust refinement.
+The Open3D parts (safeguard RANSAC :302-315, ICP :317-322) are out of scope: when the gate fails
+`register()` returns the identity like the reference does before its safeguard, and records
+`last_status = 'low_confidence'`; `use_icp` defaults to False.
+"""
+import os
+
+import numpy as np
+import torch
+
+from .. import _lib, ops
+from ..model import load_model
+from ..sparse import SparseTensor
+from ..util.timer import Timer
+from .knn import find_knn_gpu
+from .registration import GlobalRegistration
+
+
+def _cfg_get(cfg, key, default=None):
+    if isinstance(cfg, dict):
+        return cfg.get(key, default)
+    return getattr(cfg, key, default)
+
+
+def _cfg_has(cfg, key):
+    return (key in cfg) if isinstance(cfg, dict) else hasattr(cfg, key)
+
+
+class DeepGlobalRegistration:
+    def __init__(self, config, device=torch.device('cuda')):
+        self.config = config
+        self.clip_weight_thresh = _cfg_get(config, 'clip_weight_thresh', 0.05)
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise RuntimeError('DeepGlobalRegistration (MI355X build) runs on the GPU only')
+        _lib.load()                      # fail loudly here if the HIP extension is missing
+        self.safeguard_method = 'correspondence'
+        self.use_icp = False             # Open3D ICP is out of scope
+        self.feat_timer = Timer()
+        self.reg_timer = Timer()
+        self.last_status = None
+        self.last_stats = None
+
+        weights = _cfg_get(config, 'weights')
+        if isinstance(weights, (str, os.PathLike)):
+            assert os.path.exists(weights), weights
+            state = torch.load(weights, map_location='cpu', weights_only=False)
+        elif isinstance(weights, dict):
+            state = weights              # in-memory checkpoint (synthetic weights, tests)
+        else:
+            raise ValueError('config.weights must be a checkpoint path or a checkpoint dict')
+        network_config = state['config']
+        self.network_config = network_config
+        self.inlier_feature_type = _cfg_get(network_config, 'inlier_feature_type', 'coords')
+        self.voxel_size = _cfg_get(network_config, 'voxel_size')
+
+        # FCGF network (:94-116); legacy checkpoints use un-prefixed keys (:104-112)
+        if _cfg_has(network_config, 'feat_model'):
+            name, n_out, ks = (_cfg_get(network_config, 'feat_model'), _cfg_get(network_config, 'feat_model_n_out'),
+                               _cfg_get(network_config, 'feat_conv1_kernel_size'))
+        else:
+            name, n_out, ks = (_cfg_get(network_config, 'model'), _cfg_get(network_config, 'model_n_out'),
+                               _cfg_get(network_config, 'conv1_kernel_size'))
+        FCGFModel = load_model(name)
+        if FCGFModel is None:
+            raise NotImplementedError(f'feature model {name!r}: only ResUNetBN2C is implemented')
+        self.fcgf_model = FCGFModel(1, n_out, bn_momentum=_cfg_get(network_config, 'bn_momentum', 0.05),
+                                    conv1_kernel_size=ks,
+                                    normalize_feature=_cfg_get(network_config, 'normalize_feature'))
+        self.fcgf_model.load_state_dict(state['state_dict'])
+        self.fcgf_model = self.fcgf_model.to(self.device).eval()
+
+        # inlier network (:118-131)
+        num_feats = 6 if self.inlier_feature_type == 'coords' else 1
+        InlierModel = load_model(_cfg_get(network_config, 'inlier_model'))
+        if InlierModel is None:
+            raise NotImplementedError('inlier model: only ResUNetBN2C is implemented')
+        self.inlier_model = InlierModel(num_feats, 1, bn_momentum=_cfg_get(network_config, 'bn_momentum', 0.05),
+                                        conv1_kernel_size=_cfg_get(network_config, 'inlier_conv1_kernel_size'),
+                                        normalize_feature=False, D=6)
+        self.inlier_model.load_state_dict(state['state_dict_inlier'])
+        self.inlier_model = self.inlier_model.to(self.device).eval()
+        self.nn_max_n = _cfg_get(network_config, 'nn_max_n', 250)
+
+    # ---- stage methods, same names and argument order as the reference -------------------------
+    def preprocess(self, pcd, batch_index=0):
+        """Stage 0 (:134-161).  Returns xyz f32 [N,3] (device), coords i32 [N,4] (device),
+        feats ones [N,1]."""
+        if hasattr(pcd, 'points') and not isinstance(pcd, np.ndarray):   # o3d.geometry.PointCloud
+            xyz = np.array(pcd.points)
+        elif isinstance(pcd, np.ndarray):
+            xyz = pcd
+        elif torch.is_tensor(pcd):
+            xyz = pcd
+        else:
+            raise Exception('Unrecognized pcd type')
+        xyz_sel, coords, _ = ops.voxelize(xyz, self.voxel_size, batch_index, self.device)
+        feats = torch.ones(len(xyz_sel), 1, device=self.device)
+        return xyz_sel, coords, feats
+
+    def fcgf_feature_extraction(self, feats, coords):
+        """Step 1 (:163-169)."""
+        sinput = SparseTensor(feats, coordinates=coords, device=self.device)
+        return self.fcgf_model(sinput).F
+
+    def fcgf_feature_matching(self, feats0, feats1):
+        """Step 2 (:171-183)."""
+        nns = find_knn_gpu(feats0, feats1, nn_max_n=self.nn_max_n, knn=1, return_distance=False)
+        corres_idx0 = torch.arange(len(nns), device=self.device).long()
+        corres_idx1 = nns.long().reshape(-1)
+        return corres_idx0, corres_idx1
+
+    def inlier_feature_generation(self, xyz0, xyz1, coords0, coords1, fcgf_feats0, fcgf_feats1,
+                                  corres_idx0, corres_idx1):
+        """Step 3 (:185-208).  corres_idx0 must be arange(N0), as produced by step 2."""
+        assert len(corres_idx0) == len(corres_idx1)
+        feat_type = self.inlier_feature_type
+        assert feat_type in ['ones', 'feats', 'coords']
+        if feat_type == 'feats':
+            raise TypeError("inlier_feature_type 'feats' is inconsistent with the network input width "
+                            'in the reference (deep_global_registration.py:119) and is not supported')
+        _, feat = ops.inlier_inputs(coords0, xyz0, coords1, xyz1, corres_idx1, feat_type)
+        return feat
+
+    def inlier_prediction(self, inlier_feats, coords):
+        """Step 4 (:210-217)."""
+        sinput = SparseTensor(inlier_feats, coordinates=coords, device=self.device)
+        return self.inlier_model(sinput).F
+
+    def safeguard_registration(self, *args, **kwargs):
+        raise NotImplementedError('Open3D RANSAC safeguard is out of scope of the MI355X hot path '
+                                  '(SURVEY.md section 8f rank 2)')
+
+    # ---- main entry ------------------------------------------------------------------------------
+    def register(self, xyz0, xyz1, inlier_thr=0.00):
+        """Main algorithm (:238-324) without the Open3D safeguard / ICP.  Returns a 4x4 float64
+        numpy transformation."""
+        self.reg_timer.tic()
+        xyz0, coords0, feats0 = self.preprocess(xyz0)
+        xyz1, coords1, feats1 = self.preprocess(xyz1)
+
+        self.feat_timer.tic()
+        fcgf_feats0 = self.fcgf_feature_extraction(feats0, coords0)
+        fcgf_feats1 = self.fcgf_feature_extraction(feats1, coords1)
+        self.feat_timer.toc()
+
+        corres_idx0, corres_idx1 = self.fcgf_feature_matching(fcgf_feats0, fcgf_feats1)
+
+        inlier_coords, inlier_feats = ops.inlier_inputs(coords0, xyz0, coords1, xyz1, corres_idx1,
+                                                        self.inlier_feature_type)
+        logit = self.inlier_prediction(inlier_feats.contiguous(), coords=inlier_coords)
+        weights, wsum = ops.sigmoid_clip_sum(logit, self.clip_weight_thresh)
+
+        wsum_threshold = max(200, len(weights) * 0.05)
+        T = np.identity(4)
+        if wsum >= wsum_threshold:
+            try:
+                rot, trans, opt_output = GlobalRegistration(xyz0, ops.gather_rows3(xyz1, corres_idx1),
+                                                            weights=weights, break_threshold_ratio=1e-4,
+                                                            quantization_size=2 * self.voxel_size,
+                                                            verbose=False)
+                T[0:3, 0:3] = rot.detach().cpu().numpy()
+                T[0:3, 3] = trans.detach().cpu().numpy()
+                self.last_status, self.last_stats = 'ok', opt_output
+            except RuntimeError:
+                self.last_status = 'svd_failed'   # reference: "Will directly go to Safeguard" (:295-300)
+        else:
+            self.last_status = 'low_confidence'    # reference: safeguard RANSAC (:302-315), out of scope
+        self.reg_timer.toc()
+        return T
+
+    # ---- batched throughput path (no reference counterpart) ---------------
+    def register_batch(self, pairs, forced_logits=None, skip_refinement=False):
+        """Registers a list of (xyz0, xyz1) pairs with ONE sparse tensor per network (pairs are
+        distinguished by the batch column, the layout of ME.utils.batched_coordinates).  Returns
+        T [n,4,4] float64, status [n] (0 ok / 1 low confidence / 2 SVD failed), stats [n,4]."""
+        x0, c0, x1, c1, off0, off1 = [], [], [], [], [0], [0]
+        for p, (a, b) in enumerate(pairs):
+            xa, ca, _ = self.preprocess(a, batch_index=p)
+            xb, cb, _ = self.preprocess(b, batch_index=p)
+            x0.append(xa); c0.append(ca); x1.append(xb); c1.append(cb)
+            off0.append(off0[-1] + len(xa)); off1.append(off1[-1] + len(xb))
+        return self.register_voxelized(torch.cat(c0), torch.cat(x0), off0, torch.cat(c1), torch.cat(x1), off1,
+                                       forced_logits=forced_logits, skip_refinement=skip_refinement)
+
+    def register_voxelized(self, coords0, xyz0, off0, coords1, xyz1, off1, forced_logits=None,
+                           skip_refinement=False):
+        T, status, stats = ops.register_batch(
+            self.fcgf_model._handle(), self.inlier_model._handle(), coords0, xyz0, off0, coords1, xyz1, off1,
+            self.voxel_size, clip_weight_thresh=self.clip_weight_thresh,
+            inlier_feature_type=self.inlier_feature_type, break_threshold_ratio=1e-4,
+            skip_refinement=skip_refinement, forced_logit=forced_logits)
+        return T.astype(np.float64), status, stats

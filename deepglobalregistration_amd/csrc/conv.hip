@@ -1,0 +1,272 @@
+// Sparse convolution forward for gfx950: rule-major gather -> LDS tile -> f32 MFMA -> scatter.
+// Replaces the ME.MinkowskiConvolution / MinkowskiConvolutionTranspose forward invoked by every
+// conv of ResUNetBN2C (model/resunet.py:598-649, model/residual_block.py:15-80).
+//
+// Work decomposition: the kernel map lists pairs (in, out) per kernel offset k ("rule").  A tile
+// is <= 64 pairs of ONE rule: the 64 gathered input rows [64 x Cin] are staged in LDS once,
+// multiplied with the rule's dense [Cin x Cout] slice on the matrix cores
+// (v_mfma_f32_32x32x2_f32: exact f32, bitwise an fma chain) and scatter-accumulated into the output
+// rows (global_atomic_add_f32; 32 consecutive lanes hit 32 consecutive floats of one output row).
+// The grid is persistent and XCD-aware: each of the 8 XCDs walks a contiguous range of tiles, i.e.
+// a contiguous range of rules, so a rule's weight slice is pulled into ONE L2.
+//
+// Weight layout (prepared once in net.hip): W[k][s][nb][lane][c], s = Cin_pad/8 K-steps,
+// nb = Cout_pad/32 column blocks, value = W_folded[k][8 s + 4 (lane>>5) + c][32 nb + (lane&31)],
+// so a wave fetches the B operands of 4 MFMAs with one coalesced 16-byte load per lane.
+#include "dgr_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvKArgs {
+  const float *in;
+  float *out;
+  const float *w;
+  const int32_t *pair_in, *pair_out, *tile_ptr, *rule_ptr, *n_rows_dev;
+  int in_ld, out_ld, in_relu;
+  int cin, cin_pad, cout, K;
+};
+
+template <int WM, int WN, int MB, int NB>
+__global__ void __launch_bounds__(64 * WM * WN) sparse_conv_mfma(ConvKArgs a) {
+  constexpr int THREADS = 64 * WM * WN;
+  constexpr int TM = 32 * MB * WM;
+  static_assert(TM == DGR_TILE_M, "tile height must match the kernel-map tiling");
+  constexpr int NBLK = NB * WN;  // 32-column blocks of the padded output
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int CP = a.cin_pad;
+  const int LDA = CP + 4;  // +4 floats: keeps 16-B alignment, spreads rows over LDS banks
+  float *As = lds;
+  int *idx_in = reinterpret_cast<int *>(lds + TM * LDA);
+  int *idx_out = idx_in + TM;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int S = CP >> 3;
+  const bool identity = (a.pair_in == nullptr);
+
+  int T;  // total tiles
+  if (identity)
+    T = (*a.n_rows_dev + TM - 1) / TM;
+  else
+    T = a.tile_ptr[a.K];
+  // XCD-aware persistent schedule: block b runs on XCD (b % 8); give each XCD a contiguous range
+  const int per = (T + 7) >> 3;
+  const int xcd = blockIdx.x & 7;
+  const int t_end = min(T, (xcd + 1) * per);
+  const int nj = gridDim.x >> 3;
+
+  for (int t = xcd * per + (blockIdx.x >> 3); t < t_end; t += nj) {
+    // ---- locate the rule and the pair range of this tile
+    int k = 0, pstart, count;
+    if (identity) {
+      pstart = t * TM;
+      count = min(TM, *a.n_rows_dev - pstart);
+    } else {
+      int lo = 0, hi = a.K;  // largest k with tile_ptr[k] <= t
+      while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (a.tile_ptr[mid] <= t) lo = mid; else hi = mid;
+      }
+      k = lo;
+      pstart = a.rule_ptr[k] + (t - a.tile_ptr[k]) * TM;
+      count = min(TM, a.rule_ptr[k + 1] - pstart);
+    }
+    if (tid < TM) {
+      int r = tid;
+      int vi = -1, vo = -1;
+      if (r < count) {
+        vi = identity ? pstart + r : a.pair_in[pstart + r];
+        vo = identity ? pstart + r : a.pair_out[pstart + r];
+      }
+      idx_in[r] = vi;
+      idx_out[r] = vo;
+    }
+    __syncthreads();
+    // ---- gather the input rows into LDS (coalesced 16-B pieces along each row)
+    if (((a.cin | a.in_ld) & 3) == 0) {
+      const int c4n = CP >> 2;
+      for (int ch = tid; ch < TM * c4n; ch += THREADS) {
+        const int r = ch / c4n, c4 = ch - r * c4n;
+        const int row = idx_in[r];
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row >= 0 && c4 * 4 < a.cin) {
+          v = *reinterpret_cast<const f32x4 *>(a.in + (int64_t)row * a.in_ld + c4 * 4);
+          if (a.in_relu) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+          }
+        }
+        *reinterpret_cast<f32x4 *>(As + r * LDA + c4 * 4) = v;
+      }
+    } else {
+      for (int e = tid; e < TM * CP; e += THREADS) {
+        const int r = e / CP, c = e - r * CP;
+        const int row = idx_in[r];
+        float v = 0.f;
+        if (row >= 0 && c < a.cin) {
+          v = a.in[(int64_t)row * a.in_ld + c];
+          if (a.in_relu) v = fmaxf(v, 0.f);
+        }
+        As[r * LDA + c] = v;
+      }
+    }
+    __syncthreads();
+    // ---- MFMA main loop over Cin in steps of 8
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const f32x4 *wk = reinterpret_cast<const f32x4 *>(a.w) + ((int64_t)k * S * NBLK + wn * NB) * 64 + lane;
+    const float *arow = As + (32 * wm * MB + (lane & 31)) * LDA + 4 * (lane >> 5);
+    f32x4 bcur[NB], bnext[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) bcur[j] = wk[j * 64];
+    for (int s = 0; s < S; ++s) {
+      if (s + 1 < S) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) bnext[j] = wk[((int64_t)(s + 1) * NBLK + j) * 64];
+      }
+      f32x4 av[MB];
+#pragma unroll
+      for (int i = 0; i < MB; ++i) av[i] = *reinterpret_cast<const f32x4 *>(arow + i * 32 * LDA + s * 8);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+          for (int j = 0; j < NB; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][c], bcur[j][c], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) bcur[j] = bnext[j];
+    }
+    // ---- scatter-accumulate: C layout col = lane & 31, row = (e&3) + 8 (e>>2) + 4 (lane>>5)
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int r = 32 * (wm * MB + i) + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        const int orow = idx_out[r];
+        if (orow >= 0) {
+          float *dst = a.out + (int64_t)orow * a.out_ld;
+#pragma unroll
+          for (int j = 0; j < NB; ++j) {
+            const int col = 32 * (wn * NB + j) + (lane & 31);
+            if (col < a.cout) unsafeAtomicAdd(dst + col, acc[i][j][e]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int WM, int WN, int MB, int NB>
+static int launch_cfg(const ConvKArgs &ka, int64_t tile_bound, int num_cus, hipStream_t stream) {
+  constexpr int THREADS = 64 * WM * WN;
+  const size_t lds_bytes = (size_t)DGR_TILE_M * (ka.cin_pad + 4) * sizeof(float) + 2 * DGR_TILE_M * sizeof(int);
+  static size_t configured = 0;
+  if (lds_bytes > configured) {
+    DGR_HIP_CHECK(hipFuncSetAttribute((const void *)sparse_conv_mfma<WM, WN, MB, NB>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    configured = 160 * 1024;
+  }
+  int per_cu = (int)((160 * 1024) / (lds_bytes + 512));
+  if (per_cu > 4) per_cu = 4;
+  if (per_cu < 1) per_cu = 1;
+  int64_t grid = (int64_t)num_cus * per_cu;
+  if (tile_bound < grid) grid = tile_bound;
+  grid = (grid + 7) / 8 * 8;
+  if (grid < 8) grid = 8;
+  sparse_conv_mfma<WM, WN, MB, NB><<<(int)grid, THREADS, lds_bytes, stream>>>(ka);
+  DGR_LAUNCH_CHECK();
+  return DGR_OK;
+}
+
+int dgr_conv_launch(const DgrConvLaunch &a, int num_cus, hipStream_t stream) {
+  ConvKArgs ka;
+  ka.in = a.in; ka.out = a.out; ka.w = a.w;
+  ka.pair_in = a.pair_in; ka.pair_out = a.pair_out; ka.tile_ptr = a.tile_ptr; ka.rule_ptr = a.rule_ptr;
+  ka.n_rows_dev = a.n_rows_dev;
+  ka.in_ld = a.in_ld; ka.out_ld = a.out_ld; ka.in_relu = a.in_relu;
+  ka.cin = a.cin; ka.cin_pad = a.cin_pad; ka.cout = a.cout; ka.K = a.K;
+  DGR_REQUIRE(a.cin_pad % 8 == 0 && a.cin_pad >= a.cin && a.cin_pad <= 256, "bad cin_pad %d", a.cin_pad);
+  const int64_t tile_bound = a.tile_bound > 0 ? a.tile_bound : (int64_t)num_cus * 4;
+  switch (a.cout_pad) {
+    case 32: return launch_cfg<2, 1, 1, 1>(ka, tile_bound, num_cus, stream);
+    case 64: return launch_cfg<2, 2, 1, 1>(ka, tile_bound, num_cus, stream);
+    case 128: return launch_cfg<1, 4, 2, 1>(ka, tile_bound, num_cus, stream);
+    case 256: return launch_cfg<1, 4, 2, 2>(ka, tile_bound, num_cus, stream);
+    default:
+      dgr_set_error("unsupported padded output width %d", a.cout_pad);
+      return DGR_EINVAL;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// elementwise companions: output initialisation (folded-BN shift + residual) and L2 normalise
+// ------------------------------------------------------------------------------------------
+__global__ void init_rows_kernel(float *__restrict__ out, int out_ld, int cout,
+                                 const float *__restrict__ shift, const float *__restrict__ res,
+                                 int res_ld, int res_relu, const int32_t *n_dev) {
+  const int64_t n = *n_dev;
+  const int64_t total = n * cout;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cout;
+    const int c = (int)(i - r * cout);
+    float v = shift ? shift[c] : 0.f;
+    if (res) {
+      float x = res[r * res_ld + c];
+      if (res_relu) x = fmaxf(x, 0.f);
+      v += x;
+    }
+    out[r * out_ld + c] = v;
+  }
+}
+
+int dgr_init_rows(float *out, int out_ld, int cout, const float *shift, const float *res, int res_ld,
+                  int res_relu, const int32_t *n_dev, int64_t n_cap, hipStream_t stream) {
+  int64_t blocks = dgr_ceil_div(n_cap * cout, 256);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  init_rows_kernel<<<(int)blocks, 256, 0, stream>>>(out, out_ld, cout, shift, res, res_ld, res_relu, n_dev);
+  DGR_LAUNCH_CHECK();
+  return DGR_OK;
+}
+
+// F / (||F||_2 + 1e-8) per row, model/resunet.py:643-647.  One row per thread (C <= 64).
+__global__ void l2_normalize_kernel(const float *__restrict__ in, int in_ld, float *__restrict__ out,
+                                    int out_ld, int c, int relu, const int32_t *n_dev) {
+  const int64_t n = *n_dev;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n;
+       r += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int j = 0; j < c; ++j) {
+      float v = in[r * in_ld + j];
+      if (relu) v = fmaxf(v, 0.f);
+      s += v * v;
+    }
+    const float den = sqrtf(s) + 1e-8f;
+    for (int j = 0; j < c; ++j) {
+      float v = in[r * in_ld + j];
+      if (relu) v = fmaxf(v, 0.f);
+      out[r * out_ld + j] = v / den;
+    }
+  }
+}
+
+int dgr_l2_normalize_rows(const float *in, int in_ld, float *out, int out_ld, int c, int relu,
+                          const int32_t *n_dev, int64_t n_cap, hipStream_t stream) {
+  int64_t blocks = dgr_ceil_div(n_cap, 256);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  l2_normalize_kernel<<<(int)blocks, 256, 0, stream>>>(in, in_ld, out, out_ld, c, relu, n_dev);
+  DGR_LAUNCH_CHECK();
+  return DGR_OK;
+}

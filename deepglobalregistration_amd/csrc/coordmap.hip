@@ -1,0 +1,338 @@
+// Coordinate maps: COO voxel hashing, first-occurrence unique, strided maps, voxelisation.
+// Replaces the coordinate-manager part of MinkowskiEngine (ME.SparseTensor construction,
+// stride-2 output maps) and ME.utils.sparse_quantize (core/deep_global_registration.py:152).
+// Integer / HBM-latency-bound work: one thread per row, tables sized 2x rows (L2-resident).
+#include "dgr_internal.h"
+#include "hash.h"
+
+// ------------------------------------------------------------------------------------------
+// exclusive scan (int32): block-local scan + single-block scan of the block sums
+// ------------------------------------------------------------------------------------------
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_BLOCK = SCAN_THREADS * SCAN_ITEMS;
+
+__device__ __forceinline__ int block_exclusive_scan_256(int v, int *lds /*>=4 ints*/, int *total) {
+  // wave-level inclusive scan with DPP-free shuffles (wave64), then 4 wave totals through LDS
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    int y = __shfl_up(x, d, 64);
+    if (lane >= d) x += y;
+  }
+  if (lane == 63) lds[wave] = x;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < SCAN_THREADS / 64; ++w) {
+    int s = lds[w];
+    if (w < wave) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + x - v;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) scan_block_sums(const int32_t *__restrict__ in,
+                                                                int64_t n,
+                                                                int32_t *__restrict__ sums) {
+  __shared__ int lds[4];
+  int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_ITEMS;
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i)
+    if (base + i < n) s += in[base + i];
+  int tot;
+  block_exclusive_scan_256(s, lds, &tot);
+  if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) scan_sums_serial(int32_t *sums, int nblocks,
+                                                                 int32_t *total_out) {
+  __shared__ int lds[4];
+  int carry = 0;
+  for (int b0 = 0; b0 < nblocks; b0 += SCAN_THREADS) {
+    int i = b0 + threadIdx.x;
+    int v = i < nblocks ? sums[i] : 0;
+    int tot;
+    int ex = block_exclusive_scan_256(v, lds, &tot);
+    if (i < nblocks) sums[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0 && total_out) *total_out = carry;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) scan_final(const int32_t *__restrict__ in, int64_t n,
+                                                           const int32_t *__restrict__ sums,
+                                                           int32_t *__restrict__ out) {
+  __shared__ int lds[4];
+  int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_ITEMS;
+  int v[SCAN_ITEMS];
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    v[i] = (base + i < n) ? in[base + i] : 0;
+    s += v[i];
+  }
+  int tot;
+  int ex = block_exclusive_scan_256(s, lds, &tot) + sums[blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    if (base + i < n) out[base + i] = ex;
+    ex += v[i];
+  }
+}
+
+int dgr_exclusive_scan_i32(DgrArena &arena, const int32_t *in, int32_t *out, int64_t n,
+                           int32_t *total_out, hipStream_t stream) {
+  if (n <= 0) {
+    if (total_out) DGR_HIP_CHECK(hipMemsetAsync(total_out, 0, sizeof(int32_t), stream));
+    return DGR_OK;
+  }
+  int nblocks = (int)dgr_ceil_div(n, SCAN_BLOCK);
+  int32_t *sums;
+  DGR_ALLOC(sums, arena, int32_t, nblocks);
+  scan_block_sums<<<nblocks, SCAN_THREADS, 0, stream>>>(in, n, sums);
+  scan_sums_serial<<<1, SCAN_THREADS, 0, stream>>>(sums, nblocks, total_out);
+  scan_final<<<nblocks, SCAN_THREADS, 0, stream>>>(in, n, sums, out);
+  DGR_LAUNCH_CHECK();
+  return DGR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// first-occurrence unique over int32 key rows
+// ------------------------------------------------------------------------------------------
+// table[slot] ends up holding the SMALLEST row index among the rows that share a key, so the
+// surviving row ("first occurrence") does not depend on thread scheduling.
+template <int NC>
+__global__ void unique_insert(const int32_t *__restrict__ keys, const int32_t *n_dev, int64_t n_cap,
+                              int32_t *table, uint32_t mask) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t n = n_dev ? *n_dev : n_cap;
+  if (r >= n) return;
+  int32_t me[NC];
+#pragma unroll
+  for (int d = 0; d < NC; ++d) me[d] = keys[r * NC + d];
+  uint32_t slot = dgr_hash_row<NC>(me) & mask;
+  while (true) {
+    int cur = __hip_atomic_load(&table[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == DGR_EMPTY) {
+      int old = atomicCAS(&table[slot], DGR_EMPTY, (int)r);
+      if (old == DGR_EMPTY) return;
+      cur = old;
+    }
+    if (dgr_rows_equal<NC>(keys + (int64_t)cur * NC, me)) {
+      atomicMin(&table[slot], (int)r);
+      return;
+    }
+    slot = (slot + 1) & mask;
+  }
+}
+
+template <int NC>
+__global__ void unique_flag(const int32_t *__restrict__ keys, const int32_t *n_dev, int64_t n_cap,
+                            const int32_t *__restrict__ table, uint32_t mask,
+                            int32_t *__restrict__ first_flag, int32_t *dup_flag) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_cap) return;
+  int64_t n = n_dev ? *n_dev : n_cap;
+  if (r >= n) {
+    if (first_flag) first_flag[r] = 0;
+    return;
+  }
+  int32_t me[NC];
+#pragma unroll
+  for (int d = 0; d < NC; ++d) me[d] = keys[r * NC + d];
+  int v = dgr_lookup<NC>(table, mask, keys, me);
+  int first = (v == (int)r) ? 1 : 0;
+  if (first_flag) first_flag[r] = first;
+  if (!first && dup_flag) *dup_flag = 1;
+}
+
+template <int NC>
+__global__ void unique_compact(const int32_t *__restrict__ keys, const int32_t *n_dev, int64_t n_cap,
+                               const int32_t *__restrict__ first_flag,
+                               const int32_t *__restrict__ rank, int32_t *__restrict__ out_coords,
+                               int64_t *__restrict__ sel_out) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t n = n_dev ? *n_dev : n_cap;
+  if (r >= n || !first_flag[r]) return;
+  int64_t o = rank[r];
+#pragma unroll
+  for (int d = 0; d < NC; ++d) out_coords[o * NC + d] = keys[r * NC + d];
+  if (sel_out) sel_out[o] = r;
+}
+
+__global__ void table_relabel(int32_t *table, uint32_t cap, const int32_t *__restrict__ rank) {
+  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= cap) return;
+  int v = table[s];
+  if (v >= 0) table[s] = rank[v];
+}
+
+template <int NC>
+__global__ void stride_keys(const int32_t *__restrict__ coords, const int32_t *n_dev, int ts_new,
+                            int32_t *__restrict__ keys) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= *n_dev) return;
+  const int32_t m = ~(ts_new - 1);  // ts_new is a power of two: floor(c / ts) * ts == c & ~(ts-1)
+  keys[r * NC] = coords[r * NC];
+#pragma unroll
+  for (int d = 1; d < NC; ++d) keys[r * NC + d] = coords[r * NC + d] & m;
+}
+
+static inline int grid_for(int64_t n, int threads = 256) { return (int)dgr_ceil_div(n > 0 ? n : 1, threads); }
+
+// keys [n,nc] -> table (row index of the surviving row per key), first_flag, rank (exclusive scan
+// of first_flag), n_unique.  All device-side; n may be a device count (n_dev) bounded by n_cap.
+template <int NC>
+static int unique_rows_t(DgrArena &arena, const int32_t *keys, const int32_t *n_dev, int64_t n_cap,
+                         int32_t *first_flag, int32_t *rank, int32_t *n_unique_dev,
+                         int32_t **table_out, uint32_t *mask_out, hipStream_t stream) {
+  uint32_t cap = dgr_next_pow2((uint64_t)(2 * n_cap > 64 ? 2 * n_cap : 64));
+  int32_t *table;
+  DGR_ALLOC(table, arena, int32_t, cap);
+  DGR_HIP_CHECK(hipMemsetAsync(table, 0xff, (size_t)cap * sizeof(int32_t), stream));
+  unique_insert<NC><<<grid_for(n_cap), 256, 0, stream>>>(keys, n_dev, n_cap, table, cap - 1);
+  unique_flag<NC><<<grid_for(n_cap), 256, 0, stream>>>(keys, n_dev, n_cap, table, cap - 1, first_flag,
+                                                      nullptr);
+  DGR_LAUNCH_CHECK();
+  DGR_CHECK(dgr_exclusive_scan_i32(arena, first_flag, rank, n_cap, n_unique_dev, stream));
+  *table_out = table;
+  *mask_out = cap - 1;
+  return DGR_OK;
+}
+
+int dgr_unique_rows(DgrArena &arena, const int32_t *keys, int64_t n, int nc, int32_t *first_flag,
+                    int32_t *rank, int32_t *n_unique_dev, int32_t **table_out, uint32_t *mask_out,
+                    hipStream_t stream) {
+  if (nc == 4)
+    return unique_rows_t<4>(arena, keys, nullptr, n, first_flag, rank, n_unique_dev, table_out,
+                            mask_out, stream);
+  if (nc == 7)
+    return unique_rows_t<7>(arena, keys, nullptr, n, first_flag, rank, n_unique_dev, table_out,
+                            mask_out, stream);
+  dgr_set_error("unsupported coordinate width %d", nc);
+  return DGR_EINVAL;
+}
+
+// ------------------------------------------------------------------------------------------
+// coordinate maps of one sparse tensor: ts = 1 (input, must be unique) and ts = 2,4,8
+// ------------------------------------------------------------------------------------------
+template <int NC>
+static int build_coord_maps_t(DgrArena &arena, const int32_t *coords, int64_t N, DgrMapSet *ms,
+                              hipStream_t stream) {
+  // ts = 1: hash the caller's rows in place; a duplicate row raises the error flag.
+  DgrCoordMap &c1 = ms->cm[0];
+  c1.coords = const_cast<int32_t *>(coords);
+  c1.n_cap = N;
+  c1.ts = 1;
+  DGR_ALLOC(c1.n_dev, arena, int32_t, 1);
+  int32_t n32 = (int32_t)N;
+  DGR_HIP_CHECK(hipMemcpyAsync(c1.n_dev, &n32, sizeof(int32_t), hipMemcpyHostToDevice, stream));
+  {
+    uint32_t cap = dgr_next_pow2((uint64_t)(2 * N > 64 ? 2 * N : 64));
+    DGR_ALLOC(c1.table, arena, int32_t, cap);
+    c1.table_mask = cap - 1;
+    DGR_HIP_CHECK(hipMemsetAsync(c1.table, 0xff, (size_t)cap * sizeof(int32_t), stream));
+    unique_insert<NC><<<grid_for(N), 256, 0, stream>>>(coords, nullptr, N, c1.table, cap - 1);
+    unique_flag<NC><<<grid_for(N), 256, 0, stream>>>(coords, nullptr, N, c1.table, cap - 1, nullptr,
+                                                    ms->overflow);
+    DGR_LAUNCH_CHECK();
+  }
+  // ts = 2,4,8: unique(floor(c / ts) * ts), first-occurrence order
+  for (int l = 1; l < 4; ++l) {
+    DgrCoordMap &p = ms->cm[l - 1];
+    DgrCoordMap &c = ms->cm[l];
+    c.ts = p.ts * 2;
+    c.n_cap = p.n_cap;
+    int32_t *keys, *flag, *rank;
+    DGR_ALLOC(keys, arena, int32_t, p.n_cap * NC);
+    DGR_ALLOC(flag, arena, int32_t, p.n_cap);
+    DGR_ALLOC(rank, arena, int32_t, p.n_cap);
+    DGR_ALLOC(c.coords, arena, int32_t, c.n_cap * NC);
+    DGR_ALLOC(c.n_dev, arena, int32_t, 1);
+    stride_keys<NC><<<grid_for(p.n_cap), 256, 0, stream>>>(p.coords, p.n_dev, c.ts, keys);
+    DGR_CHECK(unique_rows_t<NC>(arena, keys, p.n_dev, p.n_cap, flag, rank, c.n_dev, &c.table,
+                                &c.table_mask, stream));
+    unique_compact<NC><<<grid_for(p.n_cap), 256, 0, stream>>>(keys, p.n_dev, p.n_cap, flag, rank,
+                                                             c.coords, nullptr);
+    table_relabel<<<grid_for((int64_t)c.table_mask + 1), 256, 0, stream>>>(c.table, c.table_mask + 1,
+                                                                           rank);
+    DGR_LAUNCH_CHECK();
+  }
+  return DGR_OK;
+}
+
+int dgr_build_coord_maps(DgrArena &arena, const int32_t *coords, int64_t N, DgrMapSet *ms,
+                         hipStream_t stream) {
+  if (ms->nc == 4) return build_coord_maps_t<4>(arena, coords, N, ms, stream);
+  if (ms->nc == 7) return build_coord_maps_t<7>(arena, coords, N, ms, stream);
+  dgr_set_error("unsupported dimension D=%d (3 and 6 are on the DGR path)", ms->D);
+  return DGR_EINVAL;
+}
+
+// ------------------------------------------------------------------------------------------
+// voxelisation (ME.utils.sparse_quantize + batched_coordinates + xyz[sel])
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void voxel_keys(const T *__restrict__ xyz, int64_t M, T inv_unused, T voxel, int32_t batch,
+                           int32_t *__restrict__ keys) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= M) return;
+  keys[r * 4] = batch;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) keys[r * 4 + 1 + d] = (int32_t)floor(xyz[r * 3 + d] / voxel);
+}
+
+template <typename T>
+__global__ void voxel_gather_xyz(const T *__restrict__ xyz, const int64_t *__restrict__ sel,
+                                 const int32_t *n_dev, float *__restrict__ out) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= *n_dev) return;
+  int64_t s = sel[r];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) out[r * 3 + d] = (float)xyz[s * 3 + d];
+}
+
+extern "C" int dgr_voxelize(dgr_ctx *ctx, const void *xyz, int is_f64, int64_t M, double voxel_size,
+                            int32_t batch_index, int64_t *sel_out, int32_t *coords_out,
+                            float *xyz_out, int64_t *n_out, dgr_stream stream_) {
+  DGR_REQUIRE(ctx && xyz && sel_out && coords_out && n_out, "dgr_voxelize: NULL argument");
+  DGR_REQUIRE(M > 0 && M < (1ll << 30), "dgr_voxelize: M=%lld out of range", (long long)M);
+  DGR_REQUIRE(voxel_size > 0, "dgr_voxelize: voxel_size must be positive");
+  hipStream_t stream = (hipStream_t)stream_;
+  DGR_HIP_CHECK(hipSetDevice(ctx->device));
+  DGR_CHECK(ctx->arena.reset());
+  DgrArena &A = ctx->arena;
+  int32_t *keys, *flag, *rank, *n_dev, *table;
+  uint32_t mask;
+  DGR_ALLOC(keys, A, int32_t, M * 4);
+  DGR_ALLOC(flag, A, int32_t, M);
+  DGR_ALLOC(rank, A, int32_t, M);
+  DGR_ALLOC(n_dev, A, int32_t, 1);
+  if (is_f64)
+    voxel_keys<double><<<grid_for(M), 256, 0, stream>>>((const double *)xyz, M, 0.0, voxel_size,
+                                                       batch_index, keys);
+  else
+    voxel_keys<float><<<grid_for(M), 256, 0, stream>>>((const float *)xyz, M, 0.f, (float)voxel_size,
+                                                      batch_index, keys);
+  DGR_CHECK(unique_rows_t<4>(A, keys, nullptr, M, flag, rank, n_dev, &table, &mask, stream));
+  unique_compact<4><<<grid_for(M), 256, 0, stream>>>(keys, nullptr, M, flag, rank, coords_out, sel_out);
+  if (xyz_out) {
+    if (is_f64)
+      voxel_gather_xyz<double><<<grid_for(M), 256, 0, stream>>>((const double *)xyz, sel_out, n_dev,
+                                                               xyz_out);
+    else
+      voxel_gather_xyz<float><<<grid_for(M), 256, 0, stream>>>((const float *)xyz, sel_out, n_dev,
+                                                              xyz_out);
+  }
+  DGR_LAUNCH_CHECK();
+  int32_t n32 = 0;
+  DGR_HIP_CHECK(hipMemcpyAsync(&n32, n_dev, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  DGR_HIP_CHECK(hipStreamSynchronize(stream));
+  *n_out = n32;
+  return DGR_OK;
+}

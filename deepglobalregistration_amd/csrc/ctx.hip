@@ -1,0 +1,149 @@
+// Context, error reporting and the grow-only HBM arena of libdgr_hip.so.
+#include <stdarg.h>
+#include <string.h>
+
+#include "dgr_internal.h"
+
+static thread_local char g_err[1024] = "";
+
+void dgr_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char *dgr_last_error(void) { return g_err; }
+extern "C" const char *dgr_version(void) { return "dgr_hip 0.1 (gfx950)"; }
+
+// ------------------------------------------------------------------------------------------
+// arena: sized for 288 GB of HBM -- worst-case kernel-map capacities are reserved instead of
+// synchronising with the host to learn exact sizes.
+// ------------------------------------------------------------------------------------------
+static constexpr size_t kAlign = 256;
+static constexpr size_t kMinChunk = (size_t)256 << 20;
+
+void *DgrArena::alloc(size_t bytes) {
+  bytes = (bytes + kAlign - 1) / kAlign * kAlign;
+  if (bytes == 0) bytes = kAlign;
+  while (cur < chunks.size()) {
+    if (offset + bytes <= chunks[cur].size) {
+      void *p = chunks[cur].base + offset;
+      offset += bytes;
+      used_total += bytes;
+      if (used_total > high_water) high_water = used_total;
+      return p;
+    }
+    ++cur;
+    offset = 0;
+  }
+  size_t sz = bytes > kMinChunk ? bytes : kMinChunk;
+  // grow geometrically so that a steady-state call fits one chunk after the next reset
+  size_t have = reserved();
+  if (sz < have / 2) sz = have / 2;
+  char *base = nullptr;
+  hipError_t e = hipMalloc((void **)&base, sz);
+  if (e != hipSuccess) {
+    dgr_set_error("workspace hipMalloc(%zu MiB) failed: %s", sz >> 20, hipGetErrorString(e));
+    return nullptr;
+  }
+  chunks.push_back({base, sz});
+  cur = chunks.size() - 1;
+  offset = bytes;
+  used_total += bytes;
+  if (used_total > high_water) high_water = used_total;
+  return base;
+}
+
+size_t DgrArena::reserved() const {
+  size_t s = 0;
+  for (auto &c : chunks) s += c.size;
+  return s;
+}
+
+int DgrArena::reset() {
+  if (chunks.size() > 1) {
+    // the previous call spilled into several chunks: replace them by one of the high-water size
+    DGR_HIP_CHECK(hipDeviceSynchronize());
+    for (auto &c : chunks) DGR_HIP_CHECK(hipFree(c.base));
+    chunks.clear();
+    size_t want = high_water + high_water / 8 + kAlign;
+    char *base = nullptr;
+    hipError_t e = hipMalloc((void **)&base, want);
+    if (e != hipSuccess) {
+      dgr_set_error("workspace hipMalloc(%zu MiB) failed: %s", want >> 20, hipGetErrorString(e));
+      return DGR_ENOMEM;
+    }
+    chunks.push_back({base, want});
+  }
+  cur = 0;
+  offset = 0;
+  used_total = 0;
+  return DGR_OK;
+}
+
+void DgrArena::release() {
+  for (auto &c : chunks) (void)hipFree(c.base);
+  chunks.clear();
+  cur = offset = 0;
+}
+
+hipEvent_t DgrEventPool::next() {
+  if (used == ev.size()) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) {
+      dgr_set_error("hipEventCreate failed");
+      return nullptr;
+    }
+    ev.push_back(e);
+  }
+  return ev[used++];
+}
+
+void DgrEventPool::release() {
+  for (auto e : ev) (void)hipEventDestroy(e);
+  ev.clear();
+  used = 0;
+}
+
+// ------------------------------------------------------------------------------------------
+extern "C" int dgr_ctx_create(int device, dgr_ctx **out) {
+  DGR_REQUIRE(out != nullptr, "dgr_ctx_create: out is NULL");
+  int count = 0;
+  DGR_HIP_CHECK(hipGetDeviceCount(&count));
+  DGR_REQUIRE(device >= 0 && device < count, "dgr_ctx_create: device %d out of range (%d visible)",
+              device, count);
+  DGR_HIP_CHECK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  DGR_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+  dgr_ctx *ctx = new dgr_ctx();
+  ctx->device = device;
+  ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  *out = ctx;
+  return DGR_OK;
+}
+
+extern "C" void dgr_ctx_destroy(dgr_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  ctx->arena.release();
+  ctx->events.release();
+  delete ctx;
+}
+
+extern "C" int64_t dgr_ctx_workspace_bytes(dgr_ctx *ctx) {
+  return ctx ? (int64_t)ctx->arena.reserved() : 0;
+}
+
+extern "C" int dgr_ctx_set_profiling(dgr_ctx *ctx, int enable) {
+  DGR_REQUIRE(ctx != nullptr, "ctx is NULL");
+  ctx->profiling = enable != 0;
+  return DGR_OK;
+}
+
+extern "C" int dgr_ctx_stage_times(dgr_ctx *ctx, float times_ms[8]) {
+  DGR_REQUIRE(ctx != nullptr && times_ms != nullptr, "bad argument");
+  memcpy(times_ms, ctx->stage_ms, sizeof(ctx->stage_ms));
+  return DGR_OK;
+}

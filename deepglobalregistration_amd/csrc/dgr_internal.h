@@ -1,0 +1,196 @@
+// Internal declarations shared by the HIP translation units of libdgr_hip.so.
+// gfx950 (MI355X, CDNA4) only: wave64, MFMA f32, 160 KiB LDS per CU, 8 XCDs x 32 CUs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "../../include/dgr_hip.h"
+
+// ------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------
+void dgr_set_error(const char *fmt, ...);
+
+#define DGR_HIP_CHECK(expr)                                                                  \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess) {                                                                  \
+      dgr_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return DGR_EHIP;                                                                       \
+    }                                                                                        \
+  } while (0)
+
+#define DGR_CHECK(expr)          \
+  do {                           \
+    int _r = (expr);             \
+    if (_r != DGR_OK) return _r; \
+  } while (0)
+
+#define DGR_REQUIRE(cond, ...)     \
+  do {                             \
+    if (!(cond)) {                 \
+      dgr_set_error(__VA_ARGS__);  \
+      return DGR_EINVAL;           \
+    }                              \
+  } while (0)
+
+#define DGR_LAUNCH_CHECK() DGR_HIP_CHECK(hipGetLastError())
+
+// ------------------------------------------------------------------------------------------
+// grow-only device arena (reset at the start of every top-level call)
+// ------------------------------------------------------------------------------------------
+struct DgrArena {
+  struct Chunk {
+    char *base;
+    size_t size;
+  };
+  std::vector<Chunk> chunks;
+  size_t cur = 0;     // index of the chunk being bumped
+  size_t offset = 0;  // bump offset in chunks[cur]
+  size_t high_water = 0, used_total = 0;
+
+  struct Mark {
+    size_t cur, offset, used_total;
+  };
+  Mark mark() const { return {cur, offset, used_total}; }
+  // stack discipline: memory handed out after `m` is reused by later allocations; safe for work
+  // enqueued on ONE stream (stream order separates the old and the new users)
+  void rewind(const Mark &m) { cur = m.cur; offset = m.offset; used_total = m.used_total; }
+  void *alloc(size_t bytes);  // nullptr on failure (error set)
+  int reset();                // coalesces into one chunk when the last call spilled
+  void release();
+  size_t reserved() const;
+  template <typename T>
+  T *get(size_t n) {
+    return static_cast<T *>(alloc(n * sizeof(T)));
+  }
+};
+
+#define DGR_ALLOC(ptr, arena, T, n)                       \
+  do {                                                    \
+    (ptr) = (arena).get<T>((size_t)(n) > 0 ? (size_t)(n) : 1); \
+    if (!(ptr)) return DGR_ENOMEM;                        \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------
+// coordinate maps / kernel maps (coordmap.hip, kmap.hip)
+// ------------------------------------------------------------------------------------------
+constexpr int DGR_TILE_M = 64;  // pairs per MFMA tile of the sparse conv
+
+struct DgrCoordMap {
+  int32_t *coords = nullptr;  // [n_cap, nc] row-major, nc = 1 + D
+  int32_t *n_dev = nullptr;   // device-side row count
+  int64_t n_cap = 0;          // upper bound known on the host
+  int ts = 1;                 // tensor stride
+  int32_t *table = nullptr;   // open addressing: row index or -1
+  uint32_t table_mask = 0;    // capacity - 1
+};
+
+struct DgrKernelMap {
+  int K = 0;                    // kernel volume
+  int32_t *rule_ptr = nullptr;  // [K+1] exclusive prefix of pairs per offset
+  int32_t *tile_ptr = nullptr;  // [K+1] exclusive prefix of DGR_TILE_M-tiles per offset
+  int32_t *pair_in = nullptr;   // [pair_cap]
+  int32_t *pair_out = nullptr;  // [pair_cap]
+  int64_t pair_cap = 0;
+  bool built = false;
+};
+
+struct DgrMapSet {
+  int D = 3, nc = 4, conv1_ks = 3;
+  DgrCoordMap cm[4];     // ts = 1,2,4,8
+  DgrKernelMap same[4];  // 3^D at ts 1,2,4,8
+  DgrKernelMap conv1;    // ks^D at ts = 1 (aliases same[0] when ks == 3)
+  DgrKernelMap down[3];  // ts -> 2 ts (also used, swapped, by the transposed convs)
+  int32_t *overflow = nullptr;  // device flag: kernel-map capacity exceeded / duplicate coords
+};
+
+// Builds all coordinate maps and kernel maps of one sparse tensor into `arena`.
+int dgr_build_maps(DgrArena &arena, const int32_t *coords, int64_t N, int D, int conv1_ks,
+                   DgrMapSet *ms, hipStream_t stream);
+// voxelise helper (coordmap.hip)
+int dgr_unique_rows(DgrArena &arena, const int32_t *keys, int64_t n, int nc, int32_t *first_flag,
+                    int32_t *rank, int32_t *n_unique_dev, int32_t **table_out, uint32_t *mask_out,
+                    hipStream_t stream);
+int dgr_exclusive_scan_i32(DgrArena &arena, const int32_t *in, int32_t *out, int64_t n,
+                           int32_t *total_out, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------
+// sparse convolution (conv.hip)
+// ------------------------------------------------------------------------------------------
+struct DgrConvLaunch {
+  const float *in;  // [n_in, in_ld]
+  int in_ld;
+  int in_relu;  // apply max(x,0) when gathering
+  float *out;   // [n_out, out_ld], pre-initialised; accumulated with atomics
+  int out_ld;
+  const float *w;  // MFMA-B-fragment tiled weights of this layer
+  int cin, cin_pad, cout, cout_pad, K;
+  const int32_t *pair_in, *pair_out, *tile_ptr, *rule_ptr;  // nullptr pairs => identity map
+  const int32_t *n_rows_dev;                                 // identity map: number of rows
+  int64_t tile_bound;                                        // host upper bound on the tile count (0 = unknown)
+};
+int dgr_conv_launch(const DgrConvLaunch &a, int num_cus, hipStream_t stream);
+// out[r, c] = shift[c] (+ res[r, c]) for r < *n_dev, c < cout
+int dgr_init_rows(float *out, int out_ld, int cout, const float *shift, const float *res, int res_ld,
+                  int res_relu, const int32_t *n_dev, int64_t n_cap, hipStream_t stream);
+int dgr_l2_normalize_rows(const float *in, int in_ld, float *out, int out_ld, int c, int relu,
+                          const int32_t *n_dev, int64_t n_cap, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------
+struct DgrBatchOutputs {
+  const void *ptr[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  int64_t numel[5] = {0, 0, 0, 0, 0};
+};
+
+struct DgrEventPool {  // HIP events bracketing the conv kernels when profiling is on
+  std::vector<hipEvent_t> ev;
+  size_t used = 0;
+  hipEvent_t next();
+  void release();
+};
+
+struct dgr_ctx {
+  int device = 0;
+  int num_cus = 256;
+  DgrArena arena;
+  bool profiling = false;
+  float stage_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int64_t conv_launches = 0;  // conv kernel launches covered by stage_ms[7]
+  DgrBatchOutputs last;
+  DgrEventPool events;
+  int32_t *flag_dev = nullptr;  // error flag word of the current top-level call (arena)
+};
+
+// internal forward that does not reset the arena (used by the fused pipeline)
+int dgr_resunet_forward_impl(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, const float *feats,
+                             int64_t N, float *out, hipStream_t stream, float *maps_ms,
+                             float *conv_ms);
+
+// knn.hip / reg.hip / misc.hip internals used by the fused pipeline
+int dgr_knn1_impl(dgr_ctx *ctx, const float *F0, int64_t N0, const float *F1, int64_t N1, int C,
+                  int squared, int64_t *idx_out, float *dist_out, hipStream_t stream);
+int dgr_inlier_inputs_impl(const int32_t *coords0, const float *xyz0, int64_t N0,
+                           const int32_t *coords1, const float *xyz1, const int64_t *idx1,
+                           int feature_type, int32_t *coords6, float *feats, hipStream_t stream);
+struct DgrRegResult {  // device-side result record of the registration kernel
+  float R[9];
+  float t[3];
+  float loss;
+  float wsum;
+  int32_t iterations;
+  int32_t break_count;
+  int32_t status;
+  int32_t pad;
+};
+static inline int64_t dgr_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline uint32_t dgr_next_pow2(uint64_t v) {
+  uint32_t p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}

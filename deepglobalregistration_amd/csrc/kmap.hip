@@ -1,0 +1,303 @@
+// Kernel maps: for every output coordinate and every kernel offset delta_k, probe the input
+// coordinate hash for (out + delta_k * ts_in).  Replaces MinkowskiEngine's kernel-map
+// construction behind ME.MinkowskiConvolution(Transpose) (model/residual_block.py:15-80).
+//
+// Output layout (rule-major COO): pairs sorted by (k, out) -- pair_in[p], pair_out[p] for
+// p in [rule_ptr[k], rule_ptr[k+1]) -- plus tile_ptr[k], the exclusive prefix of
+// ceil(P_k / DGR_TILE_M) used by the sparse-conv kernel to enumerate MFMA tiles.
+// Offset enumeration: first spatial dimension fastest -- kept in ONE place:
+// `offset_of`.  Deterministic: two passes (count, fill) with block-level ranks, no atomics on
+// the pair positions.
+#include "dgr_internal.h"
+#include "hash.h"
+
+constexpr int KM_THREADS = 256;
+
+// delta for offset index k, in units of ts (first spatial dimension fastest)
+template <int D>
+__device__ __forceinline__ void offset_of(int k, int ks, int ts, int32_t *delta) {
+  const int half = ks >> 1;
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    delta[d] = ((k % ks) - half) * ts;
+    k /= ks;
+  }
+}
+
+template <int D>
+__device__ __forceinline__ int probe(const int32_t *__restrict__ out_coords, int64_t o,
+                                     const int32_t *delta, const int32_t *__restrict__ in_coords,
+                                     const int32_t *__restrict__ in_table, uint32_t in_mask) {
+  constexpr int NC = D + 1;
+  int32_t q[NC];
+  q[0] = out_coords[o * NC];
+#pragma unroll
+  for (int d = 0; d < D; ++d) q[1 + d] = out_coords[o * NC + 1 + d] + delta[d];
+  return dgr_lookup<NC>(in_table, in_mask, in_coords, q);
+}
+
+// grid = (row blocks, K).  block_counts[k * RB + rb] = hits of offset k among rows of block rb.
+template <int D>
+__global__ void __launch_bounds__(KM_THREADS)
+    kmap_count(const int32_t *__restrict__ out_coords, const int32_t *n_out_dev,
+               const int32_t *__restrict__ in_coords, const int32_t *__restrict__ in_table,
+               uint32_t in_mask, int ks, int ts_in, int RB, int32_t *__restrict__ block_counts) {
+  __shared__ int wave_cnt[KM_THREADS / 64];
+  const int rb = blockIdx.x, k = blockIdx.y;
+  const int n_out = *n_out_dev;
+  if (rb * KM_THREADS >= n_out) {
+    if (threadIdx.x == 0) block_counts[(int64_t)k * RB + rb] = 0;
+    return;
+  }
+  int32_t delta[D];
+  offset_of<D>(k, ks, ts_in, delta);
+  const int64_t o = (int64_t)rb * KM_THREADS + threadIdx.x;
+  int hit = -1;
+  if (o < n_out) hit = probe<D>(out_coords, o, delta, in_coords, in_table, in_mask);
+  unsigned long long m = __ballot(hit >= 0);
+  if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int s = 0;
+#pragma unroll
+    for (int w = 0; w < KM_THREADS / 64; ++w) s += wave_cnt[w];
+    block_counts[(int64_t)k * RB + rb] = s;
+  }
+}
+
+template <int D>
+__global__ void __launch_bounds__(KM_THREADS)
+    kmap_fill(const int32_t *__restrict__ out_coords, const int32_t *n_out_dev,
+              const int32_t *__restrict__ in_coords, const int32_t *__restrict__ in_table,
+              uint32_t in_mask, int ks, int ts_in, int RB, const int32_t *__restrict__ block_base,
+              int32_t *__restrict__ pair_in, int32_t *__restrict__ pair_out, int64_t pair_cap,
+              int32_t *overflow) {
+  __shared__ int wave_cnt[KM_THREADS / 64];
+  const int rb = blockIdx.x, k = blockIdx.y;
+  const int n_out = *n_out_dev;
+  if (rb * KM_THREADS >= n_out) return;
+  int32_t delta[D];
+  offset_of<D>(k, ks, ts_in, delta);
+  const int64_t o = (int64_t)rb * KM_THREADS + threadIdx.x;
+  int hit = -1;
+  if (o < n_out) hit = probe<D>(out_coords, o, delta, in_coords, in_table, in_mask);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long m = __ballot(hit >= 0);
+  if (lane == 0) wave_cnt[wave] = __popcll(m);
+  __syncthreads();
+  if (hit >= 0) {
+    int base = block_base[(int64_t)k * RB + rb];
+    for (int w = 0; w < wave; ++w) base += wave_cnt[w];
+    int64_t pos = base + __popcll(m & ((1ull << lane) - 1ull));
+    if (pos < pair_cap) {
+      pair_in[pos] = hit;
+      pair_out[pos] = (int32_t)o;
+    } else {
+      *overflow = 2;
+    }
+  }
+}
+
+// rule_ptr[k] = block_base[k * RB], rule_ptr[K] = total; tile_ptr = exclusive scan of
+// ceil(P_k / TILE_M).  One block, K <= 1024.
+__global__ void __launch_bounds__(1024)
+    kmap_finalize(const int32_t *__restrict__ block_base, const int32_t *__restrict__ total, int K,
+                  int RB, int32_t *__restrict__ rule_ptr, int32_t *__restrict__ tile_ptr) {
+  __shared__ int s[1024];
+  const int k = threadIdx.x;
+  int start = 0, end = 0;
+  if (k < K) {
+    start = block_base[(int64_t)k * RB];
+    end = (k + 1 < K) ? block_base[(int64_t)(k + 1) * RB] : *total;
+    rule_ptr[k] = start;
+    if (k == K - 1) rule_ptr[K] = end;
+  }
+  int tiles = (end - start + DGR_TILE_M - 1) / DGR_TILE_M;
+  s[k] = tiles;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    int v = (k >= d) ? s[k - d] : 0;
+    __syncthreads();
+    s[k] += v;
+    __syncthreads();
+  }
+  if (k < K) tile_ptr[k] = s[k] - tiles;
+  if (k == K - 1) tile_ptr[K] = s[k];
+}
+
+template <int D>
+static int build_kernel_map_t(DgrArena &arena, const DgrCoordMap &in, const DgrCoordMap &out, int ks,
+                              int max_pairs_per_row, DgrKernelMap *km, int32_t *overflow,
+                              hipStream_t stream) {
+  int K = 1;
+  for (int d = 0; d < D; ++d) K *= ks;
+  DGR_REQUIRE(K <= 1024, "kernel volume %d > 1024 not supported", K);
+  km->K = K;
+  const int64_t n_cap = out.n_cap;
+  const int RB = (int)dgr_ceil_div(n_cap, KM_THREADS);
+  int64_t per_row = K < max_pairs_per_row ? K : max_pairs_per_row;
+  km->pair_cap = per_row * n_cap;
+  DGR_REQUIRE(km->pair_cap < (1ll << 31), "kernel map too large (%lld pairs)", (long long)km->pair_cap);
+  int32_t *counts, *base, *total;
+  DGR_ALLOC(counts, arena, int32_t, (int64_t)K * RB);
+  DGR_ALLOC(base, arena, int32_t, (int64_t)K * RB);
+  DGR_ALLOC(total, arena, int32_t, 1);
+  DGR_ALLOC(km->rule_ptr, arena, int32_t, K + 1);
+  DGR_ALLOC(km->tile_ptr, arena, int32_t, K + 1);
+  DGR_ALLOC(km->pair_in, arena, int32_t, km->pair_cap);
+  DGR_ALLOC(km->pair_out, arena, int32_t, km->pair_cap);
+  dim3 grid(RB, K);
+  kmap_count<D><<<grid, KM_THREADS, 0, stream>>>(out.coords, out.n_dev, in.coords, in.table,
+                                                 in.table_mask, ks, in.ts, RB, counts);
+  DGR_LAUNCH_CHECK();
+  DGR_CHECK(dgr_exclusive_scan_i32(arena, counts, base, (int64_t)K * RB, total, stream));
+  kmap_finalize<<<1, 1024, 0, stream>>>(base, total, K, RB, km->rule_ptr, km->tile_ptr);
+  kmap_fill<D><<<grid, KM_THREADS, 0, stream>>>(out.coords, out.n_dev, in.coords, in.table,
+                                                in.table_mask, ks, in.ts, RB, base, km->pair_in,
+                                                km->pair_out, km->pair_cap, overflow);
+  DGR_LAUNCH_CHECK();
+  km->built = true;
+  return DGR_OK;
+}
+
+int dgr_build_coord_maps(DgrArena &arena, const int32_t *coords, int64_t N, DgrMapSet *ms,
+                         hipStream_t stream);
+
+int dgr_build_maps(DgrArena &arena, const int32_t *coords, int64_t N, int D, int conv1_ks,
+                   DgrMapSet *ms, hipStream_t stream) {
+  DGR_REQUIRE(D == 3 || D == 6, "D=%d not supported (the DGR path uses D=3 and D=6)", D);
+  DGR_REQUIRE(conv1_ks % 2 == 1 && conv1_ks >= 1, "conv1 kernel size must be odd");
+  DGR_REQUIRE(N > 0 && N < (1ll << 30), "N=%lld out of range", (long long)N);
+  ms->D = D;
+  ms->nc = D + 1;
+  ms->conv1_ks = conv1_ks;
+  if (!ms->overflow) {  // callers may pre-set a flag word that outlives arena rewinds
+    DGR_ALLOC(ms->overflow, arena, int32_t, 1);
+    DGR_HIP_CHECK(hipMemsetAsync(ms->overflow, 0, sizeof(int32_t), stream));
+  }
+  DGR_CHECK(dgr_build_coord_maps(arena, coords, N, ms, stream));
+  // capacity per output row: exact (K) in 3-D; in 6-D 3^6 = 729 offsets but measured mean
+  // occupancy is 2..40 neighbours -- reserve 160 per row and raise the overflow flag beyond.
+  const int cap_row = (D == 3) ? 1024 : 160;
+  for (int l = 0; l < 4; ++l) {
+    if (D == 3)
+      DGR_CHECK(build_kernel_map_t<3>(arena, ms->cm[l], ms->cm[l], 3, cap_row, &ms->same[l],
+                                      ms->overflow, stream));
+    else
+      DGR_CHECK(build_kernel_map_t<6>(arena, ms->cm[l], ms->cm[l], 3, cap_row, &ms->same[l],
+                                      ms->overflow, stream));
+  }
+  if (conv1_ks == 3) {
+    ms->conv1 = ms->same[0];
+  } else if (D == 3) {
+    DGR_CHECK(build_kernel_map_t<3>(arena, ms->cm[0], ms->cm[0], conv1_ks, cap_row, &ms->conv1,
+                                    ms->overflow, stream));
+  } else {
+    DGR_CHECK(build_kernel_map_t<6>(arena, ms->cm[0], ms->cm[0], conv1_ks, cap_row, &ms->conv1,
+                                    ms->overflow, stream));
+  }
+  for (int l = 0; l < 3; ++l) {
+    if (D == 3)
+      DGR_CHECK(build_kernel_map_t<3>(arena, ms->cm[l], ms->cm[l + 1], 3, cap_row, &ms->down[l],
+                                      ms->overflow, stream));
+    else
+      DGR_CHECK(build_kernel_map_t<6>(arena, ms->cm[l], ms->cm[l + 1], 3, cap_row, &ms->down[l],
+                                      ms->overflow, stream));
+  }
+  return DGR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// stand-alone maps object (inspection / parity tests)
+// ------------------------------------------------------------------------------------------
+struct dgr_maps {
+  dgr_ctx *ctx;
+  DgrArena arena;  // private arena so the maps survive other calls on the ctx
+  DgrMapSet ms;
+  int32_t *coords_copy = nullptr;
+  hipStream_t stream;
+};
+
+extern "C" int dgr_maps_create(dgr_ctx *ctx, const int32_t *coords, int64_t N, int D,
+                               int conv1_kernel_size, dgr_maps **out, dgr_stream stream_) {
+  DGR_REQUIRE(ctx && coords && out, "dgr_maps_create: NULL argument");
+  hipStream_t stream = (hipStream_t)stream_;
+  DGR_HIP_CHECK(hipSetDevice(ctx->device));
+  dgr_maps *m = new dgr_maps();
+  m->ctx = ctx;
+  m->stream = stream;
+  int rc = DGR_OK;
+  do {
+    m->coords_copy = m->arena.get<int32_t>((size_t)N * (D + 1));
+    if (!m->coords_copy) { rc = DGR_ENOMEM; break; }
+    if (hipMemcpyAsync(m->coords_copy, coords, (size_t)N * (D + 1) * sizeof(int32_t),
+                       hipMemcpyDeviceToDevice, stream) != hipSuccess) { rc = DGR_EHIP; break; }
+    rc = dgr_build_maps(m->arena, m->coords_copy, N, D, conv1_kernel_size, &m->ms, stream);
+    if (rc != DGR_OK) break;
+    int32_t flag = 0;
+    if (hipMemcpyAsync(&flag, m->ms.overflow, sizeof(int32_t), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+        hipStreamSynchronize(stream) != hipSuccess) { rc = DGR_EHIP; dgr_set_error("maps sync failed"); break; }
+    if (flag == 1) { dgr_set_error("duplicate coordinates in the sparse tensor input"); rc = DGR_EINVAL; break; }
+    if (flag == 2) { dgr_set_error("kernel-map capacity exceeded"); rc = DGR_ENOMEM; break; }
+  } while (0);
+  if (rc != DGR_OK) {
+    m->arena.release();
+    delete m;
+    return rc;
+  }
+  *out = m;
+  return DGR_OK;
+}
+
+extern "C" void dgr_maps_destroy(dgr_maps *m) {
+  if (!m) return;
+  (void)hipDeviceSynchronize();
+  m->arena.release();
+  delete m;
+}
+
+static int level_of(int ts) { return ts == 1 ? 0 : ts == 2 ? 1 : ts == 4 ? 2 : ts == 8 ? 3 : -1; }
+
+extern "C" int dgr_maps_get_coords(dgr_maps *m, int ts, int32_t *host_out, int64_t capacity,
+                                   int64_t *n) {
+  DGR_REQUIRE(m && n, "NULL argument");
+  int l = level_of(ts);
+  DGR_REQUIRE(l >= 0, "tensor stride %d not in {1,2,4,8}", ts);
+  int32_t n32 = 0;
+  DGR_HIP_CHECK(hipMemcpy(&n32, m->ms.cm[l].n_dev, sizeof(int32_t), hipMemcpyDeviceToHost));
+  *n = n32;
+  if (host_out) {
+    DGR_REQUIRE(capacity >= (int64_t)n32 * m->ms.nc, "host buffer too small");
+    DGR_HIP_CHECK(hipMemcpy(host_out, m->ms.cm[l].coords, (size_t)n32 * m->ms.nc * sizeof(int32_t),
+                            hipMemcpyDeviceToHost));
+  }
+  return DGR_OK;
+}
+
+extern "C" int dgr_maps_get_kernel_map(dgr_maps *m, int kind, int ts, int32_t *rule_ptr,
+                                       int64_t rule_cap, int32_t *pair_in, int32_t *pair_out,
+                                       int64_t pair_cap, int64_t *K, int64_t *P) {
+  DGR_REQUIRE(m && K && P, "NULL argument");
+  int l = level_of(ts);
+  DGR_REQUIRE(l >= 0, "tensor stride %d not in {1,2,4,8}", ts);
+  const DgrKernelMap *km = nullptr;
+  if (kind == 0) km = &m->ms.same[l];
+  else if (kind == 1) km = &m->ms.conv1;
+  else if (kind == 2 && l < 3) km = &m->ms.down[l];
+  DGR_REQUIRE(km && km->built, "no such kernel map (kind %d, ts %d)", kind, ts);
+  *K = km->K;
+  int32_t total = 0;
+  DGR_HIP_CHECK(hipMemcpy(&total, km->rule_ptr + km->K, sizeof(int32_t), hipMemcpyDeviceToHost));
+  *P = total;
+  if (rule_ptr) {
+    DGR_REQUIRE(rule_cap >= km->K + 1, "rule_ptr buffer too small");
+    DGR_HIP_CHECK(hipMemcpy(rule_ptr, km->rule_ptr, (size_t)(km->K + 1) * sizeof(int32_t),
+                            hipMemcpyDeviceToHost));
+  }
+  if (pair_in && pair_out) {
+    DGR_REQUIRE(pair_cap >= total, "pair buffers too small");
+    DGR_HIP_CHECK(hipMemcpy(pair_in, km->pair_in, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost));
+    DGR_HIP_CHECK(hipMemcpy(pair_out, km->pair_out, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost));
+  }
+  return DGR_OK;
+}

@@ -1,0 +1,425 @@
+// ResUNetBN2C (3-D FCGF net and 6-D inlier net) on top of the sparse-conv kernel.
+// Replaces model.load_model('ResUNetBN2C')(...) + load_state_dict + eval + forward:
+// constructor model/resunet.py:428-596, channel tables :662-665, forward :598-649, residual block
+// model/residual_block.py:83-134, eval batch norm model/common.py:11-21.
+//
+// Load time: eval-mode batch norm is folded into the kernels (scale) and a per-channel shift; the
+// kernels are re-tiled into the MFMA B-operand order documented in conv.hip.
+// Forward: every conv is [init rows with shift (+ residual)] + [sparse_conv_mfma accumulating
+// with atomics].  ReLU is never a separate pass: a tensor carries a "ReLU pending" flag and the
+// consumer applies max(x,0) while gathering.  ME.cat is free: producers write into column ranges
+// of a pre-concatenated buffer (row stride = total channels).
+#include <math.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+
+#include "dgr_internal.h"
+
+static const int CH[5] = {0, 32, 64, 128, 256};     // model/resunet.py:664
+static const int TR[5] = {0, 64, 64, 64, 128};      // model/resunet.py:665
+static constexpr float BN_EPS = 1e-5f;
+
+struct DgrLayer {
+  std::string name;
+  int K, cin, cout, cin_pad, cout_pad;
+  float *w = nullptr;      // device, tiled
+  float *shift = nullptr;  // device [cout] or nullptr
+};
+
+struct LayerRun {  // bookkeeping of the last forward, for dgr_net_layer_stats
+  const int32_t *rule_ptr = nullptr;
+  const int32_t *n_in = nullptr, *n_out = nullptr;
+  int K = 1;
+};
+
+struct DgrTensorRef {
+  const float *ptr = nullptr;
+  int ld = 0, cols = 0;
+  const int32_t *n_dev = nullptr;
+};
+
+struct dgr_net {
+  dgr_ctx *ctx;
+  int D, cin, cout, conv1_ks, normalize;
+  std::vector<DgrLayer> layers;  // 23 convs in forward order
+  int64_t param_bytes = 0;
+  LayerRun runs[23];
+  std::map<std::string, DgrTensorRef> inter;
+};
+
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+static const dgr_weight_desc *find_desc(const dgr_weight_desc *w, int n, const std::string &name) {
+  for (int i = 0; i < n; ++i)
+    if (name == w[i].name) return &w[i];
+  return nullptr;
+}
+
+static int make_layer(dgr_net *net, const dgr_weight_desc *descs, int nd, const std::string &name, int K,
+                      int cin, int cout, const char *bn, bool bias) {
+  DgrLayer L;
+  L.name = name;
+  L.K = K; L.cin = cin; L.cout = cout;
+  L.cin_pad = round_up(cin, 8);
+  L.cout_pad = cout <= 32 ? 32 : cout <= 64 ? 64 : cout <= 128 ? 128 : 256;
+  DGR_REQUIRE(cout <= 256 && cin <= 256, "%s: channel count above 256 not supported", name.c_str());
+  const dgr_weight_desc *kd = find_desc(descs, nd, name + ".kernel");
+  DGR_REQUIRE(kd != nullptr, "state_dict is missing '%s.kernel'", name.c_str());
+  // kernel-volume-1 convs are stored [Cin,Cout] by ME 0.5.x and [1,Cin,Cout] by 0.4-era checkpoints
+  DGR_REQUIRE(kd->numel == (int64_t)K * cin * cout, "'%s.kernel' has %lld elements, expected %d x %d x %d",
+              name.c_str(), (long long)kd->numel, K, cin, cout);
+  std::vector<float> scale(cout, 1.f), shift(cout, 0.f);
+  bool has_shift = false;
+  if (bn) {
+    std::string p = std::string(bn) + ".bn.";
+    const dgr_weight_desc *g = find_desc(descs, nd, p + "weight"), *b = find_desc(descs, nd, p + "bias"),
+                          *m = find_desc(descs, nd, p + "running_mean"),
+                          *v = find_desc(descs, nd, p + "running_var");
+    DGR_REQUIRE(g && b && m && v, "state_dict is missing batch-norm tensors '%s*'", p.c_str());
+    DGR_REQUIRE(g->numel == cout && b->numel == cout && m->numel == cout && v->numel == cout,
+                "batch-norm '%s' has the wrong width", p.c_str());
+    for (int c = 0; c < cout; ++c) {
+      float s = g->data[c] / sqrtf(v->data[c] + BN_EPS);
+      scale[c] = s;
+      shift[c] = b->data[c] - m->data[c] * s;
+    }
+    has_shift = true;
+  }
+  if (bias) {
+    const dgr_weight_desc *bd = find_desc(descs, nd, name + ".bias");
+    DGR_REQUIRE(bd && bd->numel == cout, "state_dict is missing '%s.bias' [1,%d]", name.c_str(), cout);
+    for (int c = 0; c < cout; ++c) shift[c] += bd->data[c];
+    has_shift = true;
+  }
+  const int S = L.cin_pad / 8, NBLK = L.cout_pad / 32;
+  const size_t per_k = (size_t)S * NBLK * 256;
+  std::vector<float> tiled((size_t)K * per_k);
+  for (int k = 0; k < K; ++k) {
+    const float *src = kd->data + (size_t)k * cin * cout;
+    float *dst = tiled.data() + (size_t)k * per_k;
+    for (int s = 0; s < S; ++s)
+      for (int nb = 0; nb < NBLK; ++nb)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int col = 32 * nb + (lane & 31);
+          float *d = dst + ((size_t)(s * NBLK + nb) * 64 + lane) * 4;
+          for (int c = 0; c < 4; ++c) {
+            const int row = 8 * s + 4 * (lane >> 5) + c;
+            d[c] = (row < cin && col < cout) ? src[(size_t)row * cout + col] * scale[col] : 0.f;
+          }
+        }
+  }
+  DGR_HIP_CHECK(hipMalloc((void **)&L.w, tiled.size() * sizeof(float)));
+  DGR_HIP_CHECK(hipMemcpy(L.w, tiled.data(), tiled.size() * sizeof(float), hipMemcpyHostToDevice));
+  net->param_bytes += tiled.size() * sizeof(float);
+  if (has_shift) {
+    DGR_HIP_CHECK(hipMalloc((void **)&L.shift, cout * sizeof(float)));
+    DGR_HIP_CHECK(hipMemcpy(L.shift, shift.data(), cout * sizeof(float), hipMemcpyHostToDevice));
+  }
+  net->layers.push_back(L);
+  return DGR_OK;
+}
+
+extern "C" int dgr_net_create(dgr_ctx *ctx, int D, int in_channels, int out_channels,
+                              int conv1_kernel_size, int normalize_feature,
+                              const dgr_weight_desc *weights, int n_weights, dgr_net **out) {
+  DGR_REQUIRE(ctx && weights && out, "dgr_net_create: NULL argument");
+  DGR_REQUIRE(D == 3 || D == 6, "dgr_net_create: D=%d (ResUNetBN2C is used with D=3 and D=6)", D);
+  DGR_REQUIRE(in_channels >= 1 && in_channels <= 256 && out_channels >= 1 && out_channels <= 64,
+              "dgr_net_create: unsupported channel counts in=%d out=%d", in_channels, out_channels);
+  DGR_REQUIRE(conv1_kernel_size % 2 == 1, "conv1 kernel size must be odd");
+  DGR_HIP_CHECK(hipSetDevice(ctx->device));
+  dgr_net *net = new dgr_net();
+  net->ctx = ctx;
+  net->D = D; net->cin = in_channels; net->cout = out_channels;
+  net->conv1_ks = conv1_kernel_size; net->normalize = normalize_feature;
+  int k3 = 1, k1 = 1;
+  for (int d = 0; d < D; ++d) { k3 *= 3; k1 *= conv1_kernel_size; }
+  int rc = DGR_OK;
+  auto L = [&](const std::string &name, int K, int ci, int co, const char *bn, bool bias = false) {
+    if (rc == DGR_OK) rc = make_layer(net, weights, n_weights, name, K, ci, co, bn, bias);
+  };
+  auto block = [&](const std::string &b, int c) {
+    L(b + ".conv1", k3, c, c, (b + ".norm1").c_str());
+    L(b + ".conv2", k3, c, c, (b + ".norm2").c_str());
+  };
+  L("conv1", k1, in_channels, CH[1], "norm1");          block("block1", CH[1]);
+  L("conv2", k3, CH[1], CH[2], "norm2");                block("block2", CH[2]);
+  L("conv3", k3, CH[2], CH[3], "norm3");                block("block3", CH[3]);
+  L("conv4", k3, CH[3], CH[4], "norm4");                block("block4", CH[4]);
+  L("conv4_tr", k3, CH[4], TR[4], "norm4_tr");          block("block4_tr", TR[4]);
+  L("conv3_tr", k3, CH[3] + TR[4], TR[3], "norm3_tr");  block("block3_tr", TR[3]);
+  L("conv2_tr", k3, CH[2] + TR[3], TR[2], "norm2_tr");  block("block2_tr", TR[2]);
+  L("conv1_tr", 1, CH[1] + TR[2], TR[1], nullptr);      // no bias, no BN: residual_block.py:38-44
+  L("final", 1, TR[1], out_channels, nullptr, true);    // the only bias: resunet.py:589-596
+  if (rc != DGR_OK) {
+    dgr_net_destroy(net);
+    return rc;
+  }
+  *out = net;
+  return DGR_OK;
+}
+
+extern "C" void dgr_net_destroy(dgr_net *net) {
+  if (!net) return;
+  (void)hipDeviceSynchronize();
+  for (auto &l : net->layers) {
+    if (l.w) (void)hipFree(l.w);
+    if (l.shift) (void)hipFree(l.shift);
+  }
+  delete net;
+}
+
+extern "C" int64_t dgr_net_param_bytes(const dgr_net *net) { return net ? net->param_bytes : 0; }
+extern "C" int dgr_net_num_layers(const dgr_net *net) { return net ? (int)net->layers.size() : 0; }
+
+// ------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------
+struct Tensor {
+  float *ptr;
+  int ld;
+  int relu;  // consumers must apply ReLU when reading
+};
+
+struct Fwd {
+  dgr_ctx *ctx;
+  dgr_net *net;
+  hipStream_t stream;
+  DgrMapSet ms;
+  bool prof;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> spans;
+
+  // one conv: out = shift (+res) ; out += sum_k in[.] W[k]
+  int conv(int li, const Tensor &in, const DgrKernelMap *km, bool swapped, int lvl_in, int lvl_out,
+           const Tensor &out, const Tensor *res) {
+    const DgrLayer &L = net->layers[li];
+    const DgrCoordMap &cin_map = ms.cm[lvl_in], &cout_map = ms.cm[lvl_out];
+    DGR_CHECK(dgr_init_rows(out.ptr, out.ld, L.cout, L.shift, res ? res->ptr : nullptr, res ? res->ld : 0,
+                            res ? res->relu : 0, cout_map.n_dev, cout_map.n_cap, stream));
+    DgrConvLaunch a;
+    a.in = in.ptr; a.in_ld = in.ld; a.in_relu = in.relu;
+    a.out = out.ptr; a.out_ld = out.ld;
+    a.w = L.w;
+    a.cin = L.cin; a.cin_pad = L.cin_pad; a.cout = L.cout; a.cout_pad = L.cout_pad; a.K = L.K;
+    if (km) {
+      a.pair_in = swapped ? km->pair_out : km->pair_in;
+      a.pair_out = swapped ? km->pair_in : km->pair_out;
+      a.tile_ptr = km->tile_ptr; a.rule_ptr = km->rule_ptr;
+      a.n_rows_dev = nullptr;
+      a.tile_bound = km->pair_cap / DGR_TILE_M + km->K;
+      DGR_REQUIRE(km->K == L.K, "layer %s: kernel volume mismatch", L.name.c_str());
+    } else {
+      a.pair_in = a.pair_out = a.tile_ptr = a.rule_ptr = nullptr;
+      a.n_rows_dev = cout_map.n_dev;
+      a.tile_bound = dgr_ceil_div(cout_map.n_cap, DGR_TILE_M);
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (prof) {
+      e0 = ctx->events.next(); e1 = ctx->events.next();
+      if (!e0 || !e1) return DGR_EHIP;
+      DGR_HIP_CHECK(hipEventRecord(e0, stream));
+    }
+    DGR_CHECK(dgr_conv_launch(a, ctx->num_cus, stream));
+    if (prof) {
+      DGR_HIP_CHECK(hipEventRecord(e1, stream));
+      spans.push_back({e0, e1});
+    }
+    LayerRun &r = net->runs[li];
+    r.rule_ptr = km ? km->rule_ptr : nullptr;
+    r.n_in = cin_map.n_dev; r.n_out = cout_map.n_dev; r.K = L.K;
+    return DGR_OK;
+  }
+};
+
+int dgr_resunet_forward_impl(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, const float *feats,
+                             int64_t N, float *out, hipStream_t stream, float *maps_ms,
+                             float *conv_ms) {
+  DgrArena &A = ctx->arena;
+  Fwd f;
+  f.ctx = ctx; f.net = net; f.stream = stream; f.prof = ctx->profiling;
+  hipEvent_t m0 = nullptr, m1 = nullptr;
+  if (f.prof) {
+    m0 = ctx->events.next(); m1 = ctx->events.next();
+    DGR_HIP_CHECK(hipEventRecord(m0, stream));
+  }
+  f.ms.overflow = ctx->flag_dev;
+  DGR_CHECK(dgr_build_maps(A, coords, N, net->D, net->conv1_ks, &f.ms, stream));
+  if (f.prof) DGR_HIP_CHECK(hipEventRecord(m1, stream));
+  const DgrMapSet &ms = f.ms;
+  const int64_t n1 = ms.cm[0].n_cap, n2 = ms.cm[1].n_cap, n4 = ms.cm[2].n_cap, n8 = ms.cm[3].n_cap;
+  auto buf = [&](int64_t rows, int cols) -> float * { return A.get<float>((size_t)rows * cols); };
+  // activations (names follow model/resunet.py:598-649)
+  float *t1 = buf(n1, 32), *y1 = buf(n1, 32), *cat1 = buf(n1, 96);
+  float *t2 = buf(n2, 64), *y2 = buf(n2, 64), *cat2 = buf(n2, 128);
+  float *t4 = buf(n4, 128), *y4 = buf(n4, 128), *cat4 = buf(n4, 256);
+  float *t8 = buf(n8, 256), *y8 = buf(n8, 256), *s8 = buf(n8, 256);
+  float *u4 = buf(n4, 128), *v4 = buf(n4, 128);
+  float *u2 = buf(n2, 64), *v2 = buf(n2, 64);
+  float *u1 = buf(n1, 64), *v1 = buf(n1, 64);
+  float *h = buf(n1, 64);
+  float *fin = net->normalize ? buf(n1, net->cout) : out;
+  if (!t1 || !y1 || !cat1 || !t2 || !y2 || !cat2 || !t4 || !y4 || !cat4 || !t8 || !y8 || !s8 || !u4 ||
+      !v4 || !u2 || !v2 || !u1 || !v1 || !h || !fin)
+    return DGR_ENOMEM;
+
+  const Tensor X{const_cast<float *>(feats), net->cin, 0};
+  const Tensor T1{t1, 32, 0}, Y1{y1, 32, 1}, S1{cat1 + 64, 96, 1};
+  const Tensor T2{t2, 64, 0}, Y2{y2, 64, 1}, S2{cat2 + 64, 128, 1};
+  const Tensor T4{t4, 128, 0}, Y4{y4, 128, 1}, S4{cat4 + 128, 256, 1};
+  const Tensor T8{t8, 256, 0}, Y8{y8, 256, 1}, S8{s8, 256, 1};
+  const Tensor U4{u4, 128, 0}, V4{v4, 128, 1}, S4T{cat4, 256, 1};
+  const Tensor U2{u2, 64, 0}, V2{v2, 64, 1}, S2T{cat2, 128, 1};
+  const Tensor U1{u1, 64, 0}, V1{v1, 64, 1}, S1T{cat1, 96, 1};
+  const Tensor H{h, 64, 1}, FIN{fin, net->cout, 0};
+
+  int li = 0;
+  // encoder
+  DGR_CHECK(f.conv(li++, X, &ms.conv1, false, 0, 0, T1, nullptr));     // conv1 + norm1
+  DGR_CHECK(f.conv(li++, T1, &ms.same[0], false, 0, 0, Y1, nullptr));  // block1
+  DGR_CHECK(f.conv(li++, Y1, &ms.same[0], false, 0, 0, S1, &T1));
+  DGR_CHECK(f.conv(li++, S1, &ms.down[0], false, 0, 1, T2, nullptr));  // conv2 (stride 2) + norm2
+  DGR_CHECK(f.conv(li++, T2, &ms.same[1], false, 1, 1, Y2, nullptr));  // block2
+  DGR_CHECK(f.conv(li++, Y2, &ms.same[1], false, 1, 1, S2, &T2));
+  DGR_CHECK(f.conv(li++, S2, &ms.down[1], false, 1, 2, T4, nullptr));  // conv3
+  DGR_CHECK(f.conv(li++, T4, &ms.same[2], false, 2, 2, Y4, nullptr));  // block3
+  DGR_CHECK(f.conv(li++, Y4, &ms.same[2], false, 2, 2, S4, &T4));
+  DGR_CHECK(f.conv(li++, S4, &ms.down[2], false, 2, 3, T8, nullptr));  // conv4
+  DGR_CHECK(f.conv(li++, T8, &ms.same[3], false, 3, 3, Y8, nullptr));  // block4
+  DGR_CHECK(f.conv(li++, Y8, &ms.same[3], false, 3, 3, S8, &T8));
+  // decoder: transposed convs reuse the strided maps with in/out swapped
+  DGR_CHECK(f.conv(li++, S8, &ms.down[2], true, 3, 2, U4, nullptr));   // conv4_tr + norm4_tr
+  DGR_CHECK(f.conv(li++, U4, &ms.same[2], false, 2, 2, V4, nullptr));  // block4_tr
+  DGR_CHECK(f.conv(li++, V4, &ms.same[2], false, 2, 2, S4T, &U4));     // -> cat4[:, :128]
+  const Tensor CAT4{cat4, 256, 1};
+  DGR_CHECK(f.conv(li++, CAT4, &ms.down[1], true, 2, 1, U2, nullptr));  // conv3_tr
+  DGR_CHECK(f.conv(li++, U2, &ms.same[1], false, 1, 1, V2, nullptr));   // block3_tr
+  DGR_CHECK(f.conv(li++, V2, &ms.same[1], false, 1, 1, S2T, &U2));
+  const Tensor CAT2{cat2, 128, 1};
+  DGR_CHECK(f.conv(li++, CAT2, &ms.down[0], true, 1, 0, U1, nullptr));  // conv2_tr
+  DGR_CHECK(f.conv(li++, U1, &ms.same[0], false, 0, 0, V1, nullptr));   // block2_tr
+  DGR_CHECK(f.conv(li++, V1, &ms.same[0], false, 0, 0, S1T, &U1));
+  const Tensor CAT1{cat1, 96, 1};
+  DGR_CHECK(f.conv(li++, CAT1, nullptr, false, 0, 0, H, nullptr));      // conv1_tr (k=1), ReLU pending
+  DGR_CHECK(f.conv(li++, H, nullptr, false, 0, 0, FIN, nullptr));       // final (k=1) + bias
+  if (net->normalize)
+    DGR_CHECK(dgr_l2_normalize_rows(fin, net->cout, out, net->cout, net->cout, 0, ms.cm[0].n_dev, n1, stream));
+
+  auto &I = net->inter;
+  I.clear();
+  I["s1"] = {S1.ptr, 96, 32, ms.cm[0].n_dev};
+  I["s2"] = {S2.ptr, 128, 64, ms.cm[1].n_dev};
+  I["s4"] = {S4.ptr, 256, 128, ms.cm[2].n_dev};
+  I["s8"] = {S8.ptr, 256, 256, ms.cm[3].n_dev};
+  I["s4_tr"] = {cat4, 256, 128, ms.cm[2].n_dev};
+  I["s2_tr"] = {cat2, 128, 64, ms.cm[1].n_dev};
+  I["s1_tr"] = {cat1, 96, 64, ms.cm[0].n_dev};
+
+  if (f.prof) {
+    DGR_HIP_CHECK(hipStreamSynchronize(stream));
+    float ms_maps = 0.f, ms_conv = 0.f, t = 0.f;
+    DGR_HIP_CHECK(hipEventElapsedTime(&ms_maps, m0, m1));
+    for (auto &sp : f.spans) {
+      DGR_HIP_CHECK(hipEventElapsedTime(&t, sp.first, sp.second));
+      ms_conv += t;
+    }
+    if (maps_ms) *maps_ms += ms_maps;
+    if (conv_ms) *conv_ms += ms_conv;
+    ctx->conv_launches += (int64_t)f.spans.size();
+  }
+  return DGR_OK;
+}
+
+static int check_flag(dgr_ctx *ctx, const int32_t *flag_dev, hipStream_t stream) {
+  int32_t flag = 0;
+  DGR_HIP_CHECK(hipMemcpyAsync(&flag, flag_dev, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  DGR_HIP_CHECK(hipStreamSynchronize(stream));
+  if (flag == 1) {
+    dgr_set_error("duplicate coordinates in the sparse tensor input");
+    return DGR_EINVAL;
+  }
+  if (flag == 2) {
+    dgr_set_error("kernel-map capacity exceeded (more than the reserved pairs per output row)");
+    return DGR_ENOMEM;
+  }
+  return DGR_OK;
+}
+
+int dgr_ctx_new_flag(dgr_ctx *ctx, hipStream_t stream) {
+  DGR_ALLOC(ctx->flag_dev, ctx->arena, int32_t, 1);
+  DGR_HIP_CHECK(hipMemsetAsync(ctx->flag_dev, 0, sizeof(int32_t), stream));
+  return DGR_OK;
+}
+
+int dgr_ctx_check_flag(dgr_ctx *ctx, hipStream_t stream) {
+  if (!ctx->flag_dev) return DGR_OK;
+  return check_flag(ctx, ctx->flag_dev, stream);
+}
+
+int dgr_net_out_channels(const dgr_net *net) { return net->cout; }
+int dgr_net_in_channels(const dgr_net *net) { return net->cin; }
+int dgr_net_dim(const dgr_net *net) { return net->D; }
+
+extern "C" int dgr_resunet_forward(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, const float *feats,
+                                   int64_t N, float *out, dgr_stream stream_) {
+  DGR_REQUIRE(ctx && net && coords && feats && out, "dgr_resunet_forward: NULL argument");
+  DGR_REQUIRE(N > 0, "dgr_resunet_forward: empty sparse tensor (N=%lld)", (long long)N);
+  hipStream_t stream = (hipStream_t)stream_;
+  DGR_HIP_CHECK(hipSetDevice(ctx->device));
+  DGR_CHECK(ctx->arena.reset());
+  DGR_CHECK(dgr_ctx_new_flag(ctx, stream));
+  ctx->events.used = 0;
+  float maps_ms = 0.f, conv_ms = 0.f;
+  if (ctx->profiling) ctx->conv_launches = 0;
+  DGR_CHECK(dgr_resunet_forward_impl(ctx, net, coords, feats, N, out, stream, &maps_ms, &conv_ms));
+  if (ctx->profiling) {
+    memset(ctx->stage_ms, 0, sizeof(ctx->stage_ms));
+    ctx->stage_ms[net->D == 3 ? 5 : 6] = maps_ms;
+    ctx->stage_ms[7] = conv_ms;
+  }
+  return dgr_ctx_check_flag(ctx, stream);
+}
+
+extern "C" int dgr_net_get_intermediate(dgr_ctx *ctx, dgr_net *net, const char *name, float *host_out,
+                                        int64_t capacity, int64_t *rows, int64_t *cols) {
+  DGR_REQUIRE(ctx && net && name && rows && cols, "NULL argument");
+  auto it = net->inter.find(name);
+  DGR_REQUIRE(it != net->inter.end() && it->second.n_dev, "no intermediate named '%s' (run a forward first)", name);
+  const DgrTensorRef &t = it->second;
+  int32_t n = 0;
+  DGR_HIP_CHECK(hipDeviceSynchronize());
+  DGR_HIP_CHECK(hipMemcpy(&n, t.n_dev, sizeof(int32_t), hipMemcpyDeviceToHost));
+  *rows = n;
+  *cols = t.cols;
+  if (host_out) {
+    DGR_REQUIRE(capacity >= (int64_t)n * t.cols, "host buffer too small");
+    DGR_HIP_CHECK(hipMemcpy2D(host_out, (size_t)t.cols * sizeof(float), t.ptr, (size_t)t.ld * sizeof(float),
+                              (size_t)t.cols * sizeof(float), (size_t)n, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < (int64_t)n * t.cols; ++i) host_out[i] = host_out[i] > 0.f ? host_out[i] : 0.f;
+  }
+  return DGR_OK;
+}
+
+extern "C" int dgr_net_layer_stats(dgr_ctx *ctx, dgr_net *net, int layer, int64_t stats[8]) {
+  DGR_REQUIRE(ctx && net && stats, "NULL argument");
+  DGR_REQUIRE(layer >= 0 && layer < (int)net->layers.size(), "layer %d out of range", layer);
+  const LayerRun &r = net->runs[layer];
+  DGR_REQUIRE(r.n_in && r.n_out, "run a forward first");
+  const DgrLayer &L = net->layers[layer];
+  DGR_HIP_CHECK(hipDeviceSynchronize());
+  int32_t n_in = 0, n_out = 0;
+  DGR_HIP_CHECK(hipMemcpy(&n_in, r.n_in, sizeof(int32_t), hipMemcpyDeviceToHost));
+  DGR_HIP_CHECK(hipMemcpy(&n_out, r.n_out, sizeof(int32_t), hipMemcpyDeviceToHost));
+  int64_t P = n_out, kne = 1;
+  if (r.rule_ptr) {
+    std::vector<int32_t> rp(r.K + 1);
+    DGR_HIP_CHECK(hipMemcpy(rp.data(), r.rule_ptr, (size_t)(r.K + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
+    P = rp[r.K];
+    kne = 0;
+    for (int k = 0; k < r.K; ++k) kne += rp[k + 1] > rp[k];
+  }
+  stats[0] = P; stats[1] = kne; stats[2] = n_in; stats[3] = n_out;
+  stats[4] = L.cin; stats[5] = L.cout; stats[6] = L.K; stats[7] = 0;
+  return DGR_OK;
+}

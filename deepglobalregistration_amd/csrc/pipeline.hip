@@ -1,0 +1,281 @@
+// Stage glue of DeepGlobalRegistration.register() (core/deep_global_registration.py:238-300):
+// 6-D inlier-network input assembly, confidence gate, row gather, and the fused batched pipeline
+// dgr_register_batch (FCGF x2 -> 1-NN -> 6-D inputs -> inlier net -> gate + Procrustes + refinement)
+// that runs without intermediate host synchronisation.
+#include <string.h>
+
+#include "dgr_internal.h"
+
+int dgr_registration_launch_ctx(dgr_ctx *ctx, const float *xyz0, const float *xyz1, const int64_t *idx1,
+                                const float *lw, int is_logit, float clip, const int64_t *off0_dev,
+                                int npairs, int64_t total_rows, float q, int max_iter, int max_break,
+                                double ratio, int skip_refine, int gate, float eps, float *weights_out,
+                                DgrRegResult *results_dev, hipStream_t stream);
+int dgr_ctx_new_flag(dgr_ctx *ctx, hipStream_t stream);
+int dgr_ctx_check_flag(dgr_ctx *ctx, hipStream_t stream);
+int dgr_net_out_channels(const dgr_net *net);
+int dgr_net_in_channels(const dgr_net *net);
+int dgr_net_dim(const dgr_net *net);
+
+// ---- 6-D coordinates (:261-262) and inlier features (:185-208) ----------------------------------
+__global__ void inlier_inputs_kernel(const int32_t *__restrict__ coords0, const float *__restrict__ xyz0,
+                                     int64_t N0, const int32_t *__restrict__ coords1,
+                                     const float *__restrict__ xyz1, const int64_t *__restrict__ idx1,
+                                     int feature_type, int32_t *__restrict__ coords6,
+                                     float *__restrict__ feats) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N0) return;
+  const int64_t j = idx1[i];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) coords6[i * 7 + d] = coords0[i * 4 + d];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) coords6[i * 7 + 4 + d] = coords1[j * 4 + 1 + d];
+  if (feature_type == 0) {
+    feats[i] = 1.f;
+  } else {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      feats[i * 6 + d] = cosf(xyz0[i * 3 + d]);
+      feats[i * 6 + 3 + d] = cosf(xyz1[j * 3 + d]);
+    }
+  }
+}
+
+int dgr_inlier_inputs_impl(const int32_t *coords0, const float *xyz0, int64_t N0, const int32_t *coords1,
+                           const float *xyz1, const int64_t *idx1, int feature_type, int32_t *coords6,
+                           float *feats, hipStream_t stream) {
+  inlier_inputs_kernel<<<(int)dgr_ceil_div(N0, 256), 256, 0, stream>>>(coords0, xyz0, N0, coords1, xyz1, idx1,
+                                                                     feature_type, coords6, feats);
+  DGR_LAUNCH_CHECK();
+  return DGR_OK;
+}
+
+extern "C" int dgr_inlier_inputs(dgr_ctx *ctx, const int32_t *coords0, const float *xyz0, int64_t N0,
+                                 const int32_t *coords1, const float *xyz1, int64_t N1, const int64_t *idx1,
+                                 int feature_type, int32_t *coords6_out, float *feats_out,
+                                 dgr_stream stream) {
+  DGR_REQUIRE(ctx && coords0 && xyz0 && coords1 && xyz1 && idx1 && coords6_out && feats_out,
+              "dgr_inlier_inputs: NULL argument");
+  DGR_REQUIRE(feature_type == 0 || feature_type == 1,
+              "inlier_feature_type must be 'ones' (0) or 'coords' (1); 'feats' is inconsistent with the "
+              "network input width in the reference (deep_global_registration.py:119)");
+  DGR_REQUIRE(N0 > 0 && N1 > 0, "dgr_inlier_inputs: empty input");
+  DGR_HIP_CHECK(hipSetDevice(ctx->device));
+  return dgr_inlier_inputs_impl(coords0, xyz0, N0, coords1, xyz1, idx1, feature_type, coords6_out, feats_out,
+                                (hipStream_t)stream);
+}
+
+// ---- sigmoid / clip / sum (:269-272) --------------------------------------------------------------
+__global__ void sigmoid_clip_sum_kernel(const float *__restrict__ logit, int64_t N, float clip,
+                                        float *__restrict__ w_out, double *__restrict__ sum) {
+  __shared__ double part[4];
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    float w = 1.f / (1.f + expf(-logit[i]));
+    if (clip > 0.f && w < clip) w = 0.f;
+    w_out[i] = w;
+    s += (double)w;
+  }
+  for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(sum, part[0] + part[1] + part[2] + part[3]);
+}
+
+extern "C" int dgr_sigmoid_clip_sum(dgr_ctx *ctx, const float *logit, int64_t N, float clip,
+                                    float *weights_out, double *wsum, dgr_stream stream_) {
+  DGR_REQUIRE(ctx && logit && weights_out && wsum, "dgr_sigmoid_clip_sum: NULL argument");
+  DGR_REQUIRE(N > 0, "dgr_sigmoid_clip_sum: empty input");
+  hipStream_t stream = (hipStream_t)stream_;
+  DGR_HIP_CHECK(hipSetDevice(ctx->device));
+  DGR_CHECK(ctx->arena.reset());
+  double *sum;
+  DGR_ALLOC(sum, ctx->arena, double, 1);
+  DGR_HIP_CHECK(hipMemsetAsync(sum, 0, sizeof(double), stream));
+  int blocks = (int)dgr_ceil_div(N, 256);
+  if (blocks > 1024) blocks = 1024;
+  sigmoid_clip_sum_kernel<<<blocks, 256, 0, stream>>>(logit, N, clip, weights_out, sum);
+  DGR_LAUNCH_CHECK();
+  DGR_HIP_CHECK(hipMemcpyAsync(wsum, sum, sizeof(double), hipMemcpyDeviceToHost, stream));
+  DGR_HIP_CHECK(hipStreamSynchronize(stream));
+  return DGR_OK;
+}
+
+// ---- xyz1[corres_idx1] (:283-285) -------------------------------------------------------------------
+__global__ void gather_rows3_kernel(const float *__restrict__ src, const int64_t *__restrict__ idx, int64_t N,
+                                    float *__restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int64_t j = idx[i];
+  dst[i * 3] = src[j * 3]; dst[i * 3 + 1] = src[j * 3 + 1]; dst[i * 3 + 2] = src[j * 3 + 2];
+}
+
+extern "C" int dgr_gather_rows3(dgr_ctx *ctx, const float *src, const int64_t *idx, int64_t N, float *dst,
+                                dgr_stream stream) {
+  DGR_REQUIRE(ctx && src && idx && dst && N > 0, "dgr_gather_rows3: bad argument");
+  DGR_HIP_CHECK(hipSetDevice(ctx->device));
+  gather_rows3_kernel<<<(int)dgr_ceil_div(N, 256), 256, 0, (hipStream_t)stream>>>(src, idx, N, dst);
+  DGR_LAUNCH_CHECK();
+  return DGR_OK;
+}
+
+__global__ void fill_kernel(float *p, int64_t n, float v) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+__global__ void add_offset_kernel(int64_t *idx, int64_t n, int64_t off) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) idx[i] += off;
+}
+
+// ---- fused batched pipeline --------------------------------------------------------------------------
+struct StageTimer {
+  dgr_ctx *ctx;
+  hipStream_t stream;
+  hipEvent_t e[8][2];
+  bool on;
+  int rec(int stage, int which) {
+    if (!on) return DGR_OK;
+    e[stage][which] = ctx->events.next();
+    if (!e[stage][which]) return DGR_EHIP;
+    DGR_HIP_CHECK(hipEventRecord(e[stage][which], stream));
+    return DGR_OK;
+  }
+};
+
+extern "C" int dgr_register_batch(dgr_ctx *ctx, dgr_net *fcgf, dgr_net *inlier, const int32_t *coords0,
+                                  const float *xyz0, const int64_t *off0, const int32_t *coords1,
+                                  const float *xyz1, const int64_t *off1, int npairs, const dgr_params *prm,
+                                  const float *forced_logit, float *T_out, int32_t *status_out,
+                                  float *stats_out, dgr_stream stream_) {
+  DGR_REQUIRE(ctx && fcgf && inlier && coords0 && xyz0 && off0 && coords1 && xyz1 && off1 && prm && T_out &&
+                  status_out,
+              "dgr_register_batch: NULL argument");
+  DGR_REQUIRE(npairs >= 1 && npairs <= 65535, "dgr_register_batch: npairs=%d out of range", npairs);
+  DGR_REQUIRE(dgr_net_dim(fcgf) == 3 && dgr_net_dim(inlier) == 6 && dgr_net_in_channels(fcgf) == 1,
+              "dgr_register_batch: expects the 3-D FCGF net (1 input channel) and the 6-D inlier net");
+  const int ftype = prm->inlier_feature_type;
+  DGR_REQUIRE((ftype == 0 && dgr_net_in_channels(inlier) == 1) || (ftype == 1 && dgr_net_in_channels(inlier) == 6),
+              "inlier_feature_type %d does not match the inlier network input width %d", ftype,
+              dgr_net_in_channels(inlier));
+  for (int p = 0; p < npairs; ++p)
+    DGR_REQUIRE(off0[p + 1] > off0[p] && off1[p + 1] > off1[p], "pair %d is empty", p);
+  hipStream_t stream = (hipStream_t)stream_;
+  DGR_HIP_CHECK(hipSetDevice(ctx->device));
+  DGR_CHECK(ctx->arena.reset());
+  ctx->events.used = 0;
+  DGR_CHECK(dgr_ctx_new_flag(ctx, stream));
+  DgrArena &A = ctx->arena;
+  const int64_t n0 = off0[npairs], n1 = off1[npairs];
+  const int C = dgr_net_out_channels(fcgf);
+  StageTimer tm{ctx, stream, {}, ctx->profiling};
+  float maps3 = 0.f, maps6 = 0.f, conv_ms = 0.f;
+  if (ctx->profiling) ctx->conv_launches = 0;
+
+  float *F0, *F1, *ones, *feats6, *logit, *weights;
+  int64_t *idx1, *off0_dev;
+  int32_t *coords6;
+  DgrRegResult *res_dev;
+  DGR_ALLOC(F0, A, float, n0 * C);
+  DGR_ALLOC(F1, A, float, n1 * C);
+  DGR_ALLOC(ones, A, float, n0 > n1 ? n0 : n1);
+  DGR_ALLOC(idx1, A, int64_t, n0);
+  DGR_ALLOC(coords6, A, int32_t, n0 * 7);
+  DGR_ALLOC(feats6, A, float, n0 * 6);
+  DGR_ALLOC(logit, A, float, n0);
+  DGR_ALLOC(weights, A, float, n0);
+  DGR_ALLOC(off0_dev, A, int64_t, npairs + 1);
+  DGR_ALLOC(res_dev, A, DgrRegResult, npairs);
+  DGR_HIP_CHECK(hipMemcpyAsync(off0_dev, off0, (size_t)(npairs + 1) * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+  fill_kernel<<<256, 256, 0, stream>>>(ones, n0 > n1 ? n0 : n1, 1.f);
+
+  // Step 1: FCGF features of both fragments (feats = ones[N,1], :160)
+  DGR_CHECK(tm.rec(0, 0));
+  {
+    DgrArena::Mark mk = A.mark();
+    DGR_CHECK(dgr_resunet_forward_impl(ctx, fcgf, coords0, ones, n0, F0, stream, &maps3, &conv_ms));
+    A.rewind(mk);
+    DGR_CHECK(dgr_resunet_forward_impl(ctx, fcgf, coords1, ones, n1, F1, stream, &maps3, &conv_ms));
+    A.rewind(mk);
+  }
+  DGR_CHECK(tm.rec(0, 1));
+  // Step 2: coarse correspondences, per pair (corres_idx0 = arange)
+  DGR_CHECK(tm.rec(1, 0));
+  for (int p = 0; p < npairs; ++p) {
+    const int64_t m0 = off0[p + 1] - off0[p], m1 = off1[p + 1] - off1[p];
+    DGR_CHECK(dgr_knn1_impl(ctx, F0 + off0[p] * C, m0, F1 + off1[p] * C, m1, C, 0, idx1 + off0[p], nullptr, stream));
+    if (off1[p] != 0)
+      add_offset_kernel<<<(int)dgr_ceil_div(m0, 256), 256, 0, stream>>>(idx1 + off0[p], m0, off1[p]);
+  }
+  DGR_CHECK(tm.rec(1, 1));
+  // Step 3: 6-D coordinates + inlier features
+  DGR_CHECK(tm.rec(2, 0));
+  DGR_CHECK(dgr_inlier_inputs_impl(coords0, xyz0, n0, coords1, xyz1, idx1, ftype, coords6, feats6, stream));
+  DGR_CHECK(tm.rec(2, 1));
+  // Step 4: inlier likelihood
+  DGR_CHECK(tm.rec(3, 0));
+  {
+    DgrArena::Mark mk = A.mark();
+    DGR_CHECK(dgr_resunet_forward_impl(ctx, inlier, coords6, feats6, n0, logit, stream, &maps6, &conv_ms));
+    A.rewind(mk);
+  }
+  DGR_CHECK(tm.rec(3, 1));
+  // Step 5 case 0: gate + weighted Procrustes + robust refinement, one workgroup per pair
+  DGR_CHECK(tm.rec(4, 0));
+  const float eps = 1.1920928955078125e-07f;
+  DGR_CHECK(dgr_registration_launch_ctx(ctx, xyz0, xyz1, idx1, forced_logit ? forced_logit : logit, 1,
+                                        prm->clip_weight_thresh, off0_dev, npairs, n0, 2.f * prm->voxel_size,
+                                        prm->max_iter, prm->max_break_count, prm->break_threshold_ratio,
+                                        prm->skip_refinement, 1, eps, weights, res_dev, stream));
+  DGR_CHECK(tm.rec(4, 1));
+
+  std::vector<DgrRegResult> res(npairs);
+  DGR_HIP_CHECK(hipMemcpyAsync(res.data(), res_dev, (size_t)npairs * sizeof(DgrRegResult), hipMemcpyDeviceToHost, stream));
+  DGR_HIP_CHECK(hipStreamSynchronize(stream));
+  DGR_CHECK(dgr_ctx_check_flag(ctx, stream));
+  for (int p = 0; p < npairs; ++p) {
+    float *T = T_out + p * 16;
+    const DgrRegResult &r = res[p];
+    for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.f : 0.f;
+    if (r.status == DGR_STATUS_OK) {
+      for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) T[i * 4 + j] = r.R[i * 3 + j];
+        T[i * 4 + 3] = r.t[i];
+      }
+    }
+    status_out[p] = r.status;
+    if (stats_out) {
+      stats_out[p * 4 + 0] = (float)r.iterations;
+      stats_out[p * 4 + 1] = r.loss;
+      stats_out[p * 4 + 2] = (float)r.break_count;
+      stats_out[p * 4 + 3] = r.wsum;
+    }
+  }
+  ctx->last.ptr[0] = idx1;    ctx->last.numel[0] = n0;
+  ctx->last.ptr[1] = logit;   ctx->last.numel[1] = n0;
+  ctx->last.ptr[2] = weights; ctx->last.numel[2] = n0;
+  ctx->last.ptr[3] = F0;      ctx->last.numel[3] = n0 * C;
+  ctx->last.ptr[4] = F1;      ctx->last.numel[4] = n1 * C;
+  if (ctx->profiling) {
+    memset(ctx->stage_ms, 0, sizeof(ctx->stage_ms));
+    for (int s = 0; s < 5; ++s) DGR_HIP_CHECK(hipEventElapsedTime(&ctx->stage_ms[s], tm.e[s][0], tm.e[s][1]));
+    ctx->stage_ms[5] = maps3;
+    ctx->stage_ms[6] = maps6;
+    ctx->stage_ms[7] = conv_ms;
+  }
+  return DGR_OK;
+}
+
+extern "C" int dgr_register_batch_output(dgr_ctx *ctx, int which, void *dst_dev, int64_t capacity_bytes,
+                                         int64_t *numel, dgr_stream stream) {
+  DGR_REQUIRE(ctx && numel && which >= 0 && which < 5, "dgr_register_batch_output: bad argument");
+  DGR_REQUIRE(ctx->last.ptr[which] != nullptr, "no dgr_register_batch has run on this ctx");
+  *numel = ctx->last.numel[which];
+  if (dst_dev) {
+    const int64_t bytes = ctx->last.numel[which] * (which == 0 ? 8 : 4);
+    DGR_REQUIRE(capacity_bytes >= bytes, "destination buffer too small");
+    DGR_HIP_CHECK(hipMemcpyAsync(dst_dev, ctx->last.ptr[which], (size_t)bytes, hipMemcpyDeviceToDevice,
+                                 (hipStream_t)stream));
+  }
+  return DGR_OK;
+}

@@ -1,0 +1,471 @@
+// Confidence gate + weighted Procrustes + robust SE(3) refinement, one workgroup per pair.
+// Replaces, for DeepGlobalRegistration.register() step 5 (core/deep_global_registration.py:269-300):
+//   * sigmoid / clip / sum gate                     core/deep_global_registration.py:269-281
+//   * weighted_procrustes                           core/registration.py:91-113
+//   * ortho2rotation / Transformation               core/registration.py:16-64, 116-132
+//   * HighDimSmoothL1Loss                           core/loss.py:42-61
+//   * GlobalRegistration (Adam 0.1, ExpLR 0.999)    core/registration.py:135-194
+//
+// The reference runs <=1000 iterations of ~30 tiny autograd kernels with 3 host syncs each.  Here
+// the whole optimisation is ONE persistent kernel: correspondences with w > 0 are compacted once
+// (clipped weights contribute neither loss nor gradient), every iteration is a single pass over
+// them with an analytic gradient (13 block-reduced sums accumulated in f64), and the 9-parameter
+// Adam update + the discrete stopping logic run redundantly in every thread.  Per-point
+// arithmetic is f32 like the reference; the 3x3 SVD is f64 (one-sided Jacobi) like its LAPACK call.
+#include "dgr_internal.h"
+
+constexpr int REG_THREADS = 512;
+constexpr int REG_WAVES = REG_THREADS / 64;
+
+struct RegArgs {
+  const float *xyz0, *xyz1;
+  const int64_t *idx1;  // may be null: xyz1 is already gathered (row aligned with xyz0)
+  const float *lw;      // logits (is_logit) or weights
+  const int64_t *off0;  // device [npairs+1]
+  float *weights_out;   // may be null
+  float4 *cA, *cB;      // compacted (x, w) / (y, 0) per pair region
+  DgrRegResult *res;
+  float clip, q, eps;
+  int is_logit, gate, skip_refine, max_iter, max_break;
+  double ratio;
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d, 64);
+  return v;
+}
+
+// Block-wide sum of NV doubles per thread; result visible to every thread in `out`.
+template <int NV>
+__device__ __forceinline__ void block_sum(const double (&v)[NV], double *lds /* [REG_WAVES*NV + NV] */,
+                                          double (&out)[NV]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    double s = wave_sum(v[i]);
+    if (lane == 0) lds[wave * NV + i] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < REG_WAVES; ++w) s += lds[w * NV + threadIdx.x];
+    lds[REG_WAVES * NV + threadIdx.x] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NV; ++i) out[i] = lds[REG_WAVES * NV + i];
+  __syncthreads();
+}
+
+// ---- 3x3 SVD, one-sided Jacobi in f64: A = U diag(s) V^T, s sorted descending ----------------
+__device__ void svd3(const double A[9], double U[9], double s[3], double V[9]) {
+  double a[3][3], v[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) { a[i][j] = A[i * 3 + j]; v[i][j] = (i == j) ? 1.0 : 0.0; }
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0.0;
+    for (int p = 0; p < 2; ++p)
+      for (int qq = p + 1; qq < 3; ++qq) {
+        double alpha = 0, beta = 0, gamma = 0;
+        for (int i = 0; i < 3; ++i) {
+          alpha += a[i][p] * a[i][p];
+          beta += a[i][qq] * a[i][qq];
+          gamma += a[i][p] * a[i][qq];
+        }
+        off = fmax(off, fabs(gamma) / (sqrt(alpha * beta) + 1e-300));
+        if (fabs(gamma) < 1e-300) continue;
+        double zeta = (beta - alpha) / (2.0 * gamma);
+        double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+        for (int i = 0; i < 3; ++i) {
+          double x = a[i][p], y = a[i][qq];
+          a[i][p] = c * x - sn * y;
+          a[i][qq] = sn * x + c * y;
+          x = v[i][p]; y = v[i][qq];
+          v[i][p] = c * x - sn * y;
+          v[i][qq] = sn * x + c * y;
+        }
+      }
+    if (off < 1e-15) break;
+  }
+  double sv[3];
+  int ord[3] = {0, 1, 2};
+  for (int j = 0; j < 3; ++j) sv[j] = sqrt(a[0][j] * a[0][j] + a[1][j] * a[1][j] + a[2][j] * a[2][j]);
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2 - i; ++j)
+      if (sv[ord[j]] < sv[ord[j + 1]]) { int t = ord[j]; ord[j] = ord[j + 1]; ord[j + 1] = t; }
+  double u[3][3];
+  const double tol = 1e-13 * fmax(sv[ord[0]], 1e-300);
+  for (int jj = 0; jj < 3; ++jj) {
+    const int j = ord[jj];
+    s[jj] = sv[j];
+    for (int i = 0; i < 3; ++i) V[i * 3 + jj] = v[i][j];
+    if (sv[j] > tol) {
+      for (int i = 0; i < 3; ++i) u[i][jj] = a[i][j] / sv[j];
+    } else {
+      // rank deficient: complete the orthonormal basis (Gram-Schmidt against canonical axes)
+      double best[3] = {0, 0, 0}, bn = -1.0;
+      for (int e = 0; e < 3; ++e) {
+        double c[3] = {e == 0 ? 1.0 : 0.0, e == 1 ? 1.0 : 0.0, e == 2 ? 1.0 : 0.0};
+        for (int pj = 0; pj < jj; ++pj) {
+          double d = c[0] * u[0][pj] + c[1] * u[1][pj] + c[2] * u[2][pj];
+          for (int i = 0; i < 3; ++i) c[i] -= d * u[i][pj];
+        }
+        double n = sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+        if (n > bn) { bn = n; for (int i = 0; i < 3; ++i) best[i] = c[i] / n; }
+      }
+      for (int i = 0; i < 3; ++i) u[i][jj] = best[i];
+    }
+  }
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) U[i * 3 + j] = u[i][j];
+}
+
+__device__ __forceinline__ double det3(const double M[9]) {
+  return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) +
+         M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+
+// ortho2rotation (core/registration.py:16-64) forward; keeps the intermediates for the backward
+struct Ortho {
+  float x[3], y[3], z[3], b[3];
+  float na, nu, coef, inner, norm2;
+  bool a_ok, n2_ok, u_ok;
+};
+
+__device__ __forceinline__ void ortho_forward(const float p[6], Ortho &o) {
+  const float a0 = p[0], a1 = p[1], a2 = p[2];
+  o.b[0] = p[3]; o.b[1] = p[4]; o.b[2] = p[5];
+  float ra = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
+  o.a_ok = ra >= 1e-8f;
+  o.na = fmaxf(ra, 1e-8f);
+  o.x[0] = a0 / o.na; o.x[1] = a1 / o.na; o.x[2] = a2 / o.na;
+  o.inner = o.x[0] * o.b[0] + o.x[1] * o.b[1] + o.x[2] * o.b[2];
+  float n2 = o.x[0] * o.x[0] + o.x[1] * o.x[1] + o.x[2] * o.x[2];
+  o.n2_ok = n2 >= 1e-8f;
+  o.norm2 = fmaxf(n2, 1e-8f);
+  o.coef = o.inner / o.norm2;
+  float u0 = o.b[0] - o.coef * o.x[0], u1 = o.b[1] - o.coef * o.x[1], u2 = o.b[2] - o.coef * o.x[2];
+  float ru = sqrtf(u0 * u0 + u1 * u1 + u2 * u2);
+  o.u_ok = ru >= 1e-8f;
+  o.nu = fmaxf(ru, 1e-8f);
+  o.y[0] = u0 / o.nu; o.y[1] = u1 / o.nu; o.y[2] = u2 / o.nu;
+  o.z[0] = o.x[1] * o.y[2] - o.x[2] * o.y[1];
+  o.z[1] = o.x[2] * o.y[0] - o.x[0] * o.y[2];
+  o.z[2] = o.x[0] * o.y[1] - o.x[1] * o.y[0];
+}
+
+// G[a][b] = dL/dR_ab with R = [x y z] as columns  ->  gradient w.r.t. the 6 parameters
+__device__ __forceinline__ void ortho_backward(const Ortho &o, const float G[9], float gp[6]) {
+  float gx[3] = {G[0], G[3], G[6]}, gy[3] = {G[1], G[4], G[7]}, gz[3] = {G[2], G[5], G[8]};
+  // z = x cross y
+  gx[0] += o.y[1] * gz[2] - o.y[2] * gz[1];
+  gx[1] += o.y[2] * gz[0] - o.y[0] * gz[2];
+  gx[2] += o.y[0] * gz[1] - o.y[1] * gz[0];
+  gy[0] += gz[1] * o.x[2] - gz[2] * o.x[1];
+  gy[1] += gz[2] * o.x[0] - gz[0] * o.x[2];
+  gy[2] += gz[0] * o.x[1] - gz[1] * o.x[0];
+  // y = u / max(|u|, 1e-8)
+  float gu[3];
+  {
+    const float d = o.u_ok ? (o.y[0] * gy[0] + o.y[1] * gy[1] + o.y[2] * gy[2]) : 0.f;
+    for (int i = 0; i < 3; ++i) gu[i] = (gy[i] - o.y[i] * d) / o.nu;
+  }
+  // u = b - coef * x
+  float gb[3] = {gu[0], gu[1], gu[2]};
+  const float gcoef = -(gu[0] * o.x[0] + gu[1] * o.x[1] + gu[2] * o.x[2]);
+  for (int i = 0; i < 3; ++i) gx[i] -= o.coef * gu[i];
+  // coef = inner / max(x.x, 1e-8)
+  const float ginner = gcoef / o.norm2;
+  const float gn2 = o.n2_ok ? -gcoef * o.inner / (o.norm2 * o.norm2) : 0.f;
+  for (int i = 0; i < 3; ++i) {
+    gx[i] += ginner * o.b[i] + 2.f * gn2 * o.x[i];
+    gb[i] += ginner * o.x[i];
+  }
+  // x = a / max(|a|, 1e-8)
+  const float d = o.a_ok ? (o.x[0] * gx[0] + o.x[1] * gx[1] + o.x[2] * gx[2]) : 0.f;
+  for (int i = 0; i < 3; ++i) gp[i] = (gx[i] - o.x[i] * d) / o.na;
+  for (int i = 0; i < 3; ++i) gp[3 + i] = gb[i];
+}
+
+__global__ void __launch_bounds__(REG_THREADS) registration_kernel(RegArgs a) {
+  __shared__ double red[REG_WAVES * 17 + 17];
+  __shared__ int wave_cnt[REG_WAVES];
+  __shared__ float init_Rt[12];
+  __shared__ int status_s;
+  const int p = blockIdx.x;
+  const int64_t r0 = a.off0[p];
+  const int n = (int)(a.off0[p + 1] - r0);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float4 *cA = a.cA + r0, *cB = a.cB + r0;
+  DgrRegResult *res = a.res + p;
+
+  // ---- pass 1: weights (gate), compaction of w > 0 rows, Procrustes sums ---------------------
+  double acc[17];
+#pragma unroll
+  for (int i = 0; i < 17; ++i) acc[i] = 0.0;
+  int m = 0;  // compacted count so far (uniform)
+  for (int base = 0; base < n; base += REG_THREADS) {
+    const int i = base + tid;
+    float w = 0.f, x[3] = {0, 0, 0}, y[3] = {0, 0, 0};
+    if (i < n) {
+      const int64_t r = r0 + i;
+      w = a.lw[r];
+      if (a.is_logit) {
+        w = 1.f / (1.f + expf(-w));
+        if (a.clip > 0.f && w < a.clip) w = 0.f;
+      }
+      if (a.weights_out) a.weights_out[r] = w;
+      const int64_t ry = a.idx1 ? a.idx1[r] : r;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { x[d] = a.xyz0[r * 3 + d]; y[d] = a.xyz1[ry * 3 + d]; }
+      const double wd = w;
+      acc[0] += fabs(wd);
+      acc[1] += wd;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { acc[2 + d] += wd * x[d]; acc[5 + d] += wd * y[d]; }
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int e = 0; e < 3; ++e) acc[8 + d * 3 + e] += wd * (double)y[d] * (double)x[e];
+    }
+    // the refinement only ever sees rows with w != 0 (loss and gradient are both scaled by w)
+    const bool keep = (i < n) && (w != 0.f);
+    const unsigned long long msk = __ballot(keep);
+    if (lane == 0) wave_cnt[wave] = __popcll(msk);
+    __syncthreads();
+    int off = m, tot = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < REG_WAVES; ++w2) {
+      if (w2 < wave) off += wave_cnt[w2];
+      tot += wave_cnt[w2];
+    }
+    if (keep) {
+      const int pos = off + __popcll(msk & ((1ull << lane) - 1ull));
+      cA[pos] = make_float4(x[0], x[1], x[2], w);
+      cB[pos] = make_float4(y[0], y[1], y[2], 0.f);
+    }
+    m += tot;
+    __syncthreads();
+  }
+  double S[17];
+  block_sum<17>(acc, red, S);
+
+  // ---- gate + weighted Procrustes (thread 0) ----------------------------------------------------
+  if (tid == 0) {
+    int status = DGR_STATUS_OK;
+    const double wsum = S[1];
+    if (a.gate) {
+      const double thr = fmax(200.0, 0.05 * (double)n);
+      if (!(wsum >= thr)) status = DGR_STATUS_LOW_CONFIDENCE;
+    }
+    float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, t[3] = {0, 0, 0};
+    if (status == DGR_STATUS_OK) {
+      const double inv = 1.0 / (S[0] + (double)a.eps);  // w / (sum|w| + eps)
+      const double sn = S[1] * inv;
+      double mx[3], my[3], Sxy[9];
+      for (int d = 0; d < 3; ++d) { mx[d] = S[2 + d] * inv; my[d] = S[5 + d] * inv; }
+      for (int d = 0; d < 3; ++d)
+        for (int e = 0; e < 3; ++e) Sxy[d * 3 + e] = S[8 + d * 3 + e] * inv - (2.0 - sn) * my[d] * mx[e];
+      bool finite = true;
+      for (int i = 0; i < 9; ++i) finite = finite && isfinite(Sxy[i]);
+      if (!finite) {
+        status = DGR_STATUS_SVD_FAILED;
+      } else {
+        double U[9], sv[3], V[9];
+        svd3(Sxy, U, sv, V);
+        const double sg = (det3(U) * det3(V) < 0.0) ? -1.0 : 1.0;
+        double Rd[9];
+        for (int i = 0; i < 3; ++i)
+          for (int j = 0; j < 3; ++j)
+            Rd[i * 3 + j] = U[i * 3 + 0] * V[j * 3 + 0] + U[i * 3 + 1] * V[j * 3 + 1] + sg * U[i * 3 + 2] * V[j * 3 + 2];
+        for (int i = 0; i < 9; ++i) R[i] = (float)Rd[i];
+        // t = muy - R mux with the f32 R, like the reference
+        for (int i = 0; i < 3; ++i)
+          t[i] = (float)my[i] - (R[i * 3] * (float)mx[0] + R[i * 3 + 1] * (float)mx[1] + R[i * 3 + 2] * (float)mx[2]);
+      }
+    }
+    for (int i = 0; i < 9; ++i) { init_Rt[i] = R[i]; res->R[i] = R[i]; }
+    for (int i = 0; i < 3; ++i) { init_Rt[9 + i] = t[i]; res->t[i] = t[i]; }
+    res->wsum = (float)wsum;
+    res->status = status;
+    res->iterations = 0;
+    res->break_count = 0;
+    res->loss = 0.f;
+    status_s = status;
+  }
+  __syncthreads();
+  if (status_s != DGR_STATUS_OK || a.skip_refine) return;
+
+  // ---- SE(3) refinement: Adam on (rot6d, trans) -------------------------------------------------
+  float prm[9];  // rot6d = (R[:,0], R[:,1]) , trans
+  prm[0] = init_Rt[0]; prm[1] = init_Rt[3]; prm[2] = init_Rt[6];
+  prm[3] = init_Rt[1]; prm[4] = init_Rt[4]; prm[5] = init_Rt[7];
+  prm[6] = init_Rt[9]; prm[7] = init_Rt[10]; prm[8] = init_Rt[11];
+  float am[9], av[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { am[i] = 0.f; av[i] = 0.f; }
+  const float w1 = (float)S[1];  // loss_fn.w1 = weights.sum(), core/loss.py:48-49
+  const float q = a.q;
+  double lr = 0.1, b1t = 1.0, b2t = 1.0;
+  float loss_prev = 0.f, loss = 0.f;
+  int breaks = 0, it = 0;
+  for (it = 0; it < a.max_iter; ++it) {
+    Ortho o;
+    ortho_forward(prm, o);
+    const float R00 = o.x[0], R10 = o.x[1], R20 = o.x[2];
+    const float R01 = o.y[0], R11 = o.y[1], R21 = o.y[2];
+    const float R02 = o.z[0], R12 = o.z[1], R22 = o.z[2];
+    double g[13];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) g[i] = 0.0;
+    for (int i = tid; i < m; i += REG_THREADS) {
+      const float4 A = cA[i], B = cB[i];
+      const float px = A.x * R00 + A.y * R01 + A.z * R02 + prm[6];
+      const float py = A.x * R10 + A.y * R11 + A.z * R12 + prm[7];
+      const float pz = A.x * R20 + A.y * R21 + A.z * R22 + prm[8];
+      const float rx = (px - B.x) / q, ry = (py - B.y) / q, rz = (pz - B.z) / q;
+      const float s = rx * rx + ry * ry + rz * rz;
+      float per, dps;
+      if (s < 1.f) {
+        per = 0.5f * s;
+        dps = 0.5f;
+      } else {
+        const float rt = sqrtf(s + a.eps);
+        per = 0.5f * (rt - 0.5f);  // discontinuous at s == 1 like core/loss.py:55-56
+        dps = 0.25f / rt;
+      }
+      const float wk = A.w * dps * 2.f / q;
+      const float gx = wk * rx, gy = wk * ry, gz = wk * rz;
+      g[0] += (double)(per * A.w);
+      g[1] += gx; g[2] += gy; g[3] += gz;
+      g[4] += gx * A.x; g[5] += gx * A.y; g[6] += gx * A.z;
+      g[7] += gy * A.x; g[8] += gy * A.y; g[9] += gy * A.z;
+      g[10] += gz * A.x; g[11] += gz * A.y; g[12] += gz * A.z;
+    }
+    double Gs[13];
+    block_sum<13>(g, red, Gs);
+    loss = (float)(Gs[0] / (double)w1);
+    if (it == 0) loss_prev = loss;  // loss_prev = loss_fn(T(points), trans_points) before the loop
+    if (loss < 1e-7f) break;
+    float G[9], grad[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) G[i] = (float)(Gs[4 + i] / (double)w1);
+    ortho_backward(o, G, grad);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) grad[6 + i] = (float)(Gs[1 + i] / (double)w1);
+    // torch.optim.Adam (betas 0.9/0.999, eps 1e-8) followed by ExponentialLR(0.999).step()
+    b1t *= 0.9;
+    b2t *= 0.999;
+    const double step_size = lr / (1.0 - b1t);
+    const float bc2s = (float)sqrt(1.0 - b2t);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      am[i] = am[i] + (grad[i] - am[i]) * 0.1f;
+      av[i] = av[i] * 0.999f + 0.001f * grad[i] * grad[i];
+      const float denom = sqrtf(av[i]) / bc2s + 1e-8f;
+      prm[i] = prm[i] + (float)(-step_size) * (am[i] / denom);
+    }
+    lr *= 0.999;
+    if (fabs((double)loss_prev - (double)loss) < (double)loss_prev * a.ratio) {
+      ++breaks;
+      if (breaks >= a.max_break) break;
+    }
+    loss_prev = loss;
+  }
+  if (it >= a.max_iter) it = a.max_iter - 1;  // python's `i` after an exhausted range()
+  if (tid == 0) {
+    Ortho o;
+    ortho_forward(prm, o);
+    res->R[0] = o.x[0]; res->R[1] = o.y[0]; res->R[2] = o.z[0];
+    res->R[3] = o.x[1]; res->R[4] = o.y[1]; res->R[5] = o.z[1];
+    res->R[6] = o.x[2]; res->R[7] = o.y[2]; res->R[8] = o.z[2];
+    res->t[0] = prm[6]; res->t[1] = prm[7]; res->t[2] = prm[8];
+    res->iterations = it;
+    res->break_count = breaks;
+    res->loss = loss;
+  }
+}
+
+// needs 2 x float4 x total_rows of scratch; allocated by the callers below from the ctx arena
+static int launch_registration(dgr_ctx *ctx, const float *xyz0, const float *xyz1, const int64_t *idx1,
+                               const float *lw, int is_logit, float clip, const int64_t *off0_dev,
+                               int npairs, int64_t total_rows, float q, int max_iter, int max_break,
+                               double ratio, int skip_refine, int gate, float eps, float *weights_out,
+                               DgrRegResult *results_dev, hipStream_t stream) {
+  RegArgs a;
+  a.xyz0 = xyz0; a.xyz1 = xyz1; a.idx1 = idx1; a.lw = lw; a.off0 = off0_dev;
+  a.weights_out = weights_out; a.res = results_dev;
+  DGR_ALLOC(a.cA, ctx->arena, float4, total_rows);
+  DGR_ALLOC(a.cB, ctx->arena, float4, total_rows);
+  a.clip = clip; a.q = q; a.eps = eps;
+  a.is_logit = is_logit; a.gate = gate; a.skip_refine = skip_refine;
+  a.max_iter = max_iter; a.max_break = max_break; a.ratio = ratio;
+  registration_kernel<<<npairs, REG_THREADS, 0, stream>>>(a);
+  DGR_LAUNCH_CHECK();
+  return DGR_OK;
+}
+
+int dgr_registration_launch_ctx(dgr_ctx *ctx, const float *xyz0, const float *xyz1, const int64_t *idx1,
+                                const float *lw, int is_logit, float clip, const int64_t *off0_dev,
+                                int npairs, int64_t total_rows, float q, int max_iter, int max_break,
+                                double ratio, int skip_refine, int gate, float eps, float *weights_out,
+                                DgrRegResult *results_dev, hipStream_t stream) {
+  return launch_registration(ctx, xyz0, xyz1, idx1, lw, is_logit, clip, off0_dev, npairs, total_rows, q,
+                             max_iter, max_break, ratio, skip_refine, gate, eps, weights_out, results_dev,
+                             stream);
+}
+
+static int run_single(dgr_ctx *ctx, const float *X, const float *Y, const float *w, int64_t N, float q,
+                      int max_iter, int max_break, double ratio, int skip_refine, float eps,
+                      DgrRegResult *host_res, hipStream_t stream) {
+  DGR_REQUIRE(ctx && X && Y && w, "registration: NULL argument");
+  DGR_REQUIRE(N > 0 && N < (1ll << 31), "registration: N=%lld out of range", (long long)N);
+  DGR_REQUIRE(skip_refine || max_iter >= 1, "GlobalRegistration: max_iter must be >= 1");
+  DGR_HIP_CHECK(hipSetDevice(ctx->device));
+  DGR_CHECK(ctx->arena.reset());
+  int64_t *off;
+  DgrRegResult *res;
+  DGR_ALLOC(off, ctx->arena, int64_t, 2);
+  DGR_ALLOC(res, ctx->arena, DgrRegResult, 1);
+  const int64_t h_off[2] = {0, N};
+  DGR_HIP_CHECK(hipMemcpyAsync(off, h_off, sizeof(h_off), hipMemcpyHostToDevice, stream));
+  DGR_CHECK(launch_registration(ctx, X, Y, nullptr, w, 0, 0.f, off, 1, N, q, max_iter, max_break, ratio,
+                                skip_refine, 0, eps, nullptr, res, stream));
+  DGR_HIP_CHECK(hipMemcpyAsync(host_res, res, sizeof(DgrRegResult), hipMemcpyDeviceToHost, stream));
+  DGR_HIP_CHECK(hipStreamSynchronize(stream));
+  if (host_res->status == DGR_STATUS_SVD_FAILED) {
+    dgr_set_error("weighted Procrustes: non-finite covariance, SVD failed");
+    return DGR_ESVD;
+  }
+  return DGR_OK;
+}
+
+extern "C" int dgr_weighted_procrustes(dgr_ctx *ctx, const float *X, const float *Y, const float *w,
+                                       int64_t N, float eps, float *R9, float *t3, dgr_stream stream) {
+  DGR_REQUIRE(R9 && t3, "dgr_weighted_procrustes: NULL output");
+  DgrRegResult r;
+  DGR_CHECK(run_single(ctx, X, Y, w, N, 1.f, 1, 1, 0.0, 1, eps, &r, (hipStream_t)stream));
+  for (int i = 0; i < 9; ++i) R9[i] = r.R[i];
+  for (int i = 0; i < 3; ++i) t3[i] = r.t[i];
+  return DGR_OK;
+}
+
+extern "C" int dgr_se3_refine(dgr_ctx *ctx, const float *X, const float *Y, const float *w, int64_t N,
+                              float quantization_size, int max_iter, int max_break_count,
+                              double break_threshold_ratio, float *R9, float *t3, int32_t *iterations,
+                              float *loss, int32_t *break_count, dgr_stream stream) {
+  DGR_REQUIRE(R9 && t3, "dgr_se3_refine: NULL output");
+  DgrRegResult r;
+  const float eps = 1.1920928955078125e-07f;  // np.finfo(np.float32).eps, core/loss.py:44
+  DGR_CHECK(run_single(ctx, X, Y, w, N, quantization_size, max_iter, max_break_count, break_threshold_ratio, 0,
+                       eps, &r, (hipStream_t)stream));
+  for (int i = 0; i < 9; ++i) R9[i] = r.R[i];
+  for (int i = 0; i < 3; ++i) t3[i] = r.t[i];
+  if (iterations) *iterations = r.iterations;
+  if (loss) *loss = r.loss;
+  if (break_count) *break_count = r.break_count;
+  return DGR_OK;
+}

@@ -1,0 +1,325 @@
+"""Thin torch-tensor wrappers over the C ABI (one function per entry point of
+include/dgr_hip.h).  torch supplies device memory and the current stream only; all
+arithmetic happens in libdgr_hip.so."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, get_ctx, ptr, stream_ptr, vp
+
+F32_EPS = float(np.finfo(np.float32).eps)
+
+
+def _dev(t):
+    if not (torch.is_tensor(t) and t.is_cuda):
+        raise ValueError('expected a CUDA(ROCm) tensor')
+    return t.device
+
+
+def _as(t, dtype, device):
+    if not torch.is_tensor(t):
+        t = torch.as_tensor(np.asarray(t))
+    return t.to(device=device, dtype=dtype).contiguous()
+
+
+# ----------------------------------------------------------------------------
+def voxelize(xyz, voxel_size, batch_index=0, device='cuda'):
+    """ME.utils.sparse_quantize(xyz / voxel, return_index=True) + batched_coordinates
+    (core/deep_global_registration.py:152-158).  Returns (xyz_sel f32 [N,3], coords i32 [N,4],
+    sel i64 [N]) on the device.  float64 input is quantised in float64 like the reference."""
+    lib = _lib.load()
+    device = torch.device(device)
+    if not torch.is_tensor(xyz):
+        xyz = torch.from_numpy(np.ascontiguousarray(xyz))
+    if xyz.dtype not in (torch.float32, torch.float64):
+        xyz = xyz.double()
+    if xyz.dim() != 2 or xyz.shape[1] != 3:
+        raise ValueError(f'expected an [M,3] point array, got {tuple(xyz.shape)}')
+    xyz = xyz.to(device).contiguous()
+    M = xyz.shape[0]
+    if M == 0:
+        raise ValueError('empty point cloud')
+    sel = torch.empty(M, dtype=torch.int64, device=device)
+    coords = torch.empty((M, 4), dtype=torch.int32, device=device)
+    out = torch.empty((M, 3), dtype=torch.float32, device=device)
+    n = C.c_int64(0)
+    check(lib.dgr_voxelize(get_ctx(device), ptr(xyz), int(xyz.dtype == torch.float64), M,
+                           float(voxel_size), int(batch_index), ptr(sel), ptr(coords), ptr(out),
+                           C.byref(n), stream_ptr(device.index)))
+    n = n.value
+    return out[:n], coords[:n], sel[:n]
+
+
+# ----------------------------------------------------------------------------
+class NetHandle:
+    """Owns a dgr_net (weights resident in HBM)."""
+
+    def __init__(self, state_dict, D, in_channels, out_channels, conv1_kernel_size,
+                 normalize_feature, device='cuda'):
+        lib = _lib.load()
+        self.device = torch.device(device)
+        self.D, self.cin, self.cout = D, in_channels, out_channels
+        keep, descs = [], []
+        for name, t in state_dict.items():
+            if name.endswith('num_batches_tracked'):
+                continue
+            a = t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            keep.append(a)
+            descs.append(_lib.WeightDesc(name.encode(), a.ctypes.data, a.size))
+        arr = (_lib.WeightDesc * len(descs))(*descs)
+        h = vp()
+        with torch.cuda.device(self.device):
+            check(lib.dgr_net_create(get_ctx(self.device), D, in_channels, out_channels,
+                                     conv1_kernel_size, int(bool(normalize_feature)), arr, len(descs),
+                                     C.byref(h)))
+        self.handle = h
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                _lib.load().dgr_net_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    @property
+    def param_bytes(self):
+        return _lib.load().dgr_net_param_bytes(self.handle)
+
+    def forward(self, coords, feats):
+        lib = _lib.load()
+        dev = self.device
+        coords = _as(coords, torch.int32, dev)
+        feats = _as(feats, torch.float32, dev)
+        if coords.dim() != 2 or coords.shape[1] != self.D + 1:
+            raise ValueError(f'coords must be [N,{self.D + 1}] (batch column first), got {tuple(coords.shape)}')
+        if feats.dim() != 2 or feats.shape != (coords.shape[0], self.cin):
+            raise ValueError(f'feats must be [{coords.shape[0]},{self.cin}], got {tuple(feats.shape)}')
+        N = coords.shape[0]
+        if N == 0:
+            raise ValueError('empty sparse tensor')
+        out = torch.empty((N, self.cout), dtype=torch.float32, device=dev)
+        check(lib.dgr_resunet_forward(get_ctx(dev), self.handle, ptr(coords), ptr(feats), N, ptr(out),
+                                      stream_ptr(dev.index)))
+        return out
+
+    def intermediate(self, name):
+        lib = _lib.load()
+        rows, cols = C.c_int64(0), C.c_int64(0)
+        ctx = get_ctx(self.device)
+        check(lib.dgr_net_get_intermediate(ctx, self.handle, name.encode(), None, 0, C.byref(rows), C.byref(cols)))
+        buf = np.empty((rows.value, cols.value), np.float32)
+        check(lib.dgr_net_get_intermediate(ctx, self.handle, name.encode(), buf.ctypes.data, buf.size,
+                                           C.byref(rows), C.byref(cols)))
+        return buf
+
+    def layer_stats(self):
+        """Per conv layer of the last forward: dict(pairs, nonempty, n_in, n_out, cin, cout, K)."""
+        lib = _lib.load()
+        out = []
+        for li in range(lib.dgr_net_num_layers(self.handle)):
+            st = (C.c_int64 * 8)()
+            check(lib.dgr_net_layer_stats(get_ctx(self.device), self.handle, li, st))
+            out.append(dict(pairs=st[0], nonempty=st[1], n_in=st[2], n_out=st[3], cin=st[4], cout=st[5], K=st[6]))
+        return out
+
+
+# ----------------------------------------------------------------------------
+class Maps:
+    """Coordinate maps + kernel maps of one sparse tensor (inspection / parity tests)."""
+
+    def __init__(self, coords, D, conv1_kernel_size=3, device='cuda'):
+        lib = _lib.load()
+        self.device = torch.device(device)
+        coords = _as(coords, torch.int32, self.device)
+        self.D = D
+        h = vp()
+        check(lib.dgr_maps_create(get_ctx(self.device), ptr(coords), coords.shape[0], D, conv1_kernel_size,
+                                  C.byref(h), stream_ptr(self.device.index)))
+        self.handle = h
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                _lib.load().dgr_maps_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def coords(self, ts):
+        lib = _lib.load()
+        n = C.c_int64(0)
+        check(lib.dgr_maps_get_coords(self.handle, ts, None, 0, C.byref(n)))
+        out = np.empty((n.value, self.D + 1), np.int32)
+        check(lib.dgr_maps_get_coords(self.handle, ts, out.ctypes.data, out.size, C.byref(n)))
+        return out
+
+    def kernel_map(self, kind, ts):
+        """kind: 'same' | 'conv1' | 'down'.  Returns (k, in, out) int64 arrays sorted by (k, out)."""
+        lib = _lib.load()
+        kid = {'same': 0, 'conv1': 1, 'down': 2}[kind]
+        K, P = C.c_int64(0), C.c_int64(0)
+        check(lib.dgr_maps_get_kernel_map(self.handle, kid, ts, None, 0, None, None, 0, C.byref(K), C.byref(P)))
+        rule = np.empty(K.value + 1, np.int32)
+        pin = np.empty(P.value, np.int32)
+        pout = np.empty(P.value, np.int32)
+        check(lib.dgr_maps_get_kernel_map(self.handle, kid, ts, rule.ctypes.data, rule.size, pin.ctypes.data,
+                                          pout.ctypes.data, pin.size, C.byref(K), C.byref(P)))
+        k = np.repeat(np.arange(K.value), np.diff(rule))
+        return k.astype(np.int64), pin.astype(np.int64), pout.astype(np.int64)
+
+
+# ----------------------------------------------------------------------------
+def knn1(F0, F1, squared=False, return_distance=False):
+    lib = _lib.load()
+    dev = _dev(F0)
+    F0 = _as(F0, torch.float32, dev)
+    F1 = _as(F1, torch.float32, dev)
+    if F0.dim() != 2 or F1.dim() != 2 or F0.shape[1] != F1.shape[1]:
+        raise ValueError('F0 [N0,C] and F1 [N1,C] must share the feature width')
+    N0, N1 = F0.shape[0], F1.shape[0]
+    idx = torch.empty(N0, dtype=torch.int64, device=dev)
+    dist = torch.empty(N0, dtype=torch.float32, device=dev) if return_distance else None
+    check(lib.dgr_knn1_l2(get_ctx(dev), ptr(F0), N0, ptr(F1), N1, F0.shape[1], int(squared), ptr(idx),
+                          ptr(dist), stream_ptr(dev.index)))
+    return (idx, dist) if return_distance else idx
+
+
+def inlier_inputs(coords0, xyz0, coords1, xyz1, idx1, feature_type='coords'):
+    lib = _lib.load()
+    dev = _dev(xyz0)
+    ft = {'ones': 0, 'coords': 1}.get(feature_type)
+    if ft is None:
+        raise TypeError('Undefined feature type')
+    coords0, coords1 = _as(coords0, torch.int32, dev), _as(coords1, torch.int32, dev)
+    xyz0, xyz1 = _as(xyz0, torch.float32, dev), _as(xyz1, torch.float32, dev)
+    idx1 = _as(idx1, torch.int64, dev).reshape(-1)
+    N0 = coords0.shape[0]
+    if idx1.shape[0] != N0:
+        raise ValueError('one correspondence per row of fragment 0 expected')
+    coords6 = torch.empty((N0, 7), dtype=torch.int32, device=dev)
+    feats = torch.empty((N0, 6 if ft == 1 else 1), dtype=torch.float32, device=dev)
+    check(lib.dgr_inlier_inputs(get_ctx(dev), ptr(coords0), ptr(xyz0), N0, ptr(coords1), ptr(xyz1),
+                                coords1.shape[0], ptr(idx1), ft, ptr(coords6), ptr(feats),
+                                stream_ptr(dev.index)))
+    return coords6, feats
+
+
+def sigmoid_clip_sum(logit, clip):
+    lib = _lib.load()
+    dev = _dev(logit)
+    logit = _as(logit, torch.float32, dev).reshape(-1)
+    w = torch.empty_like(logit)
+    s = C.c_double(0)
+    check(lib.dgr_sigmoid_clip_sum(get_ctx(dev), ptr(logit), logit.shape[0], float(clip), ptr(w), C.byref(s),
+                                   stream_ptr(dev.index)))
+    return w.reshape(-1, 1), s.value
+
+
+def gather_rows3(src, idx):
+    lib = _lib.load()
+    dev = _dev(src)
+    src = _as(src, torch.float32, dev)
+    idx = _as(idx, torch.int64, dev).reshape(-1)
+    out = torch.empty((idx.shape[0], 3), dtype=torch.float32, device=dev)
+    check(lib.dgr_gather_rows3(get_ctx(dev), ptr(src), ptr(idx), idx.shape[0], ptr(out), stream_ptr(dev.index)))
+    return out
+
+
+def _xyw(X, Y, w):
+    dev = _dev(X)
+    X, Y = _as(X, torch.float32, dev), _as(Y, torch.float32, dev)
+    w = _as(w, torch.float32, dev).reshape(-1)
+    if X.shape != Y.shape or X.dim() != 2 or X.shape[1] != 3 or w.shape[0] != X.shape[0]:
+        raise ValueError('X, Y must be [N,3] and w [N] / [N,1]')
+    return dev, X, Y, w
+
+
+def weighted_procrustes(X, Y, w, eps=F32_EPS):
+    lib = _lib.load()
+    dev, X, Y, w = _xyw(X, Y, w)
+    R = (C.c_float * 9)()
+    t = (C.c_float * 3)()
+    check(lib.dgr_weighted_procrustes(get_ctx(dev), ptr(X), ptr(Y), ptr(w), X.shape[0], float(eps), R, t,
+                                      stream_ptr(dev.index)))
+    return np.array(R, np.float32).reshape(3, 3), np.array(t, np.float32)
+
+
+def se3_refine(X, Y, w, quantization_size=1.0, max_iter=1000, max_break_count=20,
+               break_threshold_ratio=1e-5):
+    lib = _lib.load()
+    dev, X, Y, w = _xyw(X, Y, w)
+    R = (C.c_float * 9)()
+    t = (C.c_float * 3)()
+    it, bc, loss = C.c_int32(0), C.c_int32(0), C.c_float(0)
+    check(lib.dgr_se3_refine(get_ctx(dev), ptr(X), ptr(Y), ptr(w), X.shape[0], float(quantization_size),
+                             int(max_iter), int(max_break_count), float(break_threshold_ratio), R, t,
+                             C.byref(it), C.byref(loss), C.byref(bc), stream_ptr(dev.index)))
+    return (np.array(R, np.float32).reshape(3, 3), np.array(t, np.float32),
+            {'iterations': it.value, 'loss': loss.value, 'break_count': bc.value})
+
+
+# ----------------------------------------------------------------------------
+def register_batch(fcgf, inlier, coords0, xyz0, off0, coords1, xyz1, off1, voxel_size,
+                   clip_weight_thresh=0.05, inlier_feature_type='coords', max_iter=1000,
+                   max_break_count=20, break_threshold_ratio=1e-4, skip_refinement=False,
+                   forced_logit=None):
+    """Fused pipeline over a batch of voxelised pairs (dgr_register_batch).  Returns
+    T [npairs,4,4] float32, status [npairs] int32, stats [npairs,4] float32."""
+    lib = _lib.load()
+    dev = fcgf.device
+    npairs = len(off0) - 1
+    coords0, coords1 = _as(coords0, torch.int32, dev), _as(coords1, torch.int32, dev)
+    xyz0, xyz1 = _as(xyz0, torch.float32, dev), _as(xyz1, torch.float32, dev)
+    o0 = (C.c_int64 * (npairs + 1))(*[int(v) for v in off0])
+    o1 = (C.c_int64 * (npairs + 1))(*[int(v) for v in off1])
+    if coords0.shape[0] != off0[-1] or coords1.shape[0] != off1[-1]:
+        raise ValueError('offset arrays do not match the coordinate arrays')
+    prm = _lib.Params(float(clip_weight_thresh), float(voxel_size),
+                      {'ones': 0, 'coords': 1}[inlier_feature_type], int(max_iter), int(max_break_count),
+                      float(break_threshold_ratio), int(bool(skip_refinement)))
+    T = np.empty((npairs, 16), np.float32)
+    status = np.empty(npairs, np.int32)
+    stats = np.empty((npairs, 4), np.float32)
+    fl = None
+    if forced_logit is not None:
+        fl = _as(forced_logit, torch.float32, dev).reshape(-1)
+        if fl.shape[0] != coords0.shape[0]:
+            raise ValueError('forced_logit must have one entry per row of fragment 0')
+    check(lib.dgr_register_batch(get_ctx(dev), fcgf.handle, inlier.handle, ptr(coords0), ptr(xyz0), o0,
+                                 ptr(coords1), ptr(xyz1), o1, npairs, C.byref(prm), ptr(fl),
+                                 T.ctypes.data_as(_lib.c_f32p), status.ctypes.data_as(_lib.c_i32p),
+                                 stats.ctypes.data_as(_lib.c_f32p), stream_ptr(dev.index)))
+    return T.reshape(npairs, 4, 4), status, stats
+
+
+_BATCH_OUT = {'idx1': (0, torch.int64), 'logit': (1, torch.float32), 'weights': (2, torch.float32),
+              'F0': (3, torch.float32), 'F1': (4, torch.float32)}
+
+
+def batch_output(device, which):
+    """Copy of a device-side intermediate of the last register_batch ('idx1', 'logit', 'weights',
+    'F0', 'F1') as a flat torch tensor."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    wid, dtype = _BATCH_OUT[which]
+    n = C.c_int64(0)
+    check(lib.dgr_register_batch_output(get_ctx(dev), wid, None, 0, C.byref(n), stream_ptr(dev.index)))
+    out = torch.empty(n.value, dtype=dtype, device=dev)
+    check(lib.dgr_register_batch_output(get_ctx(dev), wid, ptr(out), out.numel() * out.element_size(),
+                                        C.byref(n), stream_ptr(dev.index)))
+    return out
+
+
+def set_profiling(device, enable):
+    check(_lib.load().dgr_ctx_set_profiling(get_ctx(device), int(bool(enable))))
+
+
+def stage_times(device):
+    t = (C.c_float * 8)()
+    check(_lib.load().dgr_ctx_stage_times(get_ctx(device), t))
+    names = ['fcgf', 'knn', 'inlier_inputs', 'inlier_net', 'registration', 'maps_3d', 'maps_6d', 'conv_kernels']
+    return dict(zip(names, [float(v) for v in t]))

@@ -1,0 +1,198 @@
+/*
+ * dgr_hip.h -- C ABI of libdgr_hip.so, the MI355X (gfx950) implementation of the
+ * Deep Global Registration inference hot path.
+ *
+ * The reference (chrischoy/DeepGlobalRegistration) is pure Python with no FFI of
+ * its own; its "operator interface" for this path is the set of Python callables
+ * below.  Every entry point cites the reference interface it replaces
+ * (paths relative to the reference repo).  INTEGRATION.md shows the ctypes
+ * binding a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no torch / STL types.
+ *   - "dev" pointers are device (HBM) pointers valid on the ctx's device; the
+ *     caller owns every input/output buffer, the library owns ctx, nets, hash
+ *     tables, kernel maps and a grow-only workspace.
+ *   - all work is enqueued on the caller's `stream` (a hipStream_t passed as
+ *     void*; NULL = the default stream); functions that return host scalars
+ *     synchronise that stream, all others are asynchronous.
+ *   - return value: DGR_OK (0) or a negative DGR_E* code; dgr_last_error()
+ *     returns a thread-local message for the last failure.
+ *   - a ctx is bound to one device and is not thread-safe.
+ */
+#ifndef DGR_HIP_H
+#define DGR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dgr_ctx dgr_ctx;
+typedef struct dgr_net dgr_net;
+typedef struct dgr_maps dgr_maps;
+typedef void *dgr_stream; /* hipStream_t */
+
+enum {
+  DGR_OK = 0,
+  DGR_EINVAL = -1,   /* bad argument / shape / duplicate coordinates */
+  DGR_EHIP = -2,     /* HIP runtime error */
+  DGR_ENOMEM = -3,   /* workspace exhausted (kernel-map capacity overflow) */
+  DGR_ESVD = -4,     /* 3x3 SVD did not converge / non-finite input: maps to the
+                        RuntimeError caught at core/deep_global_registration.py:295 */
+  DGR_EINTERNAL = -5
+};
+
+/* per-pair status of the confidence gate, core/deep_global_registration.py:276-281 */
+enum { DGR_STATUS_OK = 0, DGR_STATUS_LOW_CONFIDENCE = 1, DGR_STATUS_SVD_FAILED = 2 };
+
+const char *dgr_last_error(void);
+const char *dgr_version(void);
+
+/* ---- context ------------------------------------------------------------------------ */
+int dgr_ctx_create(int device, dgr_ctx **out);
+void dgr_ctx_destroy(dgr_ctx *ctx);
+/* bytes currently reserved by the grow-only workspace (diagnostics) */
+int64_t dgr_ctx_workspace_bytes(dgr_ctx *ctx);
+
+/* ---- voxelisation: replaces ME.utils.sparse_quantize(xyz / voxel, return_index=True) and
+ * ME.utils.batched_coordinates at core/deep_global_registration.py:152,158 (preprocess, :134-161).
+ * xyz: dev [M,3] float64 (is_f64=1) or float32 (is_f64=0); floor(xyz/voxel) is taken in that dtype.
+ * sel_out: dev int64 [>=M]   indices of the first point of every voxel, ascending
+ * coords_out: dev int32 [>=M,4] (batch_index, floor(xyz[sel]/voxel))
+ * xyz_out: dev float32 [>=M,3] xyz[sel] cast to float32
+ * n_out: host int64*, number of voxels (synchronises the stream). */
+int dgr_voxelize(dgr_ctx *ctx, const void *xyz, int is_f64, int64_t M, double voxel_size,
+                 int32_t batch_index, int64_t *sel_out, int32_t *coords_out, float *xyz_out,
+                 int64_t *n_out, dgr_stream stream);
+
+/* ---- network: replaces model.load_model('ResUNetBN2C')(in, out, bn_momentum, conv1_kernel_size,
+ * normalize_feature, D) + load_state_dict + .eval() (core/deep_global_registration.py:96-131;
+ * class at model/resunet.py:419-665).  Tensors are HOST float32 arrays in MinkowskiEngine
+ * state_dict layout ("conv1.kernel" [K,Cin,Cout], "norm1.bn.weight", ..., "final.bias");
+ * the library folds eval-mode batch norm into the kernels, re-tiles them for the MFMA
+ * B-operand and copies them to HBM; the caller may free its arrays afterwards. */
+typedef struct {
+  const char *name;
+  const float *data; /* host */
+  int64_t numel;
+} dgr_weight_desc;
+
+int dgr_net_create(dgr_ctx *ctx, int D, int in_channels, int out_channels, int conv1_kernel_size,
+                   int normalize_feature, const dgr_weight_desc *weights, int n_weights,
+                   dgr_net **out);
+void dgr_net_destroy(dgr_net *net);
+int64_t dgr_net_param_bytes(const dgr_net *net);
+
+/* ---- sparse ResUNet forward: replaces ME.SparseTensor(feats, coordinates=coords) +
+ * ResUNet2.forward (core/deep_global_registration.py:163-169, 210-217; model/resunet.py:598-649).
+ * coords: dev int32 [N,1+D] (batch column first, unique rows); feats: dev f32 [N,Cin];
+ * out: dev f32 [N,Cout], row i belongs to coords row i.  Asynchronous. */
+int dgr_resunet_forward(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, const float *feats,
+                        int64_t N, float *out, dgr_stream stream);
+/* after a forward: copy an intermediate activation ("s1","s2","s4","s8","s4_tr","s2_tr","s1_tr")
+ * to a HOST buffer (post-ReLU values, like the reference's out_s* tensors); rows/cols out. */
+int dgr_net_get_intermediate(dgr_ctx *ctx, dgr_net *net, const char *name, float *host_out,
+                             int64_t capacity, int64_t *rows, int64_t *cols);
+/* per-forward work statistics of the last forward (for the roofline report): for conv layer
+ * `layer` (0..22): pairs, non-empty offsets, n_in, n_out, cin, cout.  Synchronises. */
+int dgr_net_layer_stats(dgr_ctx *ctx, dgr_net *net, int layer, int64_t stats[8]);
+int dgr_net_num_layers(const dgr_net *net);
+
+/* ---- coordinate / kernel maps as a stand-alone object (inspection + parity tests):
+ * the coordinate manager part of ME.SparseTensor / MinkowskiConvolution. */
+int dgr_maps_create(dgr_ctx *ctx, const int32_t *coords, int64_t N, int D, int conv1_kernel_size,
+                    dgr_maps **out, dgr_stream stream);
+void dgr_maps_destroy(dgr_maps *maps);
+/* coordinates of the map at tensor stride ts (1,2,4,8): host int32 [n,1+D]; returns n in *n */
+int dgr_maps_get_coords(dgr_maps *maps, int ts, int32_t *host_out, int64_t capacity, int64_t *n);
+/* kernel map: kind 0 = same-stride 3^D at ts, 1 = conv1 (ks^D at ts=1), 2 = strided ts -> 2ts.
+ * host outputs: rule_ptr int32 [K+1], pair_in/pair_out int32 [P]; *K, *P returned. */
+int dgr_maps_get_kernel_map(dgr_maps *maps, int kind, int ts, int32_t *rule_ptr, int64_t rule_cap,
+                            int32_t *pair_in, int32_t *pair_out, int64_t pair_cap, int64_t *K,
+                            int64_t *P);
+
+/* ---- feature-space 1-NN: replaces core.knn.find_knn_gpu(F0, F1, nn_max_n, knn=1,
+ * return_distance) (core/knn.py:23-74) incl. core.metrics.pdist (core/metrics.py:62-69).
+ * F0 dev f32 [N0,C], F1 dev f32 [N1,C]; idx_out dev int64 [N0]; dist_out dev f32 [N0] or NULL.
+ * squared=0: dist = sqrt(sum (a-b)^2 + 1e-7) (chunked branch, 'L2'); squared=1: sum (a-b)^2.
+ * The [chunk,N1,C] temporary of the reference is never materialised. */
+int dgr_knn1_l2(dgr_ctx *ctx, const float *F0, int64_t N0, const float *F1, int64_t N1, int C,
+                int squared, int64_t *idx_out, float *dist_out, dgr_stream stream);
+
+/* ---- 6-D inlier-network input: replaces the torch.cat at core/deep_global_registration.py:261-262
+ * and inlier_feature_generation (:185-208).  idx1 dev int64 [N0] (corres_idx1; corres_idx0 is
+ * arange(N0)).  feature_type 0='ones' -> feats [N0,1]; 1='coords' -> [N0,6] =
+ * (cos(xyz0[i]), cos(xyz1[idx1[i]])).  coords6_out dev int32 [N0,7]. */
+int dgr_inlier_inputs(dgr_ctx *ctx, const int32_t *coords0, const float *xyz0, int64_t N0,
+                      const int32_t *coords1, const float *xyz1, int64_t N1, const int64_t *idx1,
+                      int feature_type, int32_t *coords6_out, float *feats_out, dgr_stream stream);
+
+/* ---- confidence gate: replaces logit.sigmoid(); weights[weights < clip] = 0; weights.sum().item()
+ * (core/deep_global_registration.py:269-272).  weights_out dev f32 [N]; *wsum host (synchronises). */
+int dgr_sigmoid_clip_sum(dgr_ctx *ctx, const float *logit, int64_t N, float clip, float *weights_out,
+                         double *wsum, dgr_stream stream);
+
+/* gather rows: X[i] = src[idx[i]] for [*,3] float32 (xyz1[corres_idx1] at :283-285) */
+int dgr_gather_rows3(dgr_ctx *ctx, const float *src, const int64_t *idx, int64_t N, float *dst,
+                     dgr_stream stream);
+
+/* ---- weighted Procrustes: replaces core.registration.weighted_procrustes(X, Y, w, eps)
+ * (core/registration.py:91-113).  X,Y dev f32 [N,3], w dev f32 [N]; R9 (row-major 3x3) and t3
+ * are HOST outputs (the reference also lands on the host: .cpu() at :105,112).  3x3 SVD in f64
+ * on the device.  Returns DGR_ESVD on non-finite input. */
+int dgr_weighted_procrustes(dgr_ctx *ctx, const float *X, const float *Y, const float *w, int64_t N,
+                            float eps, float *R9, float *t3, dgr_stream stream);
+
+/* ---- robust SE(3) refinement: replaces core.registration.GlobalRegistration(points,
+ * trans_points, weights, max_iter, max_break_count, break_threshold_ratio, quantization_size)
+ * (core/registration.py:135-194) with HighDimSmoothL1Loss (core/loss.py:42-61), ortho2rotation
+ * (:16-64), Adam(lr=0.1) + ExponentialLR(0.999) (:163-164): weighted-Procrustes initialisation
+ * and the whole optimisation loop run in ONE persistent kernel (no per-iteration host syncs).
+ * Host outputs: R9 row-major, t3, iterations, loss, break_count. */
+int dgr_se3_refine(dgr_ctx *ctx, const float *X, const float *Y, const float *w, int64_t N,
+                   float quantization_size, int max_iter, int max_break_count,
+                   double break_threshold_ratio, float *R9, float *t3, int32_t *iterations,
+                   float *loss, int32_t *break_count, dgr_stream stream);
+
+/* ---- fused pipeline: replaces DeepGlobalRegistration.register() steps 1-5 case 0
+ * (core/deep_global_registration.py:248-300) for a batch of already voxelised pairs, without
+ * intermediate host synchronisation.  Pair p uses rows [off0[p], off0[p+1]) of coords0/xyz0 and
+ * [off1[p], off1[p+1]) of coords1/xyz1 (host offset arrays, npairs+1 entries); the batch column
+ * of the coords must equal p.  forced_logit (dev f32 [sum N0], may be NULL) overrides the inlier
+ * network's logits after it ran (teacher forcing for synthetic weights).
+ * T_out host f32 [npairs,16] row-major 4x4, status_out host int32 [npairs],
+ * stats_out host f32 [npairs,4] = (iterations, loss, break_count, wsum) or NULL. */
+typedef struct {
+  float clip_weight_thresh;     /* config.clip_weight_thresh, config.py:63 (0.05) */
+  float voxel_size;             /* checkpoint config */
+  int inlier_feature_type;      /* 0 'ones', 1 'coords' */
+  int max_iter;                 /* 1000 */
+  int max_break_count;          /* 20 */
+  double break_threshold_ratio; /* 1e-4 as passed at :286 */
+  int skip_refinement;          /* ablation (config C5): stop after weighted Procrustes */
+} dgr_params;
+
+int dgr_register_batch(dgr_ctx *ctx, dgr_net *fcgf, dgr_net *inlier, const int32_t *coords0,
+                       const float *xyz0, const int64_t *off0, const int32_t *coords1,
+                       const float *xyz1, const int64_t *off1, int npairs, const dgr_params *params,
+                       const float *forced_logit, float *T_out, int32_t *status_out,
+                       float *stats_out, dgr_stream stream);
+/* device-side intermediates of the last dgr_register_batch (valid until the next call on this
+ * ctx): which = 0 idx1 (int64 [sumN0]), 1 logit (f32 [sumN0]), 2 weights (f32 [sumN0]),
+ * 3 F0 (f32 [sumN0,C]), 4 F1 (f32 [sumN1,C]).  *numel receives the element count; when dst_dev is
+ * not NULL the data is copied (device to device, on `stream`) into dst_dev (capacity in bytes). */
+int dgr_register_batch_output(dgr_ctx *ctx, int which, void *dst_dev, int64_t capacity_bytes,
+                              int64_t *numel, dgr_stream stream);
+
+/* per-stage device time (ms, HIP events) of the last dgr_register_batch when profiling was
+ * enabled with dgr_ctx_set_profiling(ctx, 1): [fcgf, knn, inlier_inputs, inlier_net, registration,
+ * maps_3d, maps_6d, conv_kernels_total].  Synchronises. */
+int dgr_ctx_set_profiling(dgr_ctx *ctx, int enable);
+int dgr_ctx_stage_times(dgr_ctx *ctx, float times_ms[8]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DGR_HIP_H */

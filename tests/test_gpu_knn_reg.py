@@ -1,0 +1,120 @@
+"""GPU parity: 1-NN search and registration kernels against the golden vectors generated from
+the reference's own modules, and against the oracle on larger seeded inputs."""
+import ast
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rot_angle_deg
+from oracle import knn as oknn
+from oracle import registration as oreg
+
+pytestmark = pytest.mark.gpu
+
+
+def _cmp_knn(F0, F1, idx_ref, idx, d2_tol=2e-6):
+    idx = np.asarray(idx).reshape(-1)
+    idx_ref = np.asarray(idx_ref).reshape(-1)
+    bad = np.nonzero(idx != idx_ref)[0]
+    if len(bad):
+        # only genuine rounding ties may differ: both candidates equally near in float64
+        d_a = oknn.knn_sqdist_f64(F0[bad], F1, idx[bad])
+        d_b = oknn.knn_sqdist_f64(F0[bad], F1, idx_ref[bad])
+        assert np.all(np.abs(d_a - d_b) <= d2_tol), (len(bad), np.abs(d_a - d_b).max())
+    return len(bad)
+
+
+def test_knn_golden(golden):
+    from deepglobalregistration_amd.core.knn import find_knn_gpu
+    g = golden('knn')
+    for tag in 'abc':
+        F0, F1 = g[f'{tag}_F0'], g[f'{tag}_F1']
+        ic, dc = find_knn_gpu(torch.from_numpy(F0).cuda(), torch.from_numpy(F1).cuda(), nn_max_n=250,
+                              knn=1, return_distance=True)
+        assert tuple(ic.shape) == g[f'{tag}_idx_chunked'].shape and ic.dtype == torch.int64
+        assert _cmp_knn(F0, F1, g[f'{tag}_idx_chunked'], ic.cpu().numpy()) == 0
+        np.testing.assert_allclose(dc.cpu().numpy(), g[f'{tag}_dist_chunked'], atol=1e-6)
+        iu, du = find_knn_gpu(torch.from_numpy(F0).cuda(), torch.from_numpy(F1).cuda(), nn_max_n=-1,
+                              return_distance=True)
+        assert tuple(iu.shape) == g[f'{tag}_idx_unchunked'].shape
+        assert _cmp_knn(F0, F1, g[f'{tag}_idx_unchunked'], iu.cpu().numpy()) == 0
+        np.testing.assert_allclose(du.cpu().numpy(), g[f'{tag}_dist_unchunked'], atol=1e-6)
+    it = find_knn_gpu(torch.from_numpy(g['tie_F0']).cuda(), torch.from_numpy(g['tie_F1']).cuda(), nn_max_n=250)
+    np.testing.assert_array_equal(it.cpu().numpy(), g['tie_idx_chunked'])   # exact ties -> first index
+
+
+def test_knn_large_vs_oracle_and_properties():
+    from deepglobalregistration_amd import ops
+    rng = np.random.default_rng(0)
+    F0 = rng.standard_normal((5000, 32)).astype(np.float32)
+    F1 = rng.standard_normal((7000, 32)).astype(np.float32)
+    F0 /= np.linalg.norm(F0, axis=1, keepdims=True)
+    F1 /= np.linalg.norm(F1, axis=1, keepdims=True)
+    idx, dist = ops.knn1(torch.from_numpy(F0).cuda(), torch.from_numpy(F1).cuda(), return_distance=True)
+    oi, od = oknn.find_knn(F0, F1, nn_max_n=250, return_distance=True)
+    assert _cmp_knn(F0, F1, oi, idx.cpu().numpy()) <= 2
+    np.testing.assert_allclose(dist.cpu().numpy(), od.reshape(-1), atol=2e-6)
+    # property at the BASELINE size: the NN of a row of F1 inside F1 is itself, distance sqrt(1e-7)
+    G = rng.standard_normal((26000, 32)).astype(np.float32)
+    Gt = torch.from_numpy(G).cuda()
+    idx, dist = ops.knn1(Gt, Gt, return_distance=True)
+    assert torch.equal(idx.cpu(), torch.arange(26000))
+    np.testing.assert_allclose(dist.cpu().numpy(), np.sqrt(np.float32(1e-7)), rtol=1e-6)
+    with pytest.raises(ValueError):
+        ops.knn1(Gt, torch.zeros(10, 16).cuda())
+    with pytest.raises(ValueError):
+        ops.knn1(torch.zeros(0, 32).cuda(), Gt)
+
+
+def test_procrustes_golden(golden):
+    from deepglobalregistration_amd.core.registration import weighted_procrustes
+    g = golden('procrustes')
+    for tag in ('clean', 'noisy', 'zeros', 'reflect'):
+        R, t = weighted_procrustes(torch.from_numpy(g[f'{tag}_X']).cuda(), torch.from_numpy(g[f'{tag}_Y']).cuda(),
+                                   torch.from_numpy(g[f'{tag}_w']).cuda())
+        np.testing.assert_allclose(R.numpy(), g[f'{tag}_R'], atol=2e-6, err_msg=tag)
+        np.testing.assert_allclose(t.numpy(), g[f'{tag}_t'], atol=5e-6, err_msg=tag)
+    nan = torch.full((10, 3), float('nan')).cuda()
+    with pytest.raises(RuntimeError):      # the SVD failure path must stay a RuntimeError (:295)
+        weighted_procrustes(nan, nan, torch.ones(10, 1).cuda())
+
+
+def test_refinement_golden(golden):
+    """R, t within 1e-4 of the reference (north_star tolerance); the discrete stopping logic may
+    shift by a few iterations because the reductions are accumulated in f64 here."""
+    from deepglobalregistration_amd.core.registration import GlobalRegistration
+    g = golden('refine')
+    for tag in ('clean', 'outliers70', 'exact', 'maxiter', 'default_q'):
+        kw = ast.literal_eval(str(g[f'{tag}_kw']))
+        R, t, st = GlobalRegistration(torch.from_numpy(g[f'{tag}_X']).cuda(), torch.from_numpy(g[f'{tag}_Y']).cuda(),
+                                      weights=torch.from_numpy(g[f'{tag}_w']).cuda(), **kw)
+        assert tuple(R.shape) == (3, 3) and tuple(t.shape) == (1, 3)
+        np.testing.assert_allclose(R.cpu().numpy(), g[f'{tag}_R'], atol=1e-4, err_msg=tag)
+        np.testing.assert_allclose(t.cpu().numpy(), g[f'{tag}_t'], atol=1e-4, err_msg=tag)
+        assert abs(st['iterations'] - int(g[f'{tag}_iterations'])) <= 5, (tag, st)
+        assert abs(st['break_count'] - int(g[f'{tag}_break_count'])) <= 2, (tag, st)
+        np.testing.assert_allclose(st['loss'], float(g[f'{tag}_loss']), rtol=2e-3, atol=1e-9, err_msg=tag)
+    # exact early exit and exhausted max_iter are discrete: must agree exactly
+    assert GlobalRegistration(torch.from_numpy(g['exact_X']).cuda(), torch.from_numpy(g['exact_Y']).cuda(),
+                              weights=torch.from_numpy(g['exact_w']).cuda(), break_threshold_ratio=1e-4,
+                              quantization_size=0.1)[2]['iterations'] == 0
+
+
+def test_refinement_full_size_vs_oracle():
+    from deepglobalregistration_amd import ops
+    rng = np.random.default_rng(5)
+    n = 26000
+    X = rng.uniform(-2, 2, (n, 3)).astype(np.float32)
+    ang = 0.7
+    Rg = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]])
+    Y = (X @ Rg.T + [0.3, -0.2, 0.1] + rng.normal(scale=0.01, size=(n, 3))).astype(np.float32)
+    Y[: int(0.75 * n)] = rng.uniform(-3, 3, (int(0.75 * n), 3))
+    w = np.concatenate([rng.uniform(0, 0.2, int(0.75 * n)), rng.uniform(0.5, 1, n - int(0.75 * n))]).astype(np.float32)
+    w[w < 0.05] = 0
+    R, t, st = ops.se3_refine(torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda(), torch.from_numpy(w).cuda(),
+                              0.1, 1000, 20, 1e-4)
+    Ro, to, sto = oreg.global_registration(X, Y, w, break_threshold_ratio=1e-4, quantization_size=0.1)
+    assert np.abs(R - Ro).max() < 1e-4 and np.abs(t - to.reshape(-1)).max() < 1e-4
+    assert rot_angle_deg(R, Rg) < 0.5
+    assert abs(np.linalg.det(R.astype(np.float64)) - 1) < 1e-5

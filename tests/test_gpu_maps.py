@@ -1,0 +1,80 @@
+"""GPU parity: voxelisation, coordinate maps and kernel maps (integer work => bit-exact)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import kmap_set, random_cloud_coords
+from oracle import me_semantics as me
+from oracle import pipeline as opipe
+
+pytestmark = pytest.mark.gpu
+
+
+def test_voxelize_matches_sparse_quantize():
+    from deepglobalregistration_amd import ops, synth
+    xyz0, _, _ = synth.synth_pair(3, n_raw=20000)
+    xyz0 = xyz0 - 1.3                      # negative coordinates exercise floor()
+    for dtype in (np.float64, np.float32):
+        x = xyz0.astype(dtype)
+        p, c, sel = ops.voxelize(x, 0.05, batch_index=2)
+        _, osel = me.sparse_quantize(x / dtype(0.05), return_index=True)
+        np.testing.assert_array_equal(sel.cpu().numpy(), osel)
+        oc = np.floor(x[osel] / dtype(0.05)).astype(np.int32)
+        np.testing.assert_array_equal(c.cpu().numpy()[:, 1:], oc)
+        assert (c.cpu().numpy()[:, 0] == 2).all()
+        np.testing.assert_array_equal(p.cpu().numpy(), x[osel].astype(np.float32))
+    op, oc, _ = opipe.preprocess(xyz0, 0.05)
+    p, c, _ = ops.voxelize(xyz0, 0.05)
+    np.testing.assert_array_equal(c.cpu().numpy(), oc)
+    np.testing.assert_array_equal(p.cpu().numpy(), op)
+
+
+def test_voxelize_rejects_bad_input():
+    from deepglobalregistration_amd import ops
+    with pytest.raises(ValueError):
+        ops.voxelize(np.zeros((0, 3)), 0.05)
+    with pytest.raises(ValueError):
+        ops.voxelize(np.zeros((5, 2)), 0.05)
+    with pytest.raises(ValueError):
+        ops.voxelize(np.zeros((5, 3)), -1.0)
+
+
+@pytest.mark.parametrize('D,ks,n', [(3, 3, 4000), (3, 7, 3000), (3, 5, 2500), (6, 3, 1500)])
+def test_maps_match_oracle(D, ks, n):
+    from deepglobalregistration_amd import ops
+    rng = np.random.default_rng(10 * D + ks)
+    coords = np.concatenate([random_cloud_coords(rng, n, 20 if D == 3 else 6, D, batch=b) for b in (0, 1)])
+    maps = ops.Maps(coords, D, ks)
+    ocoords = {1: coords}
+    for ts in (2, 4, 8):
+        ocoords[ts] = me.stride_coords(ocoords[ts // 2], ts)
+        got = maps.coords(ts)
+        np.testing.assert_array_equal(got, ocoords[ts])      # same first-occurrence order
+    for ts in (1, 2, 4, 8):
+        k, i, o = maps.kernel_map('same', ts)
+        ok, oi, oo = me.kernel_map(ocoords[ts], ocoords[ts], D, 3, ts)
+        assert kmap_set(k, i, o) == kmap_set(ok, oi, oo)
+        assert np.all(np.diff(k) >= 0)
+        # within a rule the pairs are sorted by output row (deterministic build)
+        same_rule = np.diff(k) == 0
+        assert np.all(np.diff(o)[same_rule] > 0)
+    k, i, o = maps.kernel_map('conv1', 1)
+    assert kmap_set(k, i, o) == kmap_set(*me.kernel_map(coords, coords, D, ks, 1))
+    for ts in (1, 2, 4):
+        k, i, o = maps.kernel_map('down', ts)
+        assert kmap_set(k, i, o) == kmap_set(*me.kernel_map(ocoords[ts], ocoords[2 * ts], D, 3, ts))
+
+
+def test_duplicate_coordinates_are_rejected():
+    from deepglobalregistration_amd import ops
+    coords = np.array([[0, 1, 2, 3], [0, 4, 5, 6], [0, 1, 2, 3]], np.int32)
+    with pytest.raises(ValueError):
+        ops.Maps(coords, 3, 3)
+
+
+def test_single_voxel_and_tiny_maps():
+    from deepglobalregistration_amd import ops
+    m = ops.Maps(np.array([[0, 5, -3, 2]], np.int32), 3, 3)
+    k, i, o = m.kernel_map('same', 1)
+    assert (k.tolist(), i.tolist(), o.tolist()) == ([13], [0], [0])
+    assert m.coords(8).tolist() == [[0, 0, -8, 0]]

@@ -1,0 +1,142 @@
+"""GPU parity of the whole path: DeepGlobalRegistration.register() (stage-wise, reference-like
+call sequence) and the fused batched pipeline against the CPU oracle on identical inputs."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rot_angle_deg
+from helpers import rel_err
+from oracle import pipeline as opipe
+from oracle import registration as oreg
+from oracle import resunet as oresunet
+
+pytestmark = pytest.mark.gpu
+VOXEL = 0.05
+
+
+@pytest.fixture(scope='module')
+def setup():
+    from deepglobalregistration_amd import synth
+    from deepglobalregistration_amd.core.deep_global_registration import DeepGlobalRegistration
+    ck = synth.synth_checkpoint(seed=0, voxel_size=VOXEL, feat_conv1_kernel_size=7)
+    dgr = DeepGlobalRegistration({'weights': ck, 'clip_weight_thresh': 0.05}, torch.device('cuda'))
+    pairs = [synth.synth_pair(s, n_raw=6000) for s in (0, 1)]
+    return ck, dgr, pairs
+
+
+def test_stagewise_matches_oracle(setup):
+    from deepglobalregistration_amd import ops, synth
+    ck, dgr, pairs = setup
+    xyz0, xyz1, T_gt = pairs[0]
+    p0, c0, f0 = dgr.preprocess(xyz0)
+    p1, c1, f1 = dgr.preprocess(xyz1)
+    op0, oc0, of0 = opipe.preprocess(xyz0, VOXEL)
+    op1, oc1, of1 = opipe.preprocess(xyz1, VOXEL)
+    np.testing.assert_array_equal(c0.cpu().numpy(), oc0)
+    np.testing.assert_array_equal(p1.cpu().numpy(), op1)
+    F0 = dgr.fcgf_feature_extraction(f0, c0)
+    F1 = dgr.fcgf_feature_extraction(f1, c1)
+    oF0 = oresunet.resunet_forward(ck['state_dict'], oc0, of0, 3, 7, True)
+    oF1 = oresunet.resunet_forward(ck['state_dict'], oc1, of1, 3, 7, True)
+    assert np.abs(F0.cpu().numpy() - oF0).max() < 1e-4
+    assert np.abs(F1.cpu().numpy() - oF1).max() < 1e-4
+    # matching on the ORACLE's features (teacher forcing) so that later stages see identical inputs
+    i0, i1 = dgr.fcgf_feature_matching(torch.from_numpy(oF0).cuda(), torch.from_numpy(oF1).cuda())
+    from oracle import knn as oknn
+    oi1 = oknn.find_knn(oF0, oF1, nn_max_n=250).reshape(-1)
+    mism = np.nonzero(i1.cpu().numpy() != oi1)[0]
+    assert len(mism) <= max(2, len(oi1) // 200), len(mism)   # flat synthetic walls produce near-ties
+    i1 = torch.from_numpy(oi1).cuda()
+    feats6 = dgr.inlier_feature_generation(p0, p1, c0, c1, F0, F1, i0, i1)
+    coords6, feats6b = ops.inlier_inputs(c0, p0, c1, p1, i1, 'coords')
+    ocoords6, ofeats6 = opipe.inlier_inputs(op0, op1, oc0, oc1, np.arange(len(oi1)), oi1)
+    np.testing.assert_array_equal(coords6.cpu().numpy(), ocoords6)
+    np.testing.assert_allclose(feats6.cpu().numpy(), ofeats6, atol=2e-6)
+    logit = dgr.inlier_prediction(feats6, coords6)
+    ologit = oresunet.resunet_forward(ck['state_dict_inlier'], ocoords6, ofeats6, 6, 3, False)
+    assert rel_err(logit.cpu().numpy(), ologit) < 1e-4
+    # gate + registration on identical (teacher-forced) logits
+    forced = synth.gt_forced_logits(op0, op1[oi1], T_gt, VOXEL)
+    w, wsum = ops.sigmoid_clip_sum(torch.from_numpy(forced).cuda(), 0.05)
+    ow, owsum, thr = opipe.confidence_gate(forced, 0.05)
+    np.testing.assert_allclose(w.cpu().numpy(), ow, atol=1e-6)
+    assert abs(wsum - owsum) < 1e-2 * max(1.0, owsum) * 1e-2
+    assert owsum >= thr, 'synthetic pair should pass the confidence gate'
+    from deepglobalregistration_amd.core.registration import GlobalRegistration
+    R, t, st = GlobalRegistration(p0, ops.gather_rows3(p1, i1), weights=w, break_threshold_ratio=1e-4,
+                                  quantization_size=2 * VOXEL)
+    Ro, to, sto = oreg.global_registration(op0, op1[oi1], ow, break_threshold_ratio=1e-4,
+                                           quantization_size=2 * VOXEL)
+    assert np.abs(R.cpu().numpy() - Ro).max() < 1e-4 and np.abs(t.cpu().numpy() - to).max() < 1e-4
+    # and the estimate is close to the ground truth pose
+    assert rot_angle_deg(Ro, T_gt[:3, :3]) < 2.0 and np.linalg.norm(to.reshape(-1) - T_gt[:3, 3]) < 0.1
+
+
+def test_register_api(setup):
+    ck, dgr, pairs = setup
+    xyz0, xyz1, _ = pairs[0]
+    T = dgr.register(xyz0, xyz1)
+    assert T.shape == (4, 4) and T.dtype == np.float64
+    np.testing.assert_array_equal(T[3], [0, 0, 0, 1])
+    assert dgr.last_status in ('ok', 'low_confidence')
+    assert dgr.feat_timer.diff > 0 and dgr.reg_timer.avg > 0
+    with pytest.raises(Exception, match='Unrecognized pcd type'):
+        dgr.register([1, 2, 3], xyz1)
+
+
+def test_fused_batch_matches_stagewise_and_oracle(setup):
+    from deepglobalregistration_amd import ops, synth
+    ck, dgr, pairs = setup
+    # voxelise both pairs into one batch
+    x0, c0, x1, c1, off0, off1 = [], [], [], [], [0], [0]
+    for p, (a, b, _) in enumerate(pairs):
+        xa, ca, _ = dgr.preprocess(a, batch_index=p)
+        xb, cb, _ = dgr.preprocess(b, batch_index=p)
+        x0.append(xa); c0.append(ca); x1.append(xb); c1.append(cb)
+        off0.append(off0[-1] + len(xa)); off1.append(off1[-1] + len(xb))
+    C0, X0, C1, X1 = torch.cat(c0), torch.cat(x0), torch.cat(c1), torch.cat(x1)
+    # first run without forcing to obtain the correspondences, then force GT-derived logits
+    T, status, stats = dgr.register_voxelized(C0, X0, off0, C1, X1, off1)
+    idx1 = ops.batch_output('cuda', 'idx1').cpu().numpy()
+    logit = ops.batch_output('cuda', 'logit').cpu().numpy()
+    F0 = ops.batch_output('cuda', 'F0').reshape(-1, 32).cpu().numpy()
+    forced = np.concatenate([
+        synth.gt_forced_logits(X0[off0[p]:off0[p + 1]].cpu().numpy(),
+                               X1.cpu().numpy()[idx1[off0[p]:off0[p + 1]]], pairs[p][2], VOXEL)
+        for p in range(2)])
+    T, status, stats = dgr.register_voxelized(C0, X0, off0, C1, X1, off1,
+                                              forced_logits=torch.from_numpy(forced).cuda())
+    assert status.tolist() == [0, 0]
+    for p in range(2):
+        s0, e0, s1, e1 = off0[p], off0[p + 1], off1[p], off1[p + 1]
+        # batched features == per-pair oracle features (pairs do not interact through the batch)
+        oc0 = C0[s0:e0].cpu().numpy().copy(); oc0[:, 0] = 0
+        oF0 = oresunet.resunet_forward(ck['state_dict'], oc0, np.ones((e0 - s0, 1), np.float32), 3, 7, True)
+        assert np.abs(F0[s0:e0] - oF0).max() < 1e-4
+        # 6-D logits vs the oracle on the HIP path's own correspondences
+        li = idx1[s0:e0] - s1
+        assert li.min() >= 0 and li.max() < e1 - s1
+        oc1 = C1[s1:e1].cpu().numpy().copy(); oc1[:, 0] = 0
+        oc6, of6 = opipe.inlier_inputs(X0[s0:e0].cpu().numpy(), X1[s1:e1].cpu().numpy(), oc0, oc1,
+                                       np.arange(e0 - s0), li)
+        ologit = oresunet.resunet_forward(ck['state_dict_inlier'], oc6, of6, 6, 3, False)
+        assert rel_err(logit[s0:e0], ologit.reshape(-1)) < 1e-4
+        # registration vs the oracle on identical correspondences + forced logits
+        ow, owsum, thr = opipe.confidence_gate(forced[s0:e0], 0.05)
+        Ro, to, sto = oreg.global_registration(X0[s0:e0].cpu().numpy(), X1[s1:e1].cpu().numpy()[li], ow,
+                                               break_threshold_ratio=1e-4, quantization_size=2 * VOXEL)
+        assert np.abs(T[p, :3, :3] - Ro).max() < 1e-4, p
+        assert np.abs(T[p, :3, 3] - to.reshape(-1)).max() < 1e-4, p
+        assert rot_angle_deg(T[p, :3, :3], pairs[p][2][:3, :3]) < 2.0
+        assert abs(stats[p, 3] - owsum) < 1e-3 * owsum
+
+
+def test_low_confidence_status(setup):
+    from deepglobalregistration_amd import ops
+    ck, dgr, pairs = setup
+    xa, ca, _ = dgr.preprocess(pairs[0][0])
+    xb, cb, _ = dgr.preprocess(pairs[0][1])
+    forced = torch.full((len(xa),), -6.0).cuda()          # every correspondence rejected
+    T, status, stats = dgr.register_voxelized(ca, xa, [0, len(xa)], cb, xb, [0, len(xb)], forced_logits=forced)
+    assert status.tolist() == [1]
+    np.testing.assert_array_equal(T[0], np.eye(4))

@@ -1,0 +1,88 @@
+"""GPU parity: ResUNetBN2C forward (3-D FCGF and 6-D inlier net) against the CPU oracle.
+Tolerance: f32 conv stack, |err| <= 1e-4 * max|activation| per compared tensor (the HIP path
+folds batch norm into the kernels and accumulates with f32 atomics in arbitrary order)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import random_cloud_coords, rel_err
+from oracle import resunet as oresunet
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _check(D, cin, cout, ks, normalize, coords, feats, seed):
+    from deepglobalregistration_amd import ops, synth
+    sd = synth.synth_state_dict(D, cin, cout, ks, seed)
+    net = ops.NetHandle(sd, D, cin, cout, ks, normalize)
+    out = net.forward(torch.from_numpy(coords).cuda(), torch.from_numpy(feats).cuda()).cpu().numpy()
+    ref, inter = oresunet.resunet_forward(sd, coords, feats, D, ks, normalize, return_intermediates=True)
+    for name in ('s1', 's2', 's4', 's8', 's4_tr', 's2_tr', 's1_tr'):
+        got = net.intermediate(name)
+        assert got.shape == inter[name].shape, name
+        assert rel_err(got, np.maximum(inter[name], 0)) < TOL, (name, rel_err(got, inter[name]))
+    assert out.shape == ref.shape
+    assert rel_err(out, ref) < TOL, rel_err(out, ref)
+    return net, out, ref
+
+
+@pytest.mark.parametrize('ks', [7, 5, 3])
+def test_fcgf_forward_matches_oracle(ks):
+    rng = np.random.default_rng(ks)
+    coords = np.concatenate([random_cloud_coords(rng, 3000, 24, 3, batch=b) for b in (0, 1)])
+    feats = np.ones((len(coords), 1), np.float32)
+    net, out, ref = _check(3, 1, 32, ks, True, coords, feats, seed=ks)
+    np.testing.assert_allclose(np.linalg.norm(out, axis=1), 1.0, atol=1e-5)
+    stats = net.layer_stats()
+    assert len(stats) == 23 and stats[0]['K'] == ks ** 3 and stats[-1]['K'] == 1
+
+
+def test_fcgf_forward_general_input_features():
+    rng = np.random.default_rng(42)
+    coords = random_cloud_coords(rng, 2500, 16, 3)
+    feats = rng.standard_normal((len(coords), 3)).astype(np.float32)
+    _check(3, 3, 16, 3, False, coords, feats, seed=5)
+
+
+def test_inlier_net_6d_forward_matches_oracle():
+    rng = np.random.default_rng(7)
+    # 6-D rows built like the pipeline does: unique 3-D voxel + a second 3-D voxel
+    c0 = random_cloud_coords(rng, 1600, 12, 3)
+    c1 = c0[:, 1:] + rng.integers(-2, 3, (len(c0), 3)).astype(np.int32)
+    coords = np.concatenate([c0, c1], axis=1).astype(np.int32)
+    feats = np.cos(rng.uniform(-3, 3, (len(coords), 6))).astype(np.float32)
+    _check(6, 6, 1, 3, False, coords, feats, seed=11)
+
+
+def test_row_permutation_equivariance_full_size():
+    """Size-independent property at the BASELINE size (50k-pt pair @5cm): permuting the input rows
+    permutes the output rows (row alignment)."""
+    from deepglobalregistration_amd import ops, synth
+    xyz0, _, _ = synth.synth_pair(0, n_raw=50000)
+    p, c, _ = ops.voxelize(xyz0, 0.05)
+    sd = synth.synth_state_dict(3, 1, 32, 7, 0)
+    net = ops.NetHandle(sd, 3, 1, 32, 7, True)
+    ones = torch.ones(len(c), 1, device='cuda')
+    F = net.forward(c, ones)
+    perm = torch.randperm(len(c), device='cuda')
+    Fp = net.forward(c[perm].contiguous(), ones)
+    assert rel_err(Fp.cpu().numpy(), F[perm].cpu().numpy()) < TOL
+    np.testing.assert_allclose(F.norm(dim=1).cpu().numpy(), 1.0, atol=1e-5)
+
+
+def test_forward_rejects_bad_shapes():
+    from deepglobalregistration_amd import ops, synth
+    sd = synth.synth_state_dict(3, 1, 32, 3, 0)
+    net = ops.NetHandle(sd, 3, 1, 32, 3, True)
+    with pytest.raises(ValueError):
+        net.forward(torch.zeros((4, 7), dtype=torch.int32).cuda(), torch.ones(4, 1).cuda())
+    with pytest.raises(ValueError):
+        net.forward(torch.zeros((0, 4), dtype=torch.int32).cuda(), torch.ones(0, 1).cuda())
+    dup = torch.tensor([[0, 1, 1, 1], [0, 1, 1, 1]], dtype=torch.int32).cuda()
+    with pytest.raises(ValueError):
+        net.forward(dup, torch.ones(2, 1).cuda())
+    bad = dict(sd)
+    del bad['norm1.bn.weight']
+    with pytest.raises(ValueError):
+        ops.NetHandle(bad, 3, 1, 32, 3, True)
