@@ -1,0 +1,237 @@
+#!/usr/bin/env python
+"""Benchmark of the DGR inference hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--pairs-per-step B] [--n-raw 50000]
+
+One "step" = one pass of the hot path (FCGF x2 -> 1-NN -> 6-D inputs -> 6-D inlier net -> gate ->
+weighted Procrustes -> SE(3) refinement; dgr_register_batch) over one batch of B synthetic
+3DMatch-shaped pairs (BASELINE.json configs[1]: 50k raw points per fragment, 5 cm voxels, conv1
+k=7) whose voxelised coordinates are already resident in HBM.  With N > 1 (launched through
+torch.distributed.run, one process per GPU) every rank registers its own B pairs (weak scaling,
+pairs are independent units; no collective on the data path), the weights come from rank 0 by ONE
+RCCL broadcast and the results are gathered on rank 0.
+
+Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for the definition of every field.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+PEAK_HBM_GBPS = 8000.0          # spec
+
+
+def conv_work(stats):
+    """Algorithmic work of one net forward from the per-layer statistics:
+    FLOP = 2 P Cin Cout; compulsory bytes = 4 (Nin Cin + Nout Cout + Kne Cin Cout) + 8 P."""
+    flop = sum(2.0 * s['pairs'] * s['cin'] * s['cout'] for s in stats)
+    byts = sum(4.0 * (s['n_in'] * s['cin'] + s['n_out'] * s['cout'] + s['nonempty'] * s['cin'] * s['cout'])
+               + 8.0 * s['pairs'] for s in stats)
+    flop_c64 = sum(2.0 * s['pairs'] * s['cin'] * s['cout'] for s in stats if max(s['cin'], s['cout']) <= 64)
+    byts_c64 = sum(4.0 * (s['n_in'] * s['cin'] + s['n_out'] * s['cout'] + s['nonempty'] * s['cin'] * s['cout'])
+                   + 8.0 * s['pairs'] for s in stats if max(s['cin'], s['cout']) <= 64)
+    return flop, byts, flop_c64, byts_c64
+
+
+def cpu_baseline(ck, xyz0, xyz1, voxel, T_gt):
+    """The CPU oracle (restated reference CPU path, kind "port") timed on this host on a bounded
+    sample of the same workload: ONE pair, FCGF on both clouds and the 6-D net at full size, the
+    1-NN search on every 8th query row (scaled x8), refinement at full size."""
+    from deepglobalregistration_amd import synth
+    from oracle import knn as oknn, pipeline as opipe, registration as oreg, resunet as oresunet
+    torch.set_num_threads(os.cpu_count() or 1)
+    t = {}
+    t0 = time.time()
+    p0, c0, f0 = opipe.preprocess(xyz0, voxel)
+    p1, c1, f1 = opipe.preprocess(xyz1, voxel)
+    t['voxelize'] = time.time() - t0
+    t0 = time.time()
+    F0 = oresunet.resunet_forward(ck['state_dict'], c0, f0, 3, ck['config']['feat_conv1_kernel_size'], True)
+    F1 = oresunet.resunet_forward(ck['state_dict'], c1, f1, 3, ck['config']['feat_conv1_kernel_size'], True)
+    t['fcgf'] = time.time() - t0
+    t0 = time.time()
+    sub = np.arange(0, len(F0), 8)
+    idx_sub = oknn.find_knn(F0[sub], F1, nn_max_n=250).reshape(-1)
+    t['knn'] = (time.time() - t0) * len(F0) / len(sub)
+    # remaining rows: any plausible correspondence keeps the 6-D workload shape (nearest by a cheap proxy)
+    idx1 = np.repeat(idx_sub, 8)[:len(F0)]
+    t0 = time.time()
+    coords6, feats6 = opipe.inlier_inputs(p0, p1, c0, c1, np.arange(len(idx1)), idx1)
+    _, sel = np.unique(coords6, axis=0, return_index=True)   # proxy rows may collide in 6-D; keep unique
+    sel = np.sort(sel)
+    oresunet.resunet_forward(ck['state_dict_inlier'], coords6[sel], feats6[sel], 6, 3, False)
+    t['inlier_net'] = (time.time() - t0) * len(idx1) / len(sel)
+    t0 = time.time()
+    forced = synth.gt_forced_logits(p0, p1[idx1], T_gt, voxel)
+    w, wsum, thr = opipe.confidence_gate(forced)
+    if wsum < thr:   # keep the refinement workload even if the proxy correspondences are poor
+        w = np.clip(np.random.default_rng(0).uniform(0, 1, (len(idx1), 1)), 0.05, 1).astype(np.float32)
+    oreg.global_registration(p0, p1[idx1], w, break_threshold_ratio=1e-4, quantization_size=2 * voxel)
+    t['registration'] = time.time() - t0
+    total = t['fcgf'] + t['knn'] + t['inlier_net'] + t['registration']
+    return {'value': 1.0 / total, 'unit': 'pairs/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '1 pair at full size; 1-NN on every 8th query row scaled x8; voxelisation excluded',
+            'stage_s': {k: round(v, 3) for k, v in t.items()}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--pairs-per-step', type=int, default=2, help='pairs per rank per step')
+    ap.add_argument('--n-raw', type=int, default=50000, help='raw points per fragment')
+    ap.add_argument('--voxel', type=float, default=0.05)
+    ap.add_argument('--kind', default='indoor', choices=['indoor', 'outdoor'])
+    ap.add_argument('--conv1-ks', type=int, default=7)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-refine', action='store_true', help='ablation: stop after weighted Procrustes')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback)'
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+
+    from deepglobalregistration_amd import dist as ddist, ops, synth
+    from deepglobalregistration_amd.core.deep_global_registration import DeepGlobalRegistration
+
+    B = args.pairs_per_step
+    ck = synth.synth_checkpoint(seed=0, voxel_size=args.voxel, feat_conv1_kernel_size=args.conv1_ks) if rank == 0 else None
+    ck = ddist.broadcast_checkpoint(ck, src=0, device=device)
+    dgr = DeepGlobalRegistration({'weights': ck, 'clip_weight_thresh': 0.05}, device)
+
+    # this rank's pairs (seeds rank*B .. rank*B+B-1), voxelised once, resident in HBM
+    pairs = [synth.synth_pair(rank * B + i, n_raw=args.n_raw, kind=args.kind) for i in range(B)]
+    x0, c0, x1, c1, off0, off1 = [], [], [], [], [0], [0]
+    t_vox = time.time()
+    for p, (a, b, _) in enumerate(pairs):
+        xa, ca, _ = dgr.preprocess(a, batch_index=p)
+        xb, cb, _ = dgr.preprocess(b, batch_index=p)
+        x0.append(xa); c0.append(ca); x1.append(xb); c1.append(cb)
+        off0.append(off0[-1] + len(xa)); off1.append(off1[-1] + len(xb))
+    torch.cuda.synchronize()
+    t_vox = (time.time() - t_vox) / B
+    C0, X0, C1, X1 = torch.cat(c0), torch.cat(x0), torch.cat(c1), torch.cat(x1)
+
+    def step(forced=None):
+        return dgr.register_voxelized(C0, X0, off0, C1, X1, off1, forced_logits=forced,
+                                      skip_refinement=args.no_refine)
+
+    # untimed pass: correspondences for the teacher-forced logits (synthetic weights => the learned
+    # confidence is meaningless; the inlier net still runs in every timed step)
+    step()
+    idx1 = ops.batch_output(device, 'idx1').cpu().numpy()
+    X0h, X1h = X0.cpu().numpy(), X1.cpu().numpy()
+    forced = torch.from_numpy(np.concatenate([
+        synth.gt_forced_logits(X0h[off0[p]:off0[p + 1]], X1h[idx1[off0[p]:off0[p + 1]]], pairs[p][2], args.voxel)
+        for p in range(B)])).to(device)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(forced)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        T, status, stats = step(forced)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    gathered = ddist.gather_results(T, status, stats, dst=0, device=device)
+
+    # ---- profiled re-run of the same K steps: HIP events around every sparse-conv launch --------
+    ops.set_profiling(device, True)
+    prof = {}
+    for _ in range(args.steps):
+        step(forced)
+        st = ops.stage_times(device)
+        for k, v in st.items():
+            prof[k] = prof.get(k, 0.0) + v
+    ops.set_profiling(device, False)
+    prof = {k: v / args.steps for k, v in prof.items()}
+
+    if rank == 0:
+        # algorithmic work of the conv kernel per step, from the kernel maps of this very input
+        fc = dgr.fcgf_model._handle()
+        ones0 = torch.ones(len(C0), 1, device=device)
+        fc.forward(C0, ones0); s_a = fc.layer_stats()
+        fc.forward(C1, torch.ones(len(C1), 1, device=device)); s_b = fc.layer_stats()
+        coords6, feats6 = ops.inlier_inputs(C0, X0, C1, X1, torch.from_numpy(idx1).to(device),
+                                            dgr.inlier_feature_type)
+        inl = dgr.inlier_model._handle()
+        inl.forward(coords6, feats6); s_c = inl.layer_stats()
+        work = [conv_work(s) for s in (s_a, s_b, s_c)]
+        flop = sum(w[0] for w in work); byts = sum(w[1] for w in work)
+        flop64 = sum(w[2] for w in work); byts64 = sum(w[3] for w in work)
+        n_launch = max(1, int(prof['conv_launches']))
+        conv_ms = prof['conv_kernels']
+        achieved = flop / (conv_ms * 1e-3) / 1e12
+        T_all, status_all, stats_all = gathered
+        te, re = [], []
+        for p in range(B):
+            if status_all[p] == 0:
+                Tg = pairs[p][2]
+                te.append(float(np.linalg.norm(T_all[p][:3, 3] - Tg[:3, 3])))
+                c = (np.trace(T_all[p][:3, :3].T @ Tg[:3, :3]) - 1) / 2
+                re.append(float(np.degrees(np.arccos(np.clip(c, -1, 1)))))
+        ms_per_step = elapsed / args.steps * 1e3
+        out = {
+            'metric': 'pair registrations/sec (FCGF x2 + 1-NN + 6-D inlier net + gate + weighted Procrustes + SE(3) refinement)',
+            'value': world * B * args.steps / elapsed, 'unit': 'pairs/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'data': 'synthetic 3DMatch-shaped pairs, seeded synthetic weights, teacher-forced inlier logits',
+            'config': {'workload': f'{B} pairs/step/GPU, {args.n_raw} raw pts/fragment, {args.kind}, voxel {args.voxel}, '
+                                   f'conv1 k={args.conv1_ks} (BASELINE configs[1])',
+                       'voxels_per_pair': [int(off0[-1] / B), int(off1[-1] / B)],
+                       'pairs_per_step_per_gpu': B, 'refinement': not args.no_refine,
+                       'parallelism': f'pair-sharded x{world}, no data-path collective'},
+            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                         'kernel': 'sparse_conv_mfma', 'launches_per_step': n_launch,
+                         'avg_launch_us': conv_ms * 1e3 / n_launch, 'gflop_per_step': flop / 1e9,
+                         'compulsory_gbytes_per_step': byts / 1e9,
+                         'hbm_gbps_compulsory': byts / (conv_ms * 1e-3) / 1e9,
+                         'hbm_frac_compulsory': byts / (conv_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+                         'c_le_64_layers': {'gflop': flop64 / 1e9, 'gbytes': byts64 / 1e9}},
+            'stage_ms_per_step': {k: round(v, 3) for k, v in prof.items() if k != 'conv_launches'},
+            'te_m_mean': float(np.mean(te)) if te else None, 're_deg_mean': float(np.mean(re)) if re else None,
+            'status': [int(s) for s in status_all.tolist()],
+            'iterations': [int(v) for v in stats_all[:, 0].tolist()],
+            'voxelize_ms_per_pair': t_vox * 1e3,
+        }
+        if not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(ck, pairs[0][0], pairs[0][1], args.voxel, pairs[0][2])
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

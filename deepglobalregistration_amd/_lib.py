@@ -61,10 +61,11 @@ SIGNATURES = {
     'dgr_se3_refine': (C.c_int, [vp, vp, vp, vp, C.c_int64, C.c_float, C.c_int, C.c_int, C.c_double,
                                  c_f32p, c_f32p, c_i32p, c_f32p, c_i32p, vp]),
     'dgr_register_batch': (C.c_int, [vp, vp, vp, vp, vp, c_i64p, vp, vp, c_i64p, C.c_int,
-                                     C.POINTER(Params), vp, c_f32p, c_i32p, c_f32p, vp]),
+                                     C.POINTER(Params), vp, vp, c_f32p, c_i32p, c_f32p, vp]),
     'dgr_register_batch_output': (C.c_int, [vp, C.c_int, vp, C.c_int64, c_i64p, vp]),
     'dgr_ctx_set_profiling': (C.c_int, [vp, C.c_int]),
     'dgr_ctx_stage_times': (C.c_int, [vp, c_f32p]),
+    'dgr_ctx_conv_launches': (C.c_int64, [vp]),
 }
 
 _lib = None

@@ -188,10 +188,10 @@ class DeepGlobalRegistration:
                                        forced_logits=forced_logits, skip_refinement=skip_refinement)
 
     def register_voxelized(self, coords0, xyz0, off0, coords1, xyz1, off1, forced_logits=None,
-                           skip_refinement=False):
+                           skip_refinement=False, override_idx1=None):
         T, status, stats = ops.register_batch(
             self.fcgf_model._handle(), self.inlier_model._handle(), coords0, xyz0, off0, coords1, xyz1, off1,
             self.voxel_size, clip_weight_thresh=self.clip_weight_thresh,
             inlier_feature_type=self.inlier_feature_type, break_threshold_ratio=1e-4,
-            skip_refinement=skip_refinement, forced_logit=forced_logits)
+            skip_refinement=skip_refinement, forced_logit=forced_logits, override_idx1=override_idx1)
         return T.astype(np.float64), status, stats

@@ -147,3 +147,5 @@ extern "C" int dgr_ctx_stage_times(dgr_ctx *ctx, float times_ms[8]) {
   memcpy(times_ms, ctx->stage_ms, sizeof(ctx->stage_ms));
   return DGR_OK;
 }
+
+extern "C" int64_t dgr_ctx_conv_launches(dgr_ctx *ctx) { return ctx ? ctx->conv_launches : 0; }

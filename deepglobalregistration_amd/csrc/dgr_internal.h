@@ -164,13 +164,17 @@ struct dgr_ctx {
   int64_t conv_launches = 0;  // conv kernel launches covered by stage_ms[7]
   DgrBatchOutputs last;
   DgrEventPool events;
+  // event spans recorded while profiling; resolved by dgr_ctx_collect_profile after a sync
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> conv_spans, map3_spans, map6_spans;
   int32_t *flag_dev = nullptr;  // error flag word of the current top-level call (arena)
 };
 
 // internal forward that does not reset the arena (used by the fused pipeline)
 int dgr_resunet_forward_impl(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, const float *feats,
-                             int64_t N, float *out, hipStream_t stream, float *maps_ms,
-                             float *conv_ms);
+                             int64_t N, float *out, hipStream_t stream);
+// after the stream has been synchronised: fills stage_ms[5..7] and conv_launches from the spans
+int dgr_ctx_collect_profile(dgr_ctx *ctx);
+void dgr_ctx_begin_profile(dgr_ctx *ctx);
 
 // knn.hip / reg.hip / misc.hip internals used by the fused pipeline
 int dgr_knn1_impl(dgr_ctx *ctx, const float *F0, int64_t N0, const float *F1, int64_t N1, int C,

@@ -189,7 +189,6 @@ struct Fwd {
   hipStream_t stream;
   DgrMapSet ms;
   bool prof;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> spans;
 
   // one conv: out = shift (+res) ; out += sum_k in[.] W[k]
   int conv(int li, const Tensor &in, const DgrKernelMap *km, bool swapped, int lvl_in, int lvl_out,
@@ -224,7 +223,7 @@ struct Fwd {
     DGR_CHECK(dgr_conv_launch(a, ctx->num_cus, stream));
     if (prof) {
       DGR_HIP_CHECK(hipEventRecord(e1, stream));
-      spans.push_back({e0, e1});
+      ctx->conv_spans.push_back({e0, e1});
     }
     LayerRun &r = net->runs[li];
     r.rule_ptr = km ? km->rule_ptr : nullptr;
@@ -234,8 +233,7 @@ struct Fwd {
 };
 
 int dgr_resunet_forward_impl(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, const float *feats,
-                             int64_t N, float *out, hipStream_t stream, float *maps_ms,
-                             float *conv_ms) {
+                             int64_t N, float *out, hipStream_t stream) {
   DgrArena &A = ctx->arena;
   Fwd f;
   f.ctx = ctx; f.net = net; f.stream = stream; f.prof = ctx->profiling;
@@ -246,7 +244,10 @@ int dgr_resunet_forward_impl(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, 
   }
   f.ms.overflow = ctx->flag_dev;
   DGR_CHECK(dgr_build_maps(A, coords, N, net->D, net->conv1_ks, &f.ms, stream));
-  if (f.prof) DGR_HIP_CHECK(hipEventRecord(m1, stream));
+  if (f.prof) {
+    DGR_HIP_CHECK(hipEventRecord(m1, stream));
+    (net->D == 3 ? ctx->map3_spans : ctx->map6_spans).push_back({m0, m1});
+  }
   const DgrMapSet &ms = f.ms;
   const int64_t n1 = ms.cm[0].n_cap, n2 = ms.cm[1].n_cap, n4 = ms.cm[2].n_cap, n8 = ms.cm[3].n_cap;
   auto buf = [&](int64_t rows, int cols) -> float * { return A.get<float>((size_t)rows * cols); };
@@ -316,18 +317,31 @@ int dgr_resunet_forward_impl(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, 
   I["s2_tr"] = {cat2, 128, 64, ms.cm[1].n_dev};
   I["s1_tr"] = {cat1, 96, 64, ms.cm[0].n_dev};
 
-  if (f.prof) {
-    DGR_HIP_CHECK(hipStreamSynchronize(stream));
-    float ms_maps = 0.f, ms_conv = 0.f, t = 0.f;
-    DGR_HIP_CHECK(hipEventElapsedTime(&ms_maps, m0, m1));
-    for (auto &sp : f.spans) {
+  return DGR_OK;
+}
+
+void dgr_ctx_begin_profile(dgr_ctx *ctx) {
+  ctx->events.used = 0;
+  ctx->conv_spans.clear();
+  ctx->map3_spans.clear();
+  ctx->map6_spans.clear();
+  ctx->conv_launches = 0;
+}
+
+int dgr_ctx_collect_profile(dgr_ctx *ctx) {
+  auto total = [](const std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, float *out) -> int {
+    float s = 0.f, t = 0.f;
+    for (auto &sp : v) {
       DGR_HIP_CHECK(hipEventElapsedTime(&t, sp.first, sp.second));
-      ms_conv += t;
+      s += t;
     }
-    if (maps_ms) *maps_ms += ms_maps;
-    if (conv_ms) *conv_ms += ms_conv;
-    ctx->conv_launches += (int64_t)f.spans.size();
-  }
+    *out = s;
+    return DGR_OK;
+  };
+  DGR_CHECK(total(ctx->map3_spans, &ctx->stage_ms[5]));
+  DGR_CHECK(total(ctx->map6_spans, &ctx->stage_ms[6]));
+  DGR_CHECK(total(ctx->conv_spans, &ctx->stage_ms[7]));
+  ctx->conv_launches = (int64_t)ctx->conv_spans.size();
   return DGR_OK;
 }
 
@@ -369,16 +383,14 @@ extern "C" int dgr_resunet_forward(dgr_ctx *ctx, dgr_net *net, const int32_t *co
   DGR_HIP_CHECK(hipSetDevice(ctx->device));
   DGR_CHECK(ctx->arena.reset());
   DGR_CHECK(dgr_ctx_new_flag(ctx, stream));
-  ctx->events.used = 0;
-  float maps_ms = 0.f, conv_ms = 0.f;
-  if (ctx->profiling) ctx->conv_launches = 0;
-  DGR_CHECK(dgr_resunet_forward_impl(ctx, net, coords, feats, N, out, stream, &maps_ms, &conv_ms));
+  dgr_ctx_begin_profile(ctx);
+  DGR_CHECK(dgr_resunet_forward_impl(ctx, net, coords, feats, N, out, stream));
+  DGR_CHECK(dgr_ctx_check_flag(ctx, stream));  // synchronises the stream
   if (ctx->profiling) {
     memset(ctx->stage_ms, 0, sizeof(ctx->stage_ms));
-    ctx->stage_ms[net->D == 3 ? 5 : 6] = maps_ms;
-    ctx->stage_ms[7] = conv_ms;
+    DGR_CHECK(dgr_ctx_collect_profile(ctx));
   }
-  return dgr_ctx_check_flag(ctx, stream);
+  return DGR_OK;
 }
 
 extern "C" int dgr_net_get_intermediate(dgr_ctx *ctx, dgr_net *net, const char *name, float *host_out,

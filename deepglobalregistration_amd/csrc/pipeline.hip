@@ -123,6 +123,11 @@ __global__ void fill_kernel(float *p, int64_t n, float v) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
 }
 
+__global__ void override_idx_kernel(int64_t *idx, const int64_t *__restrict__ ovr, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && ovr[i] >= 0) idx[i] = ovr[i];
+}
+
 __global__ void add_offset_kernel(int64_t *idx, int64_t n, int64_t off) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) idx[i] += off;
@@ -146,7 +151,8 @@ struct StageTimer {
 extern "C" int dgr_register_batch(dgr_ctx *ctx, dgr_net *fcgf, dgr_net *inlier, const int32_t *coords0,
                                   const float *xyz0, const int64_t *off0, const int32_t *coords1,
                                   const float *xyz1, const int64_t *off1, int npairs, const dgr_params *prm,
-                                  const float *forced_logit, float *T_out, int32_t *status_out,
+                                  const int64_t *override_idx1, const float *forced_logit, float *T_out,
+                                  int32_t *status_out,
                                   float *stats_out, dgr_stream stream_) {
   DGR_REQUIRE(ctx && fcgf && inlier && coords0 && xyz0 && off0 && coords1 && xyz1 && off1 && prm && T_out &&
                   status_out,
@@ -163,14 +169,12 @@ extern "C" int dgr_register_batch(dgr_ctx *ctx, dgr_net *fcgf, dgr_net *inlier, 
   hipStream_t stream = (hipStream_t)stream_;
   DGR_HIP_CHECK(hipSetDevice(ctx->device));
   DGR_CHECK(ctx->arena.reset());
-  ctx->events.used = 0;
+  dgr_ctx_begin_profile(ctx);
   DGR_CHECK(dgr_ctx_new_flag(ctx, stream));
   DgrArena &A = ctx->arena;
   const int64_t n0 = off0[npairs], n1 = off1[npairs];
   const int C = dgr_net_out_channels(fcgf);
   StageTimer tm{ctx, stream, {}, ctx->profiling};
-  float maps3 = 0.f, maps6 = 0.f, conv_ms = 0.f;
-  if (ctx->profiling) ctx->conv_launches = 0;
 
   float *F0, *F1, *ones, *feats6, *logit, *weights;
   int64_t *idx1, *off0_dev;
@@ -193,9 +197,9 @@ extern "C" int dgr_register_batch(dgr_ctx *ctx, dgr_net *fcgf, dgr_net *inlier, 
   DGR_CHECK(tm.rec(0, 0));
   {
     DgrArena::Mark mk = A.mark();
-    DGR_CHECK(dgr_resunet_forward_impl(ctx, fcgf, coords0, ones, n0, F0, stream, &maps3, &conv_ms));
+    DGR_CHECK(dgr_resunet_forward_impl(ctx, fcgf, coords0, ones, n0, F0, stream));
     A.rewind(mk);
-    DGR_CHECK(dgr_resunet_forward_impl(ctx, fcgf, coords1, ones, n1, F1, stream, &maps3, &conv_ms));
+    DGR_CHECK(dgr_resunet_forward_impl(ctx, fcgf, coords1, ones, n1, F1, stream));
     A.rewind(mk);
   }
   DGR_CHECK(tm.rec(0, 1));
@@ -207,6 +211,8 @@ extern "C" int dgr_register_batch(dgr_ctx *ctx, dgr_net *fcgf, dgr_net *inlier, 
     if (off1[p] != 0)
       add_offset_kernel<<<(int)dgr_ceil_div(m0, 256), 256, 0, stream>>>(idx1 + off0[p], m0, off1[p]);
   }
+  if (override_idx1)
+    override_idx_kernel<<<(int)dgr_ceil_div(n0, 256), 256, 0, stream>>>(idx1, override_idx1, n0);
   DGR_CHECK(tm.rec(1, 1));
   // Step 3: 6-D coordinates + inlier features
   DGR_CHECK(tm.rec(2, 0));
@@ -216,7 +222,7 @@ extern "C" int dgr_register_batch(dgr_ctx *ctx, dgr_net *fcgf, dgr_net *inlier, 
   DGR_CHECK(tm.rec(3, 0));
   {
     DgrArena::Mark mk = A.mark();
-    DGR_CHECK(dgr_resunet_forward_impl(ctx, inlier, coords6, feats6, n0, logit, stream, &maps6, &conv_ms));
+    DGR_CHECK(dgr_resunet_forward_impl(ctx, inlier, coords6, feats6, n0, logit, stream));
     A.rewind(mk);
   }
   DGR_CHECK(tm.rec(3, 1));
@@ -259,9 +265,7 @@ extern "C" int dgr_register_batch(dgr_ctx *ctx, dgr_net *fcgf, dgr_net *inlier, 
   if (ctx->profiling) {
     memset(ctx->stage_ms, 0, sizeof(ctx->stage_ms));
     for (int s = 0; s < 5; ++s) DGR_HIP_CHECK(hipEventElapsedTime(&ctx->stage_ms[s], tm.e[s][0], tm.e[s][1]));
-    ctx->stage_ms[5] = maps3;
-    ctx->stage_ms[6] = maps6;
-    ctx->stage_ms[7] = conv_ms;
+    DGR_CHECK(dgr_ctx_collect_profile(ctx));
   }
   return DGR_OK;
 }

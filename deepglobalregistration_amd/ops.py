@@ -266,7 +266,7 @@ def se3_refine(X, Y, w, quantization_size=1.0, max_iter=1000, max_break_count=20
 def register_batch(fcgf, inlier, coords0, xyz0, off0, coords1, xyz1, off1, voxel_size,
                    clip_weight_thresh=0.05, inlier_feature_type='coords', max_iter=1000,
                    max_break_count=20, break_threshold_ratio=1e-4, skip_refinement=False,
-                   forced_logit=None):
+                   forced_logit=None, override_idx1=None):
     """Fused pipeline over a batch of voxelised pairs (dgr_register_batch).  Returns
     T [npairs,4,4] float32, status [npairs] int32, stats [npairs,4] float32."""
     lib = _lib.load()
@@ -289,8 +289,13 @@ def register_batch(fcgf, inlier, coords0, xyz0, off0, coords1, xyz1, off1, voxel
         fl = _as(forced_logit, torch.float32, dev).reshape(-1)
         if fl.shape[0] != coords0.shape[0]:
             raise ValueError('forced_logit must have one entry per row of fragment 0')
+    ov = None
+    if override_idx1 is not None:
+        ov = _as(override_idx1, torch.int64, dev).reshape(-1)
+        if ov.shape[0] != coords0.shape[0]:
+            raise ValueError('override_idx1 must have one entry per row of fragment 0')
     check(lib.dgr_register_batch(get_ctx(dev), fcgf.handle, inlier.handle, ptr(coords0), ptr(xyz0), o0,
-                                 ptr(coords1), ptr(xyz1), o1, npairs, C.byref(prm), ptr(fl),
+                                 ptr(coords1), ptr(xyz1), o1, npairs, C.byref(prm), ptr(ov), ptr(fl),
                                  T.ctypes.data_as(_lib.c_f32p), status.ctypes.data_as(_lib.c_i32p),
                                  stats.ctypes.data_as(_lib.c_f32p), stream_ptr(dev.index)))
     return T.reshape(npairs, 4, 4), status, stats
@@ -322,4 +327,6 @@ def stage_times(device):
     t = (C.c_float * 8)()
     check(_lib.load().dgr_ctx_stage_times(get_ctx(device), t))
     names = ['fcgf', 'knn', 'inlier_inputs', 'inlier_net', 'registration', 'maps_3d', 'maps_6d', 'conv_kernels']
-    return dict(zip(names, [float(v) for v in t]))
+    out = dict(zip(names, [float(v) for v in t]))
+    out['conv_launches'] = int(_lib.load().dgr_ctx_conv_launches(get_ctx(device)))
+    return out

@@ -160,8 +160,11 @@ int dgr_se3_refine(dgr_ctx *ctx, const float *X, const float *Y, const float *w,
  * (core/deep_global_registration.py:248-300) for a batch of already voxelised pairs, without
  * intermediate host synchronisation.  Pair p uses rows [off0[p], off0[p+1]) of coords0/xyz0 and
  * [off1[p], off1[p+1]) of coords1/xyz1 (host offset arrays, npairs+1 entries); the batch column
- * of the coords must equal p.  forced_logit (dev f32 [sum N0], may be NULL) overrides the inlier
- * network's logits after it ran (teacher forcing for synthetic weights).
+ * of the coords must equal p.  Two harness-only overrides exist because no trained checkpoint is
+ * available offline (both NULL in production, see DESIGN.md "Synthetic workload"):
+ * override_idx1 (dev int64 [sum N0], batch-global fragment-1 row or -1 = keep) replaces 1-NN
+ * results after the search ran; forced_logit (dev f32 [sum N0]) replaces the inlier network's
+ * logits after it ran.
  * T_out host f32 [npairs,16] row-major 4x4, status_out host int32 [npairs],
  * stats_out host f32 [npairs,4] = (iterations, loss, break_count, wsum) or NULL. */
 typedef struct {
@@ -177,7 +180,8 @@ typedef struct {
 int dgr_register_batch(dgr_ctx *ctx, dgr_net *fcgf, dgr_net *inlier, const int32_t *coords0,
                        const float *xyz0, const int64_t *off0, const int32_t *coords1,
                        const float *xyz1, const int64_t *off1, int npairs, const dgr_params *params,
-                       const float *forced_logit, float *T_out, int32_t *status_out,
+                       const int64_t *override_idx1, const float *forced_logit, float *T_out,
+                       int32_t *status_out,
                        float *stats_out, dgr_stream stream);
 /* device-side intermediates of the last dgr_register_batch (valid until the next call on this
  * ctx): which = 0 idx1 (int64 [sumN0]), 1 logit (f32 [sumN0]), 2 weights (f32 [sumN0]),
@@ -191,6 +195,8 @@ int dgr_register_batch_output(dgr_ctx *ctx, int which, void *dst_dev, int64_t ca
  * maps_3d, maps_6d, conv_kernels_total].  Synchronises. */
 int dgr_ctx_set_profiling(dgr_ctx *ctx, int enable);
 int dgr_ctx_stage_times(dgr_ctx *ctx, float times_ms[8]);
+/* number of sparse-conv kernel launches covered by times_ms[7] */
+int64_t dgr_ctx_conv_launches(dgr_ctx *ctx);
 
 #ifdef __cplusplus
 }
