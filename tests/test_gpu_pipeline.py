@@ -46,6 +46,9 @@ def test_stagewise_matches_oracle(setup):
     oi1 = oknn.find_knn(oF0, oF1, nn_max_n=250).reshape(-1)
     mism = np.nonzero(i1.cpu().numpy() != oi1)[0]
     assert len(mism) <= max(2, len(oi1) // 200), len(mism)   # flat synthetic walls produce near-ties
+    # untrained weights give ~0 % correct matches: override a share with ground-truth matches
+    gt = synth.gt_correspondences(op0, op1, T_gt, VOXEL)
+    oi1 = np.where(gt >= 0, gt, oi1)
     i1 = torch.from_numpy(oi1).cuda()
     feats6 = dgr.inlier_feature_generation(p0, p1, c0, c1, F0, F1, i0, i1)
     coords6, feats6b = ops.inlier_inputs(c0, p0, c1, p1, i1, 'coords')
@@ -95,17 +98,28 @@ def test_fused_batch_matches_stagewise_and_oracle(setup):
         x0.append(xa); c0.append(ca); x1.append(xb); c1.append(cb)
         off0.append(off0[-1] + len(xa)); off1.append(off1[-1] + len(xb))
     C0, X0, C1, X1 = torch.cat(c0), torch.cat(x0), torch.cat(c1), torch.cat(x1)
-    # first run without forcing to obtain the correspondences, then force GT-derived logits
-    T, status, stats = dgr.register_voxelized(C0, X0, off0, C1, X1, off1)
+    # untrained weights: override a share of the matches with ground-truth ones (batch-global rows),
+    # run once to obtain the final correspondences, then force GT-derived logits
+    ovr = np.concatenate([
+        (lambda g, o: np.where(g >= 0, g + o, -1))(
+            synth.gt_correspondences(X0[off0[p]:off0[p + 1]].cpu().numpy(), X1[off1[p]:off1[p + 1]].cpu().numpy(),
+                                     pairs[p][2], VOXEL, seed=p), off1[p])
+        for p in range(2)])
+    ovr_t = torch.from_numpy(ovr).cuda()
+    T, status, stats = dgr.register_voxelized(C0, X0, off0, C1, X1, off1, override_idx1=ovr_t)
     idx1 = ops.batch_output('cuda', 'idx1').cpu().numpy()
-    logit = ops.batch_output('cuda', 'logit').cpu().numpy()
-    F0 = ops.batch_output('cuda', 'F0').reshape(-1, 32).cpu().numpy()
     forced = np.concatenate([
         synth.gt_forced_logits(X0[off0[p]:off0[p + 1]].cpu().numpy(),
                                X1.cpu().numpy()[idx1[off0[p]:off0[p + 1]]], pairs[p][2], VOXEL)
         for p in range(2)])
-    T, status, stats = dgr.register_voxelized(C0, X0, off0, C1, X1, off1,
+    T, status, stats = dgr.register_voxelized(C0, X0, off0, C1, X1, off1, override_idx1=ovr_t,
                                               forced_logits=torch.from_numpy(forced).cuda())
+    idx1_b = ops.batch_output('cuda', 'idx1').cpu().numpy()
+    changed = np.nonzero(idx1_b != idx1)[0]       # atomics => a few near-tie matches may flip run to run
+    assert len(changed) <= len(idx1) // 200
+    idx1 = idx1_b                                  # the oracle below sees exactly what the second run saw
+    logit = ops.batch_output('cuda', 'logit').cpu().numpy()
+    F0 = ops.batch_output('cuda', 'F0').reshape(-1, 32).cpu().numpy()
     assert status.tolist() == [0, 0]
     for p in range(2):
         s0, e0, s1, e1 = off0[p], off0[p + 1], off1[p], off1[p + 1]
