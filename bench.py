@@ -82,6 +82,14 @@ def cpu_baseline(ck, xyz0, xyz1, voxel, T_gt):
             'stage_s': {k: round(v, 3) for k, v in t.items()}}
 
 
+_T0 = time.time()
+
+
+def log(msg):
+    if int(os.environ.get('RANK', 0)) == 0:
+        print(f'[bench +{time.time() - _T0:6.1f}s] {msg}', file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -115,7 +123,10 @@ def main():
     B = args.pairs_per_step
     ck = synth.synth_checkpoint(seed=0, voxel_size=args.voxel, feat_conv1_kernel_size=args.conv1_ks) if rank == 0 else None
     ck = ddist.broadcast_checkpoint(ck, src=0, device=device)
+    log('checkpoint ready')
     dgr = DeepGlobalRegistration({'weights': ck, 'clip_weight_thresh': 0.05}, device)
+    dgr.fcgf_model._handle(); dgr.inlier_model._handle()
+    log('weights resident in HBM')
 
     # this rank's pairs (seeds rank*B .. rank*B+B-1), voxelised once, resident in HBM
     pairs = [synth.synth_pair(rank * B + i, n_raw=args.n_raw, kind=args.kind) for i in range(B)]
@@ -143,7 +154,10 @@ def main():
         return dgr.register_voxelized(C0, X0, off0, C1, X1, off1, forced_logits=forced,
                                       skip_refinement=args.no_refine, override_idx1=ovr)
 
+    log(f'inputs voxelised: N0={off0[-1]} N1={off1[-1]} ({B} pairs)')
     step()      # untimed: final correspondences for the teacher-forced logits
+    torch.cuda.synchronize()
+    log('first pass done')
     idx1 = ops.batch_output(device, 'idx1').cpu().numpy()
     forced = torch.from_numpy(np.concatenate([
         synth.gt_forced_logits(X0h[off0[p]:off0[p + 1]], X1h[idx1[off0[p]:off0[p + 1]]], pairs[p][2], args.voxel)
@@ -157,6 +171,7 @@ def main():
     for _ in range(args.warmup):
         step(forced)
     barrier()
+    log('warmup done')
     t0 = time.perf_counter()
     for _ in range(args.steps):
         T, status, stats = step(forced)
@@ -166,6 +181,7 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    log(f'timed region done: {elapsed / args.steps * 1e3:.1f} ms/step')
     gathered = ddist.gather_results(T, status, stats, dst=0, device=device)
 
     # ---- profiled re-run of the same K steps: HIP events around every sparse-conv launch --------
@@ -178,6 +194,7 @@ def main():
             prof[k] = prof.get(k, 0.0) + v
     ops.set_profiling(device, False)
     prof = {k: v / args.steps for k, v in prof.items()}
+    log(f'profiled region done: {prof}')
 
     if rank == 0:
         # algorithmic work of the conv kernel per step, from the kernel maps of this very input
@@ -229,6 +246,7 @@ def main():
             'iterations': [int(v) for v in stats_all[:, 0].tolist()],
             'voxelize_ms_per_pair': t_vox * 1e3,
         }
+        log('roofline accounting done')
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(ck, pairs[0][0], pairs[0][1], args.voxel, pairs[0][2])
         else:

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from conftest import rot_angle_deg
-from helpers import rel_err
+from helpers import assert_refine_parity, rel_err
 from oracle import pipeline as opipe
 from oracle import registration as oreg
 from oracle import resunet as oresunet
@@ -68,11 +68,10 @@ def test_stagewise_matches_oracle(setup):
     from deepglobalregistration_amd.core.registration import GlobalRegistration
     R, t, st = GlobalRegistration(p0, ops.gather_rows3(p1, i1), weights=w, break_threshold_ratio=1e-4,
                                   quantization_size=2 * VOXEL)
-    Ro, to, sto = oreg.global_registration(op0, op1[oi1], ow, break_threshold_ratio=1e-4,
-                                           quantization_size=2 * VOXEL)
-    assert np.abs(R.cpu().numpy() - Ro).max() < 1e-4 and np.abs(t.cpu().numpy() - to).max() < 1e-4
+    Ro, to, sto = assert_refine_parity(op0, op1[oi1], ow, R.cpu().numpy(), t.cpu().numpy(), st,
+                                       break_threshold_ratio=1e-4, quantization_size=2 * VOXEL)
     # and the estimate is close to the ground truth pose
-    assert rot_angle_deg(Ro, T_gt[:3, :3]) < 2.0 and np.linalg.norm(to.reshape(-1) - T_gt[:3, 3]) < 0.1
+    assert rot_angle_deg(Ro, T_gt[:3, :3]) < 2.0 and np.linalg.norm(to - T_gt[:3, 3]) < 0.1
 
 
 def test_register_api(setup):
@@ -137,10 +136,9 @@ def test_fused_batch_matches_stagewise_and_oracle(setup):
         assert rel_err(logit[s0:e0], ologit.reshape(-1)) < 1e-4
         # registration vs the oracle on identical correspondences + forced logits
         ow, owsum, thr = opipe.confidence_gate(forced[s0:e0], 0.05)
-        Ro, to, sto = oreg.global_registration(X0[s0:e0].cpu().numpy(), X1[s1:e1].cpu().numpy()[li], ow,
-                                               break_threshold_ratio=1e-4, quantization_size=2 * VOXEL)
-        assert np.abs(T[p, :3, :3] - Ro).max() < 1e-4, p
-        assert np.abs(T[p, :3, 3] - to.reshape(-1)).max() < 1e-4, p
+        st = {'iterations': int(stats[p, 0]), 'loss': float(stats[p, 1]), 'break_count': int(stats[p, 2])}
+        assert_refine_parity(X0[s0:e0].cpu().numpy(), X1[s1:e1].cpu().numpy()[li], ow, T[p, :3, :3], T[p, :3, 3],
+                             st, break_threshold_ratio=1e-4, quantization_size=2 * VOXEL)
         assert rot_angle_deg(T[p, :3, :3], pairs[p][2][:3, :3]) < 2.0
         assert abs(stats[p, 3] - owsum) < 1e-3 * owsum
 
