@@ -3,6 +3,10 @@ import sys
 
 import numpy as np
 import pytest
+import torch
+
+# the oracle is many tiny CPU ops: more threads than ~16 only adds fork/join overhead
+torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
