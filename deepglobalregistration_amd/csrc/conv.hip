@@ -13,6 +13,8 @@
 // Weight layout (prepared once in net.hip): W[k][s][nb][lane][c], s = Cin_pad/8 K-steps,
 // nb = Cout_pad/32 column blocks, value = W_folded[k][8 s + 4 (lane>>5) + c][32 nb + (lane&31)],
 // so a wave fetches the B operands of 4 MFMAs with one coalesced 16-byte load per lane.
+#include <map>
+
 #include "dgr_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -176,9 +178,21 @@ static int launch_cfg(const ConvKArgs &ka, int64_t tile_bound, int num_cus, hipS
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     configured = 160 * 1024;
   }
-  int per_cu = (int)((160 * 1024) / (lds_bytes + 512));
-  if (per_cu > 4) per_cu = 4;
-  if (per_cu < 1) per_cu = 1;
+  // persistent grid: exactly as many blocks as can be co-resident (more would queue behind the
+  // resident ones and unbalance the tile ranges)
+  static std::map<size_t, int> occ_cache;
+  int per_cu;
+  auto it = occ_cache.find(lds_bytes);
+  if (it != occ_cache.end()) {
+    per_cu = it->second;
+  } else {
+    int n = 0;
+    DGR_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sparse_conv_mfma<WM, WN, MB, NB>, THREADS,
+                                                               lds_bytes));
+    per_cu = n < 1 ? 1 : n;
+    if (per_cu > 2048 / THREADS) per_cu = 2048 / THREADS;
+    occ_cache[lds_bytes] = per_cu;
+  }
   int64_t grid = (int64_t)num_cus * per_cu;
   if (tile_bound < grid) grid = tile_bound;
   grid = (grid + 7) / 8 * 8;

@@ -266,6 +266,67 @@ static int build_coord_maps_t(DgrArena &arena, const int32_t *coords, int64_t N,
   return DGR_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// D = 6: group the rows of a coordinate map by their first-half key (batch, x0, y0, z0)
+// ------------------------------------------------------------------------------------------
+__global__ void half_keys_kernel(const int32_t *__restrict__ coords7, const int32_t *n_dev,
+                                 int32_t *__restrict__ keys4) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= *n_dev) return;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) keys4[r * 4 + d] = coords7[r * 7 + d];
+}
+
+__global__ void bucket_count_kernel(const int32_t *__restrict__ keys4, const int32_t *n_dev,
+                                    const int32_t *__restrict__ table, uint32_t mask,
+                                    const int32_t *__restrict__ bkeys, int32_t *__restrict__ row_bucket,
+                                    int32_t *counts) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= *n_dev) return;
+  int32_t q[4] = {keys4[r * 4], keys4[r * 4 + 1], keys4[r * 4 + 2], keys4[r * 4 + 3]};
+  const int b = dgr_lookup<4>(table, mask, bkeys, q);
+  row_bucket[r] = b;
+  atomicAdd(&counts[b], 1);
+}
+
+__global__ void bucket_fill_kernel(const int32_t *__restrict__ row_bucket, const int32_t *n_dev,
+                                   const int32_t *__restrict__ start, int32_t *cursor,
+                                   int32_t *__restrict__ rows) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= *n_dev) return;
+  const int b = row_bucket[r];
+  rows[start[b] + atomicAdd(&cursor[b], 1)] = (int32_t)r;   // order inside a bucket is irrelevant
+}
+
+int dgr_build_half_buckets(DgrArena &arena, const DgrCoordMap &cm, DgrHalfBuckets *hb, hipStream_t stream) {
+  const int64_t n = cm.n_cap;
+  int32_t *keys, *flag, *rank, *nb_dev, *row_bucket, *counts, *cursor;
+  DGR_ALLOC(keys, arena, int32_t, n * 4);
+  DGR_ALLOC(flag, arena, int32_t, n);
+  DGR_ALLOC(rank, arena, int32_t, n);
+  DGR_ALLOC(nb_dev, arena, int32_t, 1);
+  DGR_ALLOC(row_bucket, arena, int32_t, n);
+  DGR_ALLOC(counts, arena, int32_t, n + 1);
+  DGR_ALLOC(cursor, arena, int32_t, n + 1);
+  DGR_ALLOC(hb->bkeys, arena, int32_t, n * 4);
+  DGR_ALLOC(hb->start, arena, int32_t, n + 1);
+  DGR_ALLOC(hb->rows, arena, int32_t, n);
+  half_keys_kernel<<<grid_for(n), 256, 0, stream>>>(cm.coords, cm.n_dev, keys);
+  DGR_CHECK(unique_rows_t<4>(arena, keys, cm.n_dev, n, flag, rank, nb_dev, &hb->table, &hb->mask, stream));
+  unique_compact<4><<<grid_for(n), 256, 0, stream>>>(keys, cm.n_dev, n, flag, rank, hb->bkeys, nullptr);
+  table_relabel<<<grid_for((int64_t)hb->mask + 1), 256, 0, stream>>>(hb->table, hb->mask + 1, rank);
+  DGR_HIP_CHECK(hipMemsetAsync(counts, 0, (size_t)(n + 1) * sizeof(int32_t), stream));
+  DGR_HIP_CHECK(hipMemsetAsync(cursor, 0, (size_t)(n + 1) * sizeof(int32_t), stream));
+  bucket_count_kernel<<<grid_for(n), 256, 0, stream>>>(keys, cm.n_dev, hb->table, hb->mask, hb->bkeys, row_bucket,
+                                                       counts);
+  DGR_LAUNCH_CHECK();
+  DGR_CHECK(dgr_exclusive_scan_i32(arena, counts, hb->start, n + 1, nullptr, stream));
+  bucket_fill_kernel<<<grid_for(n), 256, 0, stream>>>(row_bucket, cm.n_dev, hb->start, cursor, hb->rows);
+  DGR_LAUNCH_CHECK();
+  hb->built = true;
+  return DGR_OK;
+}
+
 int dgr_build_coord_maps(DgrArena &arena, const int32_t *coords, int64_t N, DgrMapSet *ms,
                          hipStream_t stream) {
   if (ms->nc == 4) return build_coord_maps_t<4>(arena, coords, N, ms, stream);

@@ -89,6 +89,17 @@ struct DgrCoordMap {
   uint32_t table_mask = 0;    // capacity - 1
 };
 
+// D = 6 only: rows grouped by their first-half key (batch, x0, y0, z0); lets the kernel-map search
+// enumerate 27 half-offsets per row instead of 729 full offsets (kmap.hip)
+struct DgrHalfBuckets {
+  int32_t *bkeys = nullptr;   // [n_buckets, 4] key of each bucket
+  int32_t *table = nullptr;   // half-key hash -> bucket id
+  uint32_t mask = 0;
+  int32_t *start = nullptr;   // [n_cap + 1] exclusive prefix of bucket sizes
+  int32_t *rows = nullptr;    // [n] row indices grouped by bucket
+  bool built = false;
+};
+
 struct DgrKernelMap {
   int K = 0;                    // kernel volume
   int32_t *rule_ptr = nullptr;  // [K+1] exclusive prefix of pairs per offset
@@ -102,6 +113,7 @@ struct DgrKernelMap {
 struct DgrMapSet {
   int D = 3, nc = 4, conv1_ks = 3;
   DgrCoordMap cm[4];     // ts = 1,2,4,8
+  DgrHalfBuckets hb[4];  // D = 6: half-key buckets of cm[l] (built for l < 3)
   DgrKernelMap same[4];  // 3^D at ts 1,2,4,8
   DgrKernelMap conv1;    // ks^D at ts = 1 (aliases same[0] when ks == 3)
   DgrKernelMap down[3];  // ts -> 2 ts (also used, swapped, by the transposed convs)

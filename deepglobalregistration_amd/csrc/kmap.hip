@@ -36,12 +36,15 @@ __device__ __forceinline__ int probe(const int32_t *__restrict__ out_coords, int
   return dgr_lookup<NC>(in_table, in_mask, in_coords, q);
 }
 
-// grid = (row blocks, K).  block_counts[k * RB + rb] = hits of offset k among rows of block rb.
+// ---- pass 1, generic: grid = (row blocks, K).  Probes every (output row, offset); the hit (or -1)
+// is cached in hits[k * n_cap + o] so that pass 2 never probes again, and the number of hits of
+// offset k among the rows of block rb goes to block_counts[k * RB + rb].
 template <int D>
 __global__ void __launch_bounds__(KM_THREADS)
-    kmap_count(const int32_t *__restrict__ out_coords, const int32_t *n_out_dev,
-               const int32_t *__restrict__ in_coords, const int32_t *__restrict__ in_table,
-               uint32_t in_mask, int ks, int ts_in, int RB, int32_t *__restrict__ block_counts) {
+    kmap_search(const int32_t *__restrict__ out_coords, const int32_t *n_out_dev,
+                const int32_t *__restrict__ in_coords, const int32_t *__restrict__ in_table,
+                uint32_t in_mask, int ks, int ts_in, int RB, int64_t n_cap, int32_t *__restrict__ hits,
+                int32_t *__restrict__ block_counts) {
   __shared__ int wave_cnt[KM_THREADS / 64];
   const int rb = blockIdx.x, k = blockIdx.y;
   const int n_out = *n_out_dev;
@@ -53,7 +56,10 @@ __global__ void __launch_bounds__(KM_THREADS)
   offset_of<D>(k, ks, ts_in, delta);
   const int64_t o = (int64_t)rb * KM_THREADS + threadIdx.x;
   int hit = -1;
-  if (o < n_out) hit = probe<D>(out_coords, o, delta, in_coords, in_table, in_mask);
+  if (o < n_out) {
+    hit = probe<D>(out_coords, o, delta, in_coords, in_table, in_mask);
+    hits[(int64_t)k * n_cap + o] = hit;
+  }
   unsigned long long m = __ballot(hit >= 0);
   if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = __popcll(m);
   __syncthreads();
@@ -65,22 +71,55 @@ __global__ void __launch_bounds__(KM_THREADS)
   }
 }
 
-template <int D>
+// ---- pass 1, D = 6 pruned: one thread per (output row, first-half offset).  A 6-D neighbour
+// (ca + da, cb + db) can only exist among the rows whose first half equals ca + da: look that bucket
+// up once (27 lookups per row instead of 729 probes) and test the second half of its rows.  hits[]
+// is pre-set to -1 and block_counts to 0 by the caller.
 __global__ void __launch_bounds__(KM_THREADS)
-    kmap_fill(const int32_t *__restrict__ out_coords, const int32_t *n_out_dev,
-              const int32_t *__restrict__ in_coords, const int32_t *__restrict__ in_table,
-              uint32_t in_mask, int ks, int ts_in, int RB, const int32_t *__restrict__ block_base,
+    kmap_search_pruned6(const int32_t *__restrict__ out_coords, const int32_t *n_out_dev,
+                        const int32_t *__restrict__ in_coords, DgrHalfBuckets hb, int ts_in, int RB,
+                        int64_t n_cap, int32_t *__restrict__ hits, int32_t *block_counts) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t o = t / 27;
+  const int ja = (int)(t - o * 27);
+  if (o >= *n_out_dev) return;
+  const int32_t *co = out_coords + o * 7;
+  int32_t q[4];
+  q[0] = co[0];
+  q[1] = co[1] + ((ja % 3) - 1) * ts_in;
+  q[2] = co[2] + (((ja / 3) % 3) - 1) * ts_in;
+  q[3] = co[3] + ((ja / 9) - 1) * ts_in;
+  const int b = dgr_lookup<4>(hb.table, hb.mask, hb.bkeys, q);
+  if (b < 0) return;
+  const int c4 = co[4], c5 = co[5], c6 = co[6];
+  const int beg = hb.start[b], end = hb.start[b + 1];
+  for (int p = beg; p < end; ++p) {
+    const int r = hb.rows[p];
+    const int32_t *ci = in_coords + (int64_t)r * 7;
+    const int d4 = ci[4] - c4, d5 = ci[5] - c5, d6 = ci[6] - c6;
+    // every component must be -ts, 0 or +ts (all coordinates of a level are multiples of ts)
+    if (abs(d4) <= ts_in && abs(d5) <= ts_in && abs(d6) <= ts_in) {
+      const int k = ja + 27 * ((d4 / ts_in + 1) + 3 * (d5 / ts_in + 1) + 9 * (d6 / ts_in + 1));
+      hits[(int64_t)k * n_cap + o] = r;
+      atomicAdd(&block_counts[(int64_t)k * RB + (int)(o / KM_THREADS)], 1);
+    }
+  }
+}
+
+// ---- pass 2: grid = (row blocks, K): rank the cached hits inside the block (row order) and write
+// the pairs at block_base + rank: sorted by (k, out), no atomics, no probing.
+__global__ void __launch_bounds__(KM_THREADS)
+    kmap_fill(const int32_t *n_out_dev, int RB, int64_t n_cap, const int32_t *__restrict__ hits,
+              const int32_t *__restrict__ block_counts, const int32_t *__restrict__ block_base,
               int32_t *__restrict__ pair_in, int32_t *__restrict__ pair_out, int64_t pair_cap,
               int32_t *overflow) {
   __shared__ int wave_cnt[KM_THREADS / 64];
   const int rb = blockIdx.x, k = blockIdx.y;
+  if (block_counts[(int64_t)k * RB + rb] == 0) return;   // most (offset, block) cells are empty in 6-D
   const int n_out = *n_out_dev;
-  if (rb * KM_THREADS >= n_out) return;
-  int32_t delta[D];
-  offset_of<D>(k, ks, ts_in, delta);
   const int64_t o = (int64_t)rb * KM_THREADS + threadIdx.x;
   int hit = -1;
-  if (o < n_out) hit = probe<D>(out_coords, o, delta, in_coords, in_table, in_mask);
+  if (o < n_out) hit = hits[(int64_t)k * n_cap + o];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned long long m = __ballot(hit >= 0);
   if (lane == 0) wave_cnt[wave] = __popcll(m);
@@ -126,9 +165,9 @@ __global__ void __launch_bounds__(1024)
 }
 
 template <int D>
-static int build_kernel_map_t(DgrArena &arena, const DgrCoordMap &in, const DgrCoordMap &out, int ks,
-                              int max_pairs_per_row, DgrKernelMap *km, int32_t *overflow,
-                              hipStream_t stream) {
+static int build_kernel_map_t(DgrArena &arena, const DgrCoordMap &in, const DgrCoordMap &out,
+                              const DgrHalfBuckets *in_buckets, int ks, int max_pairs_per_row,
+                              DgrKernelMap *km, int32_t *overflow, hipStream_t stream) {
   int K = 1;
   for (int d = 0; d < D; ++d) K *= ks;
   DGR_REQUIRE(K <= 1024, "kernel volume %d > 1024 not supported", K);
@@ -138,30 +177,46 @@ static int build_kernel_map_t(DgrArena &arena, const DgrCoordMap &in, const DgrC
   int64_t per_row = K < max_pairs_per_row ? K : max_pairs_per_row;
   km->pair_cap = per_row * n_cap;
   DGR_REQUIRE(km->pair_cap < (1ll << 31), "kernel map too large (%lld pairs)", (long long)km->pair_cap);
-  int32_t *counts, *base, *total;
-  DGR_ALLOC(counts, arena, int32_t, (int64_t)K * RB);
-  DGR_ALLOC(base, arena, int32_t, (int64_t)K * RB);
-  DGR_ALLOC(total, arena, int32_t, 1);
   DGR_ALLOC(km->rule_ptr, arena, int32_t, K + 1);
   DGR_ALLOC(km->tile_ptr, arena, int32_t, K + 1);
   DGR_ALLOC(km->pair_in, arena, int32_t, km->pair_cap);
   DGR_ALLOC(km->pair_out, arena, int32_t, km->pair_cap);
+  // transient: dense hit cache [K, n_cap] + per-(offset, block) counts; released after pass 2
+  DgrArena::Mark mk = arena.mark();
+  int32_t *counts, *base, *total, *hits;
+  DGR_ALLOC(counts, arena, int32_t, (int64_t)K * RB);
+  DGR_ALLOC(base, arena, int32_t, (int64_t)K * RB);
+  DGR_ALLOC(total, arena, int32_t, 1);
+  DGR_ALLOC(hits, arena, int32_t, (int64_t)K * n_cap);
   dim3 grid(RB, K);
-  kmap_count<D><<<grid, KM_THREADS, 0, stream>>>(out.coords, out.n_dev, in.coords, in.table,
-                                                 in.table_mask, ks, in.ts, RB, counts);
+  bool pruned = false;
+  if constexpr (D == 6) {
+    if (in_buckets && in_buckets->built && ks == 3) {
+      pruned = true;
+      DGR_HIP_CHECK(hipMemsetAsync(hits, 0xff, (size_t)K * n_cap * sizeof(int32_t), stream));
+      DGR_HIP_CHECK(hipMemsetAsync(counts, 0, (size_t)K * RB * sizeof(int32_t), stream));
+      const int64_t threads = n_cap * 27;
+      kmap_search_pruned6<<<(int)dgr_ceil_div(threads, KM_THREADS), KM_THREADS, 0, stream>>>(
+          out.coords, out.n_dev, in.coords, *in_buckets, in.ts, RB, n_cap, hits, counts);
+    }
+  }
+  if (!pruned)
+    kmap_search<D><<<grid, KM_THREADS, 0, stream>>>(out.coords, out.n_dev, in.coords, in.table,
+                                                    in.table_mask, ks, in.ts, RB, n_cap, hits, counts);
   DGR_LAUNCH_CHECK();
   DGR_CHECK(dgr_exclusive_scan_i32(arena, counts, base, (int64_t)K * RB, total, stream));
   kmap_finalize<<<1, 1024, 0, stream>>>(base, total, K, RB, km->rule_ptr, km->tile_ptr);
-  kmap_fill<D><<<grid, KM_THREADS, 0, stream>>>(out.coords, out.n_dev, in.coords, in.table,
-                                                in.table_mask, ks, in.ts, RB, base, km->pair_in,
-                                                km->pair_out, km->pair_cap, overflow);
+  kmap_fill<<<grid, KM_THREADS, 0, stream>>>(out.n_dev, RB, n_cap, hits, counts, base, km->pair_in,
+                                             km->pair_out, km->pair_cap, overflow);
   DGR_LAUNCH_CHECK();
+  arena.rewind(mk);
   km->built = true;
   return DGR_OK;
 }
 
 int dgr_build_coord_maps(DgrArena &arena, const int32_t *coords, int64_t N, DgrMapSet *ms,
                          hipStream_t stream);
+int dgr_build_half_buckets(DgrArena &arena, const DgrCoordMap &cm, DgrHalfBuckets *hb, hipStream_t stream);
 
 int dgr_build_maps(DgrArena &arena, const int32_t *coords, int64_t N, int D, int conv1_ks,
                    DgrMapSet *ms, hipStream_t stream) {
@@ -179,31 +234,22 @@ int dgr_build_maps(DgrArena &arena, const int32_t *coords, int64_t N, int D, int
   // capacity per output row: exact (K) in 3-D; in 6-D 3^6 = 729 offsets but measured mean
   // occupancy is 2..40 neighbours -- reserve 160 per row and raise the overflow flag beyond.
   const int cap_row = (D == 3) ? 1024 : 160;
-  for (int l = 0; l < 4; ++l) {
-    if (D == 3)
-      DGR_CHECK(build_kernel_map_t<3>(arena, ms->cm[l], ms->cm[l], 3, cap_row, &ms->same[l],
-                                      ms->overflow, stream));
-    else
-      DGR_CHECK(build_kernel_map_t<6>(arena, ms->cm[l], ms->cm[l], 3, cap_row, &ms->same[l],
-                                      ms->overflow, stream));
+  if (D == 6) {
+    // the pruned search pays while buckets are small: fine levels (ts 1,2,4); at ts = 8 the ~20 k rows
+    // share only a few hundred first halves and the generic 729-probe search is as cheap
+    for (int l = 0; l < 3; ++l) DGR_CHECK(dgr_build_half_buckets(arena, ms->cm[l], &ms->hb[l], stream));
   }
-  if (conv1_ks == 3) {
+  auto build = [&](const DgrCoordMap &in, const DgrCoordMap &out, const DgrHalfBuckets *hb, int ks,
+                   DgrKernelMap *km) -> int {
+    if (D == 3) return build_kernel_map_t<3>(arena, in, out, nullptr, ks, cap_row, km, ms->overflow, stream);
+    return build_kernel_map_t<6>(arena, in, out, hb, ks, cap_row, km, ms->overflow, stream);
+  };
+  for (int l = 0; l < 4; ++l) DGR_CHECK(build(ms->cm[l], ms->cm[l], &ms->hb[l], 3, &ms->same[l]));
+  if (conv1_ks == 3)
     ms->conv1 = ms->same[0];
-  } else if (D == 3) {
-    DGR_CHECK(build_kernel_map_t<3>(arena, ms->cm[0], ms->cm[0], conv1_ks, cap_row, &ms->conv1,
-                                    ms->overflow, stream));
-  } else {
-    DGR_CHECK(build_kernel_map_t<6>(arena, ms->cm[0], ms->cm[0], conv1_ks, cap_row, &ms->conv1,
-                                    ms->overflow, stream));
-  }
-  for (int l = 0; l < 3; ++l) {
-    if (D == 3)
-      DGR_CHECK(build_kernel_map_t<3>(arena, ms->cm[l], ms->cm[l + 1], 3, cap_row, &ms->down[l],
-                                      ms->overflow, stream));
-    else
-      DGR_CHECK(build_kernel_map_t<6>(arena, ms->cm[l], ms->cm[l + 1], 3, cap_row, &ms->down[l],
-                                      ms->overflow, stream));
-  }
+  else
+    DGR_CHECK(build(ms->cm[0], ms->cm[0], nullptr, conv1_ks, &ms->conv1));
+  for (int l = 0; l < 3; ++l) DGR_CHECK(build(ms->cm[l], ms->cm[l + 1], &ms->hb[l], 3, &ms->down[l]));
   return DGR_OK;
 }
 

@@ -59,6 +59,42 @@ __device__ __forceinline__ void block_sum(const double (&v)[NV], double *lds /* 
   __syncthreads();
 }
 
+// Per-iteration reduction of <= 16 f64 values per thread in 17 cross-lane exchanges and ONE barrier:
+// halving butterfly -- at the xor-32 step each lane hands 8 of its 16 values to its partner and adds
+// the 8 it receives, then 4, 2, 1; after four steps every lane owns one value summed over 16 lanes,
+// two more steps finish the wave.  Wave results go to a double-buffered LDS slab (`buf` alternates
+// per call, which removes the write-after-read barrier); every thread then sums the waves itself.
+template <int NV>
+__device__ __forceinline__ void block_sum_butterfly(const double (&vin)[NV], double *slab /* [2][REG_WAVES][16] */,
+                                                    int buf, double (&out)[NV]) {
+  static_assert(NV <= 16, "at most 16 values");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = i < NV ? vin[i] : 0.0;
+  const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
+  double a[8], b[4], c[2], d;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = (b5 ? v[i + 8] : v[i]) + __shfl_xor(b5 ? v[i] : v[i + 8], 32, 64);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) b[i] = (b4 ? a[i + 4] : a[i]) + __shfl_xor(b4 ? a[i] : a[i + 4], 16, 64);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) c[i] = (b3 ? b[i + 2] : b[i]) + __shfl_xor(b3 ? b[i] : b[i + 2], 8, 64);
+  d = (b2 ? c[1] : c[0]) + __shfl_xor(b2 ? c[0] : c[1], 4, 64);
+  d += __shfl_xor(d, 2, 64);
+  d += __shfl_xor(d, 1, 64);
+  double *mine = slab + (buf * REG_WAVES + wave) * 16;
+  if ((lane & 3) == 0) mine[(b5 ? 8 : 0) + (b4 ? 4 : 0) + (b3 ? 2 : 0) + (b2 ? 1 : 0)] = d;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < REG_WAVES; ++w) s += slab[(buf * REG_WAVES + w) * 16 + i];
+    out[i] = s;
+  }
+}
+
 // ---- 3x3 SVD, one-sided Jacobi in f64: A = U diag(s) V^T, s sorted descending ----------------
 __device__ void svd3(const double A[9], double U[9], double s[3], double V[9]) {
   double a[3][3], v[3][3];
@@ -192,6 +228,7 @@ __device__ __forceinline__ void ortho_backward(const Ortho &o, const float G[9],
 
 __global__ void __launch_bounds__(REG_THREADS) registration_kernel(RegArgs a) {
   __shared__ double red[REG_WAVES * 17 + 17];
+  __shared__ double slab[2 * REG_WAVES * 16];
   __shared__ int wave_cnt[REG_WAVES];
   __shared__ float init_Rt[12];
   __shared__ int status_s;
@@ -346,7 +383,7 @@ __global__ void __launch_bounds__(REG_THREADS) registration_kernel(RegArgs a) {
       g[10] += gz * A.x; g[11] += gz * A.y; g[12] += gz * A.z;
     }
     double Gs[13];
-    block_sum<13>(g, red, Gs);
+    block_sum_butterfly<13>(g, slab, it & 1, Gs);
     loss = (float)(Gs[0] / (double)w1);
     if (it == 0) loss_prev = loss;  // loss_prev = loss_fn(T(points), trans_points) before the loop
     if (loss < 1e-7f) break;
