@@ -251,6 +251,8 @@ def main():
             'status': [int(s) for s in status_all.tolist()],
             'iterations': [int(v) for v in stats_all[:, 0].tolist()],
             'voxelize_ms_per_pair': t_vox * 1e3,
+            'layers_6d': [[x['pairs'], x['nonempty'], x['n_in'], x['n_out'], x['cin'], x['cout']] for x in s_c],
+            'layers_3d_cloud0': [[x['pairs'], x['nonempty'], x['n_in'], x['n_out'], x['cin'], x['cout']] for x in s_a],
         }
         log('roofline accounting done')
         if not args.no_cpu_baseline:

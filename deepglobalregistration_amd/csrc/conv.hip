@@ -1,14 +1,20 @@
-// Sparse convolution forward for gfx950: rule-major gather -> LDS tile -> f32 MFMA -> scatter.
+// Sparse convolution forward for gfx950: rule-major gather -> LDS tile -> f32 MFMA -> per-pair rows,
+// then a deterministic segmented reduction per output row.
 // Replaces the ME.MinkowskiConvolution / MinkowskiConvolutionTranspose forward invoked by every
 // conv of ResUNetBN2C (model/resunet.py:598-649, model/residual_block.py:15-80).
 //
-// Work decomposition: the kernel map lists pairs (in, out) per kernel offset k ("rule").  A tile
-// is <= 64 pairs of ONE rule: the 64 gathered input rows [64 x Cin] are staged in LDS once,
+// Phase 1 (sparse_conv_mfma): the kernel map lists pairs (in, out) per kernel offset k ("rule").  A
+// tile is <= 64 pairs of ONE rule: the 64 gathered input rows [64 x Cin] are staged in LDS once and
 // multiplied with the rule's dense [Cin x Cout] slice on the matrix cores
-// (v_mfma_f32_32x32x2_f32: exact f32, bitwise an fma chain) and scatter-accumulated into the output
-// rows (global_atomic_add_f32; 32 consecutive lanes hit 32 consecutive floats of one output row).
-// The grid is persistent and XCD-aware: each of the 8 XCDs walks a contiguous range of tiles, i.e.
-// a contiguous range of rules, so a rule's weight slice is pulled into ONE L2.
+// (v_mfma_f32_32x32x2_f32: exact f32, bitwise an fma chain); the product rows go to Y[pair, Cout]
+// with plain coalesced stores (32 consecutive lanes write 128 consecutive bytes).  The grid is
+// persistent and XCD-aware: each of the 8 XCDs walks a contiguous range of tiles, i.e. a contiguous
+// range of rules, so a rule's weight slice is pulled into ONE L2.
+// Phase 2 (reduce_rows): every output row sums its Y rows in ascending-k order (output-major CSR
+// from kmap.hip), starting from the folded batch-norm shift (+ residual), and is written once.
+// Measured alternative that this replaces: scatter with global_atomic_add_f32 is capped at ~333 G
+// lanes/s chip-wide (tools/microbench/atomic_xcd.hip, independent of XCD locality) and serialises
+// with the MFMA phase; plain stores + one streaming pass are faster AND bit-reproducible.
 //
 // Weight layout (prepared once in net.hip): W[k][s][nb][lane][c], s = Cin_pad/8 K-steps,
 // nb = Cout_pad/32 column blocks, value = W_folded[k][8 s + 4 (lane>>5) + c][32 nb + (lane&31)],
@@ -22,10 +28,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvKArgs {
   const float *in;
-  float *out;
+  float *out;          // identity maps: written directly (acc + shift); otherwise unused
+  float *y;            // [pairs, y_ld] per-pair product rows
+  const float *shift;  // identity maps: folded bias / BN shift (may be null)
   const float *w;
   const int32_t *pair_in, *pair_out, *tile_ptr, *rule_ptr, *n_rows_dev;
-  int in_ld, out_ld, in_relu;
+  int in_ld, out_ld, in_relu, y_ld;
   int cin, cin_pad, cout, K;
 };
 
@@ -147,19 +155,27 @@ __global__ void __launch_bounds__(64 * WM * WN) sparse_conv_mfma(ConvKArgs a) {
 #pragma unroll
       for (int j = 0; j < NB; ++j) bcur[j] = bnext[j];
     }
-    // ---- scatter-accumulate: C layout col = lane & 31, row = (e&3) + 8 (e>>2) + 4 (lane>>5)
+    // ---- write the product rows: C layout col = lane & 31, row = (e&3) + 8 (e>>2) + 4 (lane>>5)
 #pragma unroll
     for (int i = 0; i < MB; ++i) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int r = 32 * (wm * MB + i) + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        const int orow = idx_out[r];
-        if (orow >= 0) {
-          float *dst = a.out + (int64_t)orow * a.out_ld;
+        if (r < count) {
+          if (identity) {
+            float *dst = a.out + (int64_t)(pstart + r) * a.out_ld;
 #pragma unroll
-          for (int j = 0; j < NB; ++j) {
-            const int col = 32 * (wn * NB + j) + (lane & 31);
-            if (col < a.cout) unsafeAtomicAdd(dst + col, acc[i][j][e]);
+            for (int j = 0; j < NB; ++j) {
+              const int col = 32 * (wn * NB + j) + (lane & 31);
+              if (col < a.cout) dst[col] = acc[i][j][e] + (a.shift ? a.shift[col] : 0.f);
+            }
+          } else {
+            float *dst = a.y + (int64_t)(pstart + r) * a.y_ld;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+              const int col = 32 * (wn * NB + j) + (lane & 31);
+              if (col < a.cout) dst[col] = acc[i][j][e];
+            }
           }
         }
       }
@@ -204,7 +220,7 @@ static int launch_cfg(const ConvKArgs &ka, int64_t tile_bound, int num_cus, hipS
 
 int dgr_conv_launch(const DgrConvLaunch &a, int num_cus, hipStream_t stream) {
   ConvKArgs ka;
-  ka.in = a.in; ka.out = a.out; ka.w = a.w;
+  ka.in = a.in; ka.out = a.out; ka.w = a.w; ka.y = a.y; ka.shift = a.shift; ka.y_ld = a.cout;
   ka.pair_in = a.pair_in; ka.pair_out = a.pair_out; ka.tile_ptr = a.tile_ptr; ka.rule_ptr = a.rule_ptr;
   ka.n_rows_dev = a.n_rows_dev;
   ka.in_ld = a.in_ld; ka.out_ld = a.out_ld; ka.in_relu = a.in_relu;
@@ -223,33 +239,61 @@ int dgr_conv_launch(const DgrConvLaunch &a, int num_cus, hipStream_t stream) {
 }
 
 // ------------------------------------------------------------------------------------------
-// elementwise companions: output initialisation (folded-BN shift + residual) and L2 normalise
+// phase 2: out[o, :] = shift (+ residual[o, :]) + sum over the row's pairs (ascending k) of Y[pos, :]
+// LPR lanes cooperate on one output row (one float4 column group each); rows are independent.
 // ------------------------------------------------------------------------------------------
-__global__ void init_rows_kernel(float *__restrict__ out, int out_ld, int cout,
-                                 const float *__restrict__ shift, const float *__restrict__ res,
-                                 int res_ld, int res_relu, const int32_t *n_dev) {
-  const int64_t n = *n_dev;
-  const int64_t total = n * cout;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = i / cout;
-    const int c = (int)(i - r * cout);
-    float v = shift ? shift[c] : 0.f;
+template <int LPR>
+__global__ void __launch_bounds__(256)
+    reduce_rows_kernel(const float *__restrict__ y, int y_ld, const int32_t *__restrict__ ptr,
+                       const int32_t *__restrict__ pos, const int32_t *n_dev, float *__restrict__ out, int out_ld,
+                       const float *__restrict__ shift, const float *__restrict__ res, int res_ld, int res_relu) {
+  constexpr int ROWS = 256 / LPR;
+  const int n = *n_dev;
+  const int sub = threadIdx.x / LPR, c = (threadIdx.x % LPR) * 4;
+  for (int64_t row = (int64_t)blockIdx.x * ROWS + sub; row < n; row += (int64_t)gridDim.x * ROWS) {
+    f32x4 acc = shift ? *reinterpret_cast<const f32x4 *>(shift + c) : f32x4{0.f, 0.f, 0.f, 0.f};
     if (res) {
-      float x = res[r * res_ld + c];
-      if (res_relu) x = fmaxf(x, 0.f);
-      v += x;
+      f32x4 r = *reinterpret_cast<const f32x4 *>(res + row * res_ld + c);
+      if (res_relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+      acc += r;
     }
-    out[r * out_ld + c] = v;
+    int j = ptr[row];
+    const int end = ptr[row + 1];
+    // four independent loads in flight; the additions stay in ascending-k order
+    for (; j + 4 <= end; j += 4) {
+      const int p0 = pos[j], p1 = pos[j + 1], p2 = pos[j + 2], p3 = pos[j + 3];
+      const f32x4 v0 = *reinterpret_cast<const f32x4 *>(y + (int64_t)p0 * y_ld + c);
+      const f32x4 v1 = *reinterpret_cast<const f32x4 *>(y + (int64_t)p1 * y_ld + c);
+      const f32x4 v2 = *reinterpret_cast<const f32x4 *>(y + (int64_t)p2 * y_ld + c);
+      const f32x4 v3 = *reinterpret_cast<const f32x4 *>(y + (int64_t)p3 * y_ld + c);
+      acc += v0; acc += v1; acc += v2; acc += v3;
+    }
+    for (; j < end; ++j) acc += *reinterpret_cast<const f32x4 *>(y + (int64_t)pos[j] * y_ld + c);
+    *reinterpret_cast<f32x4 *>(out + row * out_ld + c) = acc;
   }
 }
 
-int dgr_init_rows(float *out, int out_ld, int cout, const float *shift, const float *res, int res_ld,
-                  int res_relu, const int32_t *n_dev, int64_t n_cap, hipStream_t stream) {
-  int64_t blocks = dgr_ceil_div(n_cap * cout, 256);
-  if (blocks > 2048) blocks = 2048;
+int dgr_reduce_rows(const float *y, int cout, const int32_t *ptr, const int32_t *pos, const int32_t *n_dev,
+                    int64_t n_cap, float *out, int out_ld, const float *shift, const float *res, int res_ld,
+                    int res_relu, hipStream_t stream) {
+  DGR_REQUIRE((out_ld & 3) == 0 && (res == nullptr || (res_ld & 3) == 0), "reduce_rows: row strides must be x4");
+  const int lpr = cout / 4;
+  int64_t blocks = dgr_ceil_div(n_cap, 256 / lpr);
+  if (blocks > 8192) blocks = 8192;
   if (blocks < 1) blocks = 1;
-  init_rows_kernel<<<(int)blocks, 256, 0, stream>>>(out, out_ld, cout, shift, res, res_ld, res_relu, n_dev);
+#define DGR_RR(L)                                                                                              \
+  reduce_rows_kernel<L><<<(int)blocks, 256, 0, stream>>>(y, cout, ptr, pos, n_dev, out, out_ld, shift, res, res_ld, \
+                                                         res_relu)
+  switch (cout) {
+    case 32: DGR_RR(8); break;
+    case 64: DGR_RR(16); break;
+    case 128: DGR_RR(32); break;
+    case 256: DGR_RR(64); break;
+    default:
+      dgr_set_error("reduce_rows: unsupported width %d", cout);
+      return DGR_EINVAL;
+  }
+#undef DGR_RR
   DGR_LAUNCH_CHECK();
   return DGR_OK;
 }

@@ -106,6 +106,11 @@ struct DgrKernelMap {
   int32_t *tile_ptr = nullptr;  // [K+1] exclusive prefix of DGR_TILE_M-tiles per offset
   int32_t *pair_in = nullptr;   // [pair_cap]
   int32_t *pair_out = nullptr;  // [pair_cap]
+  // output-major CSR over the same pairs (entries of a row in ascending k): the deterministic
+  // segmented reduction of the sparse conv walks it.  out_* is keyed by pair_out; in_* (strided
+  // maps only) by pair_in, for the transposed convs that use the map with in/out swapped.
+  int32_t *out_ptr = nullptr, *out_pos = nullptr;
+  int32_t *in_ptr = nullptr, *in_pos = nullptr;
   int64_t pair_cap = 0;
   bool built = false;
 };
@@ -137,8 +142,10 @@ struct DgrConvLaunch {
   const float *in;  // [n_in, in_ld]
   int in_ld;
   int in_relu;  // apply max(x,0) when gathering
-  float *out;   // [n_out, out_ld], pre-initialised; accumulated with atomics
+  float *out;   // identity maps only: [n_out, out_ld] written directly (product + shift)
   int out_ld;
+  float *y;            // non-identity maps: per-pair product rows [pairs, cout]
+  const float *shift;  // identity maps: per-channel shift (may be null)
   const float *w;  // MFMA-B-fragment tiled weights of this layer
   int cin, cin_pad, cout, cout_pad, K;
   const int32_t *pair_in, *pair_out, *tile_ptr, *rule_ptr;  // nullptr pairs => identity map
@@ -146,9 +153,10 @@ struct DgrConvLaunch {
   int64_t tile_bound;                                        // host upper bound on the tile count (0 = unknown)
 };
 int dgr_conv_launch(const DgrConvLaunch &a, int num_cus, hipStream_t stream);
-// out[r, c] = shift[c] (+ res[r, c]) for r < *n_dev, c < cout
-int dgr_init_rows(float *out, int out_ld, int cout, const float *shift, const float *res, int res_ld,
-                  int res_relu, const int32_t *n_dev, int64_t n_cap, hipStream_t stream);
+// out[o,:] = shift (+res[o,:]) + sum_{j in [ptr[o], ptr[o+1])} y[pos[j],:]   (ascending-k order)
+int dgr_reduce_rows(const float *y, int cout, const int32_t *ptr, const int32_t *pos, const int32_t *n_dev,
+                    int64_t n_cap, float *out, int out_ld, const float *shift, const float *res, int res_ld,
+                    int res_relu, hipStream_t stream);
 int dgr_l2_normalize_rows(const float *in, int in_ld, float *out, int out_ld, int c, int relu,
                           const int32_t *n_dev, int64_t n_cap, hipStream_t stream);
 

@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(KM_THREADS)
     kmap_search(const int32_t *__restrict__ out_coords, const int32_t *n_out_dev,
                 const int32_t *__restrict__ in_coords, const int32_t *__restrict__ in_table,
                 uint32_t in_mask, int ks, int ts_in, int RB, int64_t n_cap, int32_t *__restrict__ hits,
-                int32_t *__restrict__ block_counts) {
+                int32_t *__restrict__ block_counts, int KW, uint32_t *mask_out, uint32_t *mask_in) {
   __shared__ int wave_cnt[KM_THREADS / 64];
   const int rb = blockIdx.x, k = blockIdx.y;
   const int n_out = *n_out_dev;
@@ -59,6 +59,10 @@ __global__ void __launch_bounds__(KM_THREADS)
   if (o < n_out) {
     hit = probe<D>(out_coords, o, delta, in_coords, in_table, in_mask);
     hits[(int64_t)k * n_cap + o] = hit;
+    if (hit >= 0) {
+      atomicOr(&mask_out[o * KW + (k >> 5)], 1u << (k & 31));
+      if (mask_in) atomicOr(&mask_in[(int64_t)hit * KW + (k >> 5)], 1u << (k & 31));
+    }
   }
   unsigned long long m = __ballot(hit >= 0);
   if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = __popcll(m);
@@ -78,7 +82,8 @@ __global__ void __launch_bounds__(KM_THREADS)
 __global__ void __launch_bounds__(KM_THREADS)
     kmap_search_pruned6(const int32_t *__restrict__ out_coords, const int32_t *n_out_dev,
                         const int32_t *__restrict__ in_coords, DgrHalfBuckets hb, int ts_in, int RB,
-                        int64_t n_cap, int32_t *__restrict__ hits, int32_t *block_counts) {
+                        int64_t n_cap, int32_t *__restrict__ hits, int32_t *block_counts, int KW,
+                        uint32_t *mask_out, uint32_t *mask_in) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t o = t / 27;
   const int ja = (int)(t - o * 27);
@@ -102,8 +107,27 @@ __global__ void __launch_bounds__(KM_THREADS)
       const int k = ja + 27 * ((d4 / ts_in + 1) + 3 * (d5 / ts_in + 1) + 9 * (d6 / ts_in + 1));
       hits[(int64_t)k * n_cap + o] = r;
       atomicAdd(&block_counts[(int64_t)k * RB + (int)(o / KM_THREADS)], 1);
+      atomicOr(&mask_out[o * KW + (k >> 5)], 1u << (k & 31));
+      if (mask_in) atomicOr(&mask_in[(int64_t)r * KW + (k >> 5)], 1u << (k & 31));
     }
   }
+}
+
+__device__ __forceinline__ int mask_rank(const uint32_t *__restrict__ m, int k) {
+  int r = 0;
+  const int w = k >> 5;
+  for (int i = 0; i < w; ++i) r += __popc(m[i]);
+  return r + __popc(m[w] & ((1u << (k & 31)) - 1u));
+}
+
+__global__ void mask_count_kernel(const uint32_t *__restrict__ mask, int KW, const int32_t *n_dev, int64_t n_cap,
+                                  int32_t *__restrict__ cnt) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_cap) return;
+  int c = 0;
+  if (r < *n_dev)
+    for (int i = 0; i < KW; ++i) c += __popc(mask[r * KW + i]);
+  cnt[r] = c;
 }
 
 // ---- pass 2: grid = (row blocks, K): rank the cached hits inside the block (row order) and write
@@ -112,7 +136,10 @@ __global__ void __launch_bounds__(KM_THREADS)
     kmap_fill(const int32_t *n_out_dev, int RB, int64_t n_cap, const int32_t *__restrict__ hits,
               const int32_t *__restrict__ block_counts, const int32_t *__restrict__ block_base,
               int32_t *__restrict__ pair_in, int32_t *__restrict__ pair_out, int64_t pair_cap,
-              int32_t *overflow) {
+              int32_t *overflow, int KW, const uint32_t *__restrict__ mask_out,
+              const int32_t *__restrict__ out_ptr, int32_t *__restrict__ out_pos,
+              const uint32_t *__restrict__ mask_in, const int32_t *__restrict__ in_ptr,
+              int32_t *__restrict__ in_pos) {
   __shared__ int wave_cnt[KM_THREADS / 64];
   const int rb = blockIdx.x, k = blockIdx.y;
   if (block_counts[(int64_t)k * RB + rb] == 0) return;   // most (offset, block) cells are empty in 6-D
@@ -131,6 +158,9 @@ __global__ void __launch_bounds__(KM_THREADS)
     if (pos < pair_cap) {
       pair_in[pos] = hit;
       pair_out[pos] = (int32_t)o;
+      // CSR slot = row start + number of this row's offsets below k (ascending-k order per row)
+      out_pos[out_ptr[o] + mask_rank(mask_out + o * KW, k)] = (int32_t)pos;
+      if (mask_in) in_pos[in_ptr[hit] + mask_rank(mask_in + (int64_t)hit * KW, k)] = (int32_t)pos;
     } else {
       *overflow = 2;
     }
@@ -167,7 +197,7 @@ __global__ void __launch_bounds__(1024)
 template <int D>
 static int build_kernel_map_t(DgrArena &arena, const DgrCoordMap &in, const DgrCoordMap &out,
                               const DgrHalfBuckets *in_buckets, int ks, int max_pairs_per_row,
-                              DgrKernelMap *km, int32_t *overflow, hipStream_t stream) {
+                              bool need_in_csr, DgrKernelMap *km, int32_t *overflow, hipStream_t stream) {
   int K = 1;
   for (int d = 0; d < D; ++d) K *= ks;
   DGR_REQUIRE(K <= 1024, "kernel volume %d > 1024 not supported", K);
@@ -181,6 +211,14 @@ static int build_kernel_map_t(DgrArena &arena, const DgrCoordMap &in, const DgrC
   DGR_ALLOC(km->tile_ptr, arena, int32_t, K + 1);
   DGR_ALLOC(km->pair_in, arena, int32_t, km->pair_cap);
   DGR_ALLOC(km->pair_out, arena, int32_t, km->pair_cap);
+  DGR_ALLOC(km->out_ptr, arena, int32_t, n_cap + 1);
+  DGR_ALLOC(km->out_pos, arena, int32_t, km->pair_cap);
+  const int64_t n_in_cap = in.n_cap;
+  if (need_in_csr) {
+    DGR_ALLOC(km->in_ptr, arena, int32_t, n_in_cap + 1);
+    DGR_ALLOC(km->in_pos, arena, int32_t, km->pair_cap);
+  }
+  const int KW = (K + 31) / 32;
   // transient: dense hit cache [K, n_cap] + per-(offset, block) counts; released after pass 2
   DgrArena::Mark mk = arena.mark();
   int32_t *counts, *base, *total, *hits;
@@ -188,6 +226,16 @@ static int build_kernel_map_t(DgrArena &arena, const DgrCoordMap &in, const DgrC
   DGR_ALLOC(base, arena, int32_t, (int64_t)K * RB);
   DGR_ALLOC(total, arena, int32_t, 1);
   DGR_ALLOC(hits, arena, int32_t, (int64_t)K * n_cap);
+  uint32_t *mask_out, *mask_in = nullptr;
+  int32_t *cnt_out, *cnt_in = nullptr;
+  DGR_ALLOC(mask_out, arena, uint32_t, (n_cap + 1) * KW);
+  DGR_ALLOC(cnt_out, arena, int32_t, n_cap + 1);
+  DGR_HIP_CHECK(hipMemsetAsync(mask_out, 0, (size_t)(n_cap + 1) * KW * sizeof(uint32_t), stream));
+  if (need_in_csr) {
+    DGR_ALLOC(mask_in, arena, uint32_t, (n_in_cap + 1) * KW);
+    DGR_ALLOC(cnt_in, arena, int32_t, n_in_cap + 1);
+    DGR_HIP_CHECK(hipMemsetAsync(mask_in, 0, (size_t)(n_in_cap + 1) * KW * sizeof(uint32_t), stream));
+  }
   dim3 grid(RB, K);
   bool pruned = false;
   if constexpr (D == 6) {
@@ -197,17 +245,27 @@ static int build_kernel_map_t(DgrArena &arena, const DgrCoordMap &in, const DgrC
       DGR_HIP_CHECK(hipMemsetAsync(counts, 0, (size_t)K * RB * sizeof(int32_t), stream));
       const int64_t threads = n_cap * 27;
       kmap_search_pruned6<<<(int)dgr_ceil_div(threads, KM_THREADS), KM_THREADS, 0, stream>>>(
-          out.coords, out.n_dev, in.coords, *in_buckets, in.ts, RB, n_cap, hits, counts);
+          out.coords, out.n_dev, in.coords, *in_buckets, in.ts, RB, n_cap, hits, counts, KW, mask_out, mask_in);
     }
   }
   if (!pruned)
     kmap_search<D><<<grid, KM_THREADS, 0, stream>>>(out.coords, out.n_dev, in.coords, in.table,
-                                                    in.table_mask, ks, in.ts, RB, n_cap, hits, counts);
+                                                    in.table_mask, ks, in.ts, RB, n_cap, hits, counts, KW,
+                                                    mask_out, mask_in);
   DGR_LAUNCH_CHECK();
+  // per-row pair counts -> CSR row pointers (out rows; in rows for maps used swapped)
+  mask_count_kernel<<<(int)dgr_ceil_div(n_cap + 1, 256), 256, 0, stream>>>(mask_out, KW, out.n_dev, n_cap + 1, cnt_out);
+  DGR_CHECK(dgr_exclusive_scan_i32(arena, cnt_out, km->out_ptr, n_cap + 1, nullptr, stream));
+  if (need_in_csr) {
+    mask_count_kernel<<<(int)dgr_ceil_div(n_in_cap + 1, 256), 256, 0, stream>>>(mask_in, KW, in.n_dev, n_in_cap + 1,
+                                                                                cnt_in);
+    DGR_CHECK(dgr_exclusive_scan_i32(arena, cnt_in, km->in_ptr, n_in_cap + 1, nullptr, stream));
+  }
   DGR_CHECK(dgr_exclusive_scan_i32(arena, counts, base, (int64_t)K * RB, total, stream));
   kmap_finalize<<<1, 1024, 0, stream>>>(base, total, K, RB, km->rule_ptr, km->tile_ptr);
   kmap_fill<<<grid, KM_THREADS, 0, stream>>>(out.n_dev, RB, n_cap, hits, counts, base, km->pair_in,
-                                             km->pair_out, km->pair_cap, overflow);
+                                             km->pair_out, km->pair_cap, overflow, KW, mask_out, km->out_ptr,
+                                             km->out_pos, mask_in, km->in_ptr, km->in_pos);
   DGR_LAUNCH_CHECK();
   arena.rewind(mk);
   km->built = true;
@@ -239,17 +297,18 @@ int dgr_build_maps(DgrArena &arena, const int32_t *coords, int64_t N, int D, int
     // share only a few hundred first halves and the generic 729-probe search is as cheap
     for (int l = 0; l < 3; ++l) DGR_CHECK(dgr_build_half_buckets(arena, ms->cm[l], &ms->hb[l], stream));
   }
-  auto build = [&](const DgrCoordMap &in, const DgrCoordMap &out, const DgrHalfBuckets *hb, int ks,
+  auto build = [&](const DgrCoordMap &in, const DgrCoordMap &out, const DgrHalfBuckets *hb, int ks, bool rev,
                    DgrKernelMap *km) -> int {
-    if (D == 3) return build_kernel_map_t<3>(arena, in, out, nullptr, ks, cap_row, km, ms->overflow, stream);
-    return build_kernel_map_t<6>(arena, in, out, hb, ks, cap_row, km, ms->overflow, stream);
+    if (D == 3) return build_kernel_map_t<3>(arena, in, out, nullptr, ks, cap_row, rev, km, ms->overflow, stream);
+    return build_kernel_map_t<6>(arena, in, out, hb, ks, cap_row, rev, km, ms->overflow, stream);
   };
-  for (int l = 0; l < 4; ++l) DGR_CHECK(build(ms->cm[l], ms->cm[l], &ms->hb[l], 3, &ms->same[l]));
+  for (int l = 0; l < 4; ++l) DGR_CHECK(build(ms->cm[l], ms->cm[l], &ms->hb[l], 3, false, &ms->same[l]));
   if (conv1_ks == 3)
     ms->conv1 = ms->same[0];
   else
-    DGR_CHECK(build(ms->cm[0], ms->cm[0], nullptr, conv1_ks, &ms->conv1));
-  for (int l = 0; l < 3; ++l) DGR_CHECK(build(ms->cm[l], ms->cm[l + 1], &ms->hb[l], 3, &ms->down[l]));
+    DGR_CHECK(build(ms->cm[0], ms->cm[0], nullptr, conv1_ks, false, &ms->conv1));
+  // strided maps are also used swapped by the transposed convs: build the in-major CSR too
+  for (int l = 0; l < 3; ++l) DGR_CHECK(build(ms->cm[l], ms->cm[l + 1], &ms->hb[l], 3, true, &ms->down[l]));
   return DGR_OK;
 }
 

@@ -12,6 +12,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <string>
 
@@ -190,16 +191,17 @@ struct Fwd {
   DgrMapSet ms;
   bool prof;
 
-  // one conv: out = shift (+res) ; out += sum_k in[.] W[k]
+  float *ybuf = nullptr;  // per-pair product rows, sized for the largest layer of this forward
+
+  // one conv: Y[pair] = in[pair_in] W[k] (MFMA), then out[o] = shift (+res) + sum of the row's Y rows
   int conv(int li, const Tensor &in, const DgrKernelMap *km, bool swapped, int lvl_in, int lvl_out,
            const Tensor &out, const Tensor *res) {
     const DgrLayer &L = net->layers[li];
     const DgrCoordMap &cin_map = ms.cm[lvl_in], &cout_map = ms.cm[lvl_out];
-    DGR_CHECK(dgr_init_rows(out.ptr, out.ld, L.cout, L.shift, res ? res->ptr : nullptr, res ? res->ld : 0,
-                            res ? res->relu : 0, cout_map.n_dev, cout_map.n_cap, stream));
     DgrConvLaunch a;
     a.in = in.ptr; a.in_ld = in.ld; a.in_relu = in.relu;
     a.out = out.ptr; a.out_ld = out.ld;
+    a.y = ybuf; a.shift = L.shift;
     a.w = L.w;
     a.cin = L.cin; a.cin_pad = L.cin_pad; a.cout = L.cout; a.cout_pad = L.cout_pad; a.K = L.K;
     if (km) {
@@ -209,7 +211,9 @@ struct Fwd {
       a.n_rows_dev = nullptr;
       a.tile_bound = km->pair_cap / DGR_TILE_M + km->K;
       DGR_REQUIRE(km->K == L.K, "layer %s: kernel volume mismatch", L.name.c_str());
+      DGR_REQUIRE(!swapped || km->in_ptr, "layer %s: map has no in-major CSR", L.name.c_str());
     } else {
+      DGR_REQUIRE(res == nullptr, "identity conv with residual not supported");
       a.pair_in = a.pair_out = a.tile_ptr = a.rule_ptr = nullptr;
       a.n_rows_dev = cout_map.n_dev;
       a.tile_bound = dgr_ceil_div(cout_map.n_cap, DGR_TILE_M);
@@ -221,6 +225,10 @@ struct Fwd {
       DGR_HIP_CHECK(hipEventRecord(e0, stream));
     }
     DGR_CHECK(dgr_conv_launch(a, ctx->num_cus, stream));
+    if (km)
+      DGR_CHECK(dgr_reduce_rows(ybuf, L.cout, swapped ? km->in_ptr : km->out_ptr, swapped ? km->in_pos : km->out_pos,
+                                cout_map.n_dev, cout_map.n_cap, out.ptr, out.ld, L.shift, res ? res->ptr : nullptr,
+                                res ? res->ld : 0, res ? res->relu : 0, stream));
     if (prof) {
       DGR_HIP_CHECK(hipEventRecord(e1, stream));
       ctx->conv_spans.push_back({e0, e1});
@@ -247,6 +255,15 @@ int dgr_resunet_forward_impl(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, 
   if (f.prof) {
     DGR_HIP_CHECK(hipEventRecord(m1, stream));
     (net->D == 3 ? ctx->map3_spans : ctx->map6_spans).push_back({m0, m1});
+  }
+  {
+    // Y capacity: the largest (pair capacity x Cout) over the layers of this net
+    const DgrMapSet &m = f.ms;
+    int64_t need = m.conv1.pair_cap * 32;
+    const int64_t same_c[4] = {64, 64, 128, 256}, down_c[3] = {64, 128, 256};  // widest Cout per map
+    for (int l = 0; l < 4; ++l) need = std::max(need, m.same[l].pair_cap * same_c[l]);
+    for (int l = 0; l < 3; ++l) need = std::max(need, m.down[l].pair_cap * down_c[l]);
+    DGR_ALLOC(f.ybuf, A, float, need);
   }
   const DgrMapSet &ms = f.ms;
   const int64_t n1 = ms.cm[0].n_cap, n2 = ms.cm[1].n_cap, n4 = ms.cm[2].n_cap, n8 = ms.cm[3].n_cap;

@@ -61,9 +61,10 @@ def smooth_l1_highdim(P, Q, w, wsum, q, eps=F32_EPS):
 
 
 def global_registration(X, Y, w, max_iter=1000, max_break_count=20,
-                        break_threshold_ratio=1e-5, quantization_size=1.0):
+                        break_threshold_ratio=1e-5, quantization_size=1.0, trace=None):
     """Returns R [3,3], t [1,3] (float32 numpy) and the stats dict
-    {'iterations','loss','break_count'} of the reference."""
+    {'iterations','loss','break_count'} of the reference.  `trace` (a list) receives (R, t) after
+    every optimiser step (test instrumentation; not part of the reference)."""
     X, Y, w = (torch.as_tensor(np.asarray(a), dtype=torch.float32) for a in (X, Y, w))
     w = w.reshape(-1, 1)
     wsum = w.sum()
@@ -88,6 +89,9 @@ def global_registration(X, Y, w, max_iter=1000, max_break_count=20,
         loss.backward()
         opt.step()
         sched.step()
+        if trace is not None:
+            with torch.no_grad():
+                trace.append((rot6d_to_matrix(rot6d)[0].numpy().copy(), trans.detach().numpy().reshape(3).copy()))
         if abs(loss_prev - loss.item()) < loss_prev * break_threshold_ratio:
             breaks += 1
             if breaks >= max_break_count:
