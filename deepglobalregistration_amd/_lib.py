@@ -11,7 +11,7 @@ import os
 import torch  # noqa: F401  (must be loaded before libdgr_hip.so, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libdgr_hip.so')
+LIB_PATH = os.environ.get('DGR_HIP_LIB') or os.path.join(_HERE, 'lib', 'libdgr_hip.so')  # override: experiments only
 
 DGR_OK, DGR_EINVAL, DGR_EHIP, DGR_ENOMEM, DGR_ESVD, DGR_EINTERNAL = 0, -1, -2, -3, -4, -5
 STATUS_OK, STATUS_LOW_CONFIDENCE, STATUS_SVD_FAILED = 0, 1, 2

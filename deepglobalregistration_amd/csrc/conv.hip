@@ -19,6 +19,8 @@
 // Weight layout (prepared once in net.hip): W[k][s][nb][lane][c], s = Cin_pad/8 K-steps,
 // nb = Cout_pad/32 column blocks, value = W_folded[k][8 s + 4 (lane>>5) + c][32 nb + (lane&31)],
 // so a wave fetches the B operands of 4 MFMAs with one coalesced 16-byte load per lane.
+#include <stdlib.h>
+
 #include <map>
 
 #include "dgr_internal.h"
@@ -218,6 +220,226 @@ static int launch_cfg(const ConvKArgs &ka, int64_t tile_bound, int num_cus, hipS
   return DGR_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// v2: compile-time Cin, software-pipelined across tiles.  While the matrix cores work on tile t out
+// of LDS, the 64 input rows of the block's NEXT tile are already in flight into registers (issued
+// right after the first two B-operand loads so that those stay ahead of them in the in-order vmcnt
+// queue) and the row indices of the tile after that are being fetched; after the MFMA loop the
+// registers are dropped into LDS between two barriers.  B operands are prefetched three K-steps deep.
+// ------------------------------------------------------------------------------------------
+template <int CP, int WM, int WN, int MB, int NB, bool VEC>
+__global__ void __launch_bounds__(64 * WM * WN) sparse_conv_mfma_v2(ConvKArgs a) {
+  constexpr int THREADS = 64 * WM * WN;
+  constexpr int TM = 32 * MB * WM;
+  static_assert(TM == DGR_TILE_M, "tile height must match the kernel-map tiling");
+  constexpr int NBLK = NB * WN;
+  constexpr int C4N = CP / 4;                 // 16-byte pieces per row
+  constexpr int NCH = TM * C4N / THREADS;     // pieces per thread per tile
+  static_assert(TM * C4N % THREADS == 0, "gather pieces must divide evenly");
+  constexpr int LDA = CP + 4;
+  constexpr int S = CP / 8;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *As = lds;
+  int *idxbuf = reinterpret_cast<int *>(lds + TM * LDA);  // [2][TM] input-row index of the tile rows
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const bool identity = (a.pair_in == nullptr);
+  const int n_rows = identity ? *a.n_rows_dev : 0;
+  const int T = identity ? (n_rows + TM - 1) / TM : a.tile_ptr[a.K];
+  const int per = (T + 7) >> 3;
+  const int xcd = blockIdx.x & 7;
+  const int t_end = min(T, (xcd + 1) * per);
+  const int nj = gridDim.x >> 3;
+  int t = xcd * per + (blockIdx.x >> 3);
+  if (t >= t_end) return;
+
+  auto locate = [&](int tt, int &k, int &pstart, int &count) {
+    if (identity) {
+      k = 0;
+      pstart = tt * TM;
+      count = min(TM, n_rows - pstart);
+    } else {
+      int lo = 0, hi = a.K;
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (a.tile_ptr[mid] <= tt) lo = mid; else hi = mid;
+      }
+      k = lo;
+      pstart = a.rule_ptr[k] + (tt - a.tile_ptr[k]) * TM;
+      count = min(TM, a.rule_ptr[k + 1] - pstart);
+    }
+  };
+  auto load_idx = [&](int pstart, int count) -> int {
+    if (tid < TM && tid < count) return identity ? pstart + tid : a.pair_in[pstart + tid];
+    return -1;
+  };
+  f32x4 G[NCH];
+  auto gather = [&](const int *idx) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int ch = tid + i * THREADS;
+      const int r = ch / C4N, c4 = ch % C4N;
+      const int row = idx[r];
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#ifdef DGR_ABL_NOGATHER
+      if (row >= 0 && a.cin < 0) {
+#else
+      if (row >= 0) {
+#endif
+        const float *src = a.in + (int64_t)row * a.in_ld + c4 * 4;
+        if (VEC) {
+          if (c4 * 4 < a.cin) v = *reinterpret_cast<const f32x4 *>(src);
+        } else {
+          if (c4 * 4 + 0 < a.cin) v.x = src[0];
+          if (c4 * 4 + 1 < a.cin) v.y = src[1];
+          if (c4 * 4 + 2 < a.cin) v.z = src[2];
+          if (c4 * 4 + 3 < a.cin) v.w = src[3];
+        }
+        if (a.in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      }
+      G[i] = v;
+    }
+  };
+
+  // ---- prologue: indices of tile t into LDS, indices of the next tile into a register, gather tile t
+  int k, pstart, count;
+  locate(t, k, pstart, count);
+  {
+    const int mine = load_idx(pstart, count);
+    if (tid < TM) idxbuf[tid] = mine;
+  }
+  int tn = t + nj;
+  bool has_next = tn < t_end;
+  int kn = 0, pn = 0, cn = 0, idx_next = -1;
+  if (has_next) {
+    locate(tn, kn, pn, cn);
+    idx_next = load_idx(pn, cn);
+  }
+  __syncthreads();
+  gather(idxbuf);
+  int buf = 0;
+
+  while (true) {
+    // registers -> LDS (tile t); publish the next tile's indices in the other index buffer
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int ch = tid + i * THREADS;
+      *reinterpret_cast<f32x4 *>(As + (ch / C4N) * LDA + (ch % C4N) * 4) = G[i];
+    }
+    if (tid < TM) idxbuf[(buf ^ 1) * TM + tid] = idx_next;
+    __syncthreads();
+
+    // first B operands of this tile, THEN the next tile's gather (keeps them ahead in the vmcnt queue)
+    const f32x4 *wk = reinterpret_cast<const f32x4 *>(a.w) + ((int64_t)k * S * NBLK + wn * NB) * 64 + lane;
+    f32x4 b[3][NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) b[0][j] = wk[j * 64];
+    if (S > 1) {
+#pragma unroll
+      for (int j = 0; j < NB; ++j) b[1][j] = wk[((int64_t)NBLK + j) * 64];
+    }
+    const int tn2 = tn + nj;
+    const bool has_next2 = has_next && tn2 < t_end;
+    int k2 = 0, p2 = 0, c2 = 0, idx_next2 = -1;
+    if (has_next) gather(idxbuf + (buf ^ 1) * TM);
+    if (has_next2) {
+      locate(tn2, k2, p2, c2);
+      idx_next2 = load_idx(p2, c2);
+    }
+
+    // ---- MFMA main loop over Cin in steps of 8
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const float *arow = As + (32 * wm * MB + (lane & 31)) * LDA + 4 * (lane >> 5);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      if (s + 2 < S) {
+#ifdef DGR_ABL_BONCE
+#pragma unroll
+        for (int j = 0; j < NB; ++j) b[(s + 2) % 3][j] = b[0][j];
+#else
+#pragma unroll
+        for (int j = 0; j < NB; ++j) b[(s + 2) % 3][j] = wk[((int64_t)(s + 2) * NBLK + j) * 64];
+#endif
+      }
+      f32x4 av[MB];
+#pragma unroll
+      for (int i = 0; i < MB; ++i) av[i] = *reinterpret_cast<const f32x4 *>(arow + i * 32 * LDA + s * 8);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+          for (int j = 0; j < NB; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][c], b[s % 3][j][c], acc[i][j], 0, 0, 0);
+    }
+    // ---- product rows: C layout col = lane & 31, row = (e&3) + 8 (e>>2) + 4 (lane>>5)
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int r = 32 * (wm * MB + i) + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+#ifdef DGR_ABL_NOSTORE
+        if (r < count && a.cout < 0) {
+#else
+        if (r < count) {
+#endif
+          if (identity) {
+            float *dst = a.out + (int64_t)(pstart + r) * a.out_ld;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+              const int col = 32 * (wn * NB + j) + (lane & 31);
+              if (col < a.cout) dst[col] = acc[i][j][e] + (a.shift ? a.shift[col] : 0.f);
+            }
+          } else {
+            float *dst = a.y + (int64_t)(pstart + r) * a.y_ld;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+              const int col = 32 * (wn * NB + j) + (lane & 31);
+              if (col < a.cout) dst[col] = acc[i][j][e];
+            }
+          }
+        }
+      }
+    }
+    if (!has_next) break;
+    __syncthreads();  // every wave is done reading As
+    t = tn; k = kn; pstart = pn; count = cn;
+    tn = tn2; has_next = has_next2; kn = k2; pn = p2; cn = c2; idx_next = idx_next2;
+    buf ^= 1;
+  }
+}
+
+template <int CP, int WM, int WN, int MB, int NB, bool VEC>
+static int launch_v2(const ConvKArgs &ka, int64_t tile_bound, int num_cus, hipStream_t stream) {
+  constexpr int THREADS = 64 * WM * WN;
+  const size_t lds_bytes = (size_t)DGR_TILE_M * (CP + 4) * sizeof(float) + 2 * DGR_TILE_M * sizeof(int);
+  static int per_cu = 0;
+  if (per_cu == 0) {
+    DGR_HIP_CHECK(hipFuncSetAttribute((const void *)sparse_conv_mfma_v2<CP, WM, WN, MB, NB, VEC>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    int n = 0;
+    DGR_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sparse_conv_mfma_v2<CP, WM, WN, MB, NB, VEC>,
+                                                               THREADS, lds_bytes));
+    per_cu = n < 1 ? 1 : (n > 2048 / THREADS ? 2048 / THREADS : n);
+  }
+  int64_t grid = (int64_t)num_cus * per_cu;
+  if (tile_bound < grid) grid = tile_bound;
+  grid = (grid + 7) / 8 * 8;
+  if (grid < 8) grid = 8;
+  sparse_conv_mfma_v2<CP, WM, WN, MB, NB, VEC><<<(int)grid, THREADS, lds_bytes, stream>>>(ka);
+  DGR_LAUNCH_CHECK();
+  return DGR_OK;
+}
+
 int dgr_conv_launch(const DgrConvLaunch &a, int num_cus, hipStream_t stream) {
   ConvKArgs ka;
   ka.in = a.in; ka.out = a.out; ka.w = a.w; ka.y = a.y; ka.shift = a.shift; ka.y_ld = a.cout;
@@ -227,6 +449,25 @@ int dgr_conv_launch(const DgrConvLaunch &a, int num_cus, hipStream_t stream) {
   ka.cin = a.cin; ka.cin_pad = a.cin_pad; ka.cout = a.cout; ka.K = a.K;
   DGR_REQUIRE(a.cin_pad % 8 == 0 && a.cin_pad >= a.cin && a.cin_pad <= 256, "bad cin_pad %d", a.cin_pad);
   const int64_t tile_bound = a.tile_bound > 0 ? a.tile_bound : (int64_t)num_cus * 4;
+  // specialised (compile-time Cin, pipelined) instantiations for every layer shape of ResUNetBN2C
+  const bool vec = ((a.cin | a.in_ld) & 3) == 0;
+  static const bool use_v2 = getenv("DGR_CONV_V1") == nullptr;
+#define DGR_V2(CPV, WMV, WNV, MBV, NBV)                                                             \
+  if (a.cin_pad == CPV) {                                                                            \
+    return vec ? launch_v2<CPV, WMV, WNV, MBV, NBV, true>(ka, tile_bound, num_cus, stream)          \
+               : launch_v2<CPV, WMV, WNV, MBV, NBV, false>(ka, tile_bound, num_cus, stream);        \
+  }
+  if (use_v2) {
+    switch (a.cout_pad) {
+      case 32: DGR_V2(8, 2, 1, 1, 1) DGR_V2(32, 2, 1, 1, 1) DGR_V2(64, 2, 1, 1, 1) break;
+      case 64: DGR_V2(32, 2, 2, 1, 1) DGR_V2(64, 2, 2, 1, 1) DGR_V2(96, 2, 2, 1, 1) DGR_V2(128, 2, 2, 1, 1)
+               DGR_V2(256, 2, 2, 1, 1) break;
+      case 128: DGR_V2(64, 1, 4, 2, 1) DGR_V2(128, 1, 4, 2, 1) DGR_V2(256, 1, 4, 2, 1) break;
+      case 256: DGR_V2(128, 1, 4, 2, 2) DGR_V2(256, 1, 4, 2, 2) break;
+      default: break;
+    }
+  }
+#undef DGR_V2
   switch (a.cout_pad) {
     case 32: return launch_cfg<2, 1, 1, 1>(ka, tile_bound, num_cus, stream);
     case 64: return launch_cfg<2, 2, 1, 1>(ka, tile_bound, num_cus, stream);
