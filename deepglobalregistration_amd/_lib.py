@@ -48,6 +48,7 @@ SIGNATURES = {
     'dgr_net_get_intermediate': (C.c_int, [vp, vp, C.c_char_p, vp, C.c_int64, c_i64p, c_i64p]),
     'dgr_net_layer_stats': (C.c_int, [vp, vp, C.c_int, c_i64p]),
     'dgr_net_num_layers': (C.c_int, [vp]),
+    'dgr_net_rerun_layer': (C.c_int, [vp, vp, C.c_int, C.c_int, c_f32p, c_f32p]),
     'dgr_maps_create': (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int, C.POINTER(vp), vp]),
     'dgr_maps_destroy': (None, [vp]),
     'dgr_maps_get_coords': (C.c_int, [vp, C.c_int, vp, C.c_int64, c_i64p]),

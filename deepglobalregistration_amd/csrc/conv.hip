@@ -221,26 +221,37 @@ static int launch_cfg(const ConvKArgs &ka, int64_t tile_bound, int num_cus, hipS
 }
 
 // ------------------------------------------------------------------------------------------
-// v2: compile-time Cin, software-pipelined across tiles.  While the matrix cores work on tile t out
-// of LDS, the 64 input rows of the block's NEXT tile are already in flight into registers (issued
-// right after the first two B-operand loads so that those stay ahead of them in the in-order vmcnt
-// queue) and the row indices of the tile after that are being fetched; after the MFMA loop the
-// registers are dropped into LDS between two barriers.  B operands are prefetched three K-steps deep.
+// v2: compile-time Cin, software-pipelined in PHASES of <= 128 input channels.
+//   * LDS holds two A buffers [64 rows x CK channels]; phase q multiplies out of buffer q&1 while
+//     the rows of phase q+1 (requested one phase earlier, held in <= 8 float4 registers per thread)
+//     are dropped into the other buffer and the rows of phase q+2 are requested -> ONE barrier per
+//     phase, and every gather has a whole MFMA phase to land.
+//   * vmcnt retires in order and store acknowledgements are slow, so the first three B-operand
+//     loads of a tile are issued before the previous tile's stores; B runs a 4-deep register ring.
+//   * MFMA operands are swapped (D = W^T . In^T): a lane owns one pair and 4 x 4 consecutive output
+//     channels, so product rows leave as 16-byte stores.
+//   * row indices travel through a 4-slot LDS ring, loaded two tiles ahead.
 // ------------------------------------------------------------------------------------------
 template <int CP, int WM, int WN, int MB, int NB, bool VEC>
-__global__ void __launch_bounds__(64 * WM * WN) sparse_conv_mfma_v2(ConvKArgs a) {
+__global__ void __launch_bounds__(64 * WM * WN, (MB * NB >= 4 ? 2 : 1)) sparse_conv_mfma_v2(ConvKArgs a) {
   constexpr int THREADS = 64 * WM * WN;
   constexpr int TM = 32 * MB * WM;
   static_assert(TM == DGR_TILE_M, "tile height must match the kernel-map tiling");
   constexpr int NBLK = NB * WN;
-  constexpr int C4N = CP / 4;                 // 16-byte pieces per row
-  constexpr int NCH = TM * C4N / THREADS;     // pieces per thread per tile
-  static_assert(TM * C4N % THREADS == 0, "gather pieces must divide evenly");
-  constexpr int LDA = CP + 4;
-  constexpr int S = CP / 8;
+  constexpr int CK = CP > 128 ? 128 : CP;     // channels per phase
+  constexpr int PPT = CP / CK;                // phases per tile
+  static_assert(CP % CK == 0, "phase width must divide Cin");
+  constexpr int C4K = CK / 4;                 // 16-byte pieces per row per phase
+  constexpr int NCH = TM * C4K / THREADS;     // pieces per thread per phase
+  static_assert(TM * C4K % THREADS == 0, "gather pieces must divide evenly");
+  constexpr int LDA = CK + 4;
+  constexpr int SK = CK / 8;                  // K-steps per phase
+  constexpr int S = CP / 8;                   // K-steps per tile
+  constexpr int RING = 4;
+  static_assert(SK == 1 || SK % RING == 0, "phase length must be a multiple of the B ring");
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float *As = lds;
-  int *idxbuf = reinterpret_cast<int *>(lds + TM * LDA);  // [2][TM] input-row index of the tile rows
+  float *As = lds;                                                 // [2][TM][LDA]
+  int *idxbuf = reinterpret_cast<int *>(lds + 2 * TM * LDA);       // [4][TM]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -253,10 +264,13 @@ __global__ void __launch_bounds__(64 * WM * WN) sparse_conv_mfma_v2(ConvKArgs a)
   const int xcd = blockIdx.x & 7;
   const int t_end = min(T, (xcd + 1) * per);
   const int nj = gridDim.x >> 3;
-  int t = xcd * per + (blockIdx.x >> 3);
-  if (t >= t_end) return;
+  const int t_first = xcd * per + (blockIdx.x >> 3);
+  if (t_first >= t_end) return;
+  const int n_my = (t_end - t_first + nj - 1) / nj;  // tiles of this block: t_first + i * nj
+  const int NQ = n_my * PPT;                         // phases of this block
 
-  auto locate = [&](int tt, int &k, int &pstart, int &count) {
+  auto locate = [&](int i, int &k, int &pstart, int &count) {
+    const int tt = t_first + i * nj;
     if (identity) {
       k = 0;
       pstart = tt * TM;
@@ -272,16 +286,21 @@ __global__ void __launch_bounds__(64 * WM * WN) sparse_conv_mfma_v2(ConvKArgs a)
       count = min(TM, a.rule_ptr[k + 1] - pstart);
     }
   };
-  auto load_idx = [&](int pstart, int count) -> int {
-    if (tid < TM && tid < count) return identity ? pstart + tid : a.pair_in[pstart + tid];
-    return -1;
+  auto load_idx = [&](int i) -> int {  // input row of tile-row `tid` of the block's i-th tile, or -1
+    if (i >= n_my || tid >= TM) return -1;
+    int k, pstart, count;
+    locate(i, k, pstart, count);
+    if (tid >= count) return -1;
+    return identity ? pstart + tid : a.pair_in[pstart + tid];
   };
   f32x4 G[NCH];
-  auto gather = [&](const int *idx) {
+  auto gather = [&](int q) {  // request the rows of phase q (tile q / PPT, channels (q % PPT) * CK ..)
+    const int *idx = idxbuf + ((q / PPT) & 3) * TM;
+    const int cbase = (q % PPT) * CK;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int ch = tid + i * THREADS;
-      const int r = ch / C4N, c4 = ch % C4N;
+      const int r = ch / C4K, c = cbase + (ch % C4K) * 4;
       const int row = idx[r];
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #ifdef DGR_ABL_NOGATHER
@@ -289,85 +308,86 @@ __global__ void __launch_bounds__(64 * WM * WN) sparse_conv_mfma_v2(ConvKArgs a)
 #else
       if (row >= 0) {
 #endif
-        const float *src = a.in + (int64_t)row * a.in_ld + c4 * 4;
+        const float *src = a.in + (int64_t)row * a.in_ld + c;
         if (VEC) {
-          if (c4 * 4 < a.cin) v = *reinterpret_cast<const f32x4 *>(src);
+          if (c < a.cin) v = *reinterpret_cast<const f32x4 *>(src);
         } else {
-          if (c4 * 4 + 0 < a.cin) v.x = src[0];
-          if (c4 * 4 + 1 < a.cin) v.y = src[1];
-          if (c4 * 4 + 2 < a.cin) v.z = src[2];
-          if (c4 * 4 + 3 < a.cin) v.w = src[3];
+          if (c + 0 < a.cin) v.x = src[0];
+          if (c + 1 < a.cin) v.y = src[1];
+          if (c + 2 < a.cin) v.z = src[2];
+          if (c + 3 < a.cin) v.w = src[3];
         }
         if (a.in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       }
       G[i] = v;
     }
   };
-
-  // ---- prologue: indices of tile t into LDS, indices of the next tile into a register, gather tile t
-  int k, pstart, count;
-  locate(t, k, pstart, count);
-  {
-    const int mine = load_idx(pstart, count);
-    if (tid < TM) idxbuf[tid] = mine;
-  }
-  int tn = t + nj;
-  bool has_next = tn < t_end;
-  int kn = 0, pn = 0, cn = 0, idx_next = -1;
-  if (has_next) {
-    locate(tn, kn, pn, cn);
-    idx_next = load_idx(pn, cn);
-  }
-  __syncthreads();
-  gather(idxbuf);
-  int buf = 0;
-
-  while (true) {
-    // registers -> LDS (tile t); publish the next tile's indices in the other index buffer
+  auto land = [&](int q) {  // registers -> A buffer q & 1
+    float *dst = As + (q & 1) * TM * LDA;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int ch = tid + i * THREADS;
-      *reinterpret_cast<f32x4 *>(As + (ch / C4N) * LDA + (ch % C4N) * 4) = G[i];
+      *reinterpret_cast<f32x4 *>(dst + (ch / C4K) * LDA + (ch % C4K) * 4) = G[i];
     }
-    if (tid < TM) idxbuf[(buf ^ 1) * TM + tid] = idx_next;
-    __syncthreads();
+  };
 
-    // first B operands of this tile, THEN the next tile's gather (keeps them ahead in the vmcnt queue)
+  // ---- prologue: indices of tiles 0..2 into the LDS ring, tile 3's into a register; phase 0 landed,
+  //      phase 1 in flight; first B operands of tile 0 requested
+  {
+    const int i0 = load_idx(0), i1 = load_idx(1), i2 = load_idx(2);
+    if (tid < TM) { idxbuf[tid] = i0; idxbuf[TM + tid] = i1; idxbuf[2 * TM + tid] = i2; }
+  }
+  int next_pub = 3;
+  int idx_reg = load_idx(3);
+  int k, pstart, count;
+  locate(0, k, pstart, count);
+  f32x4 b[RING][NB];
+  {
+    const f32x4 *w0 = reinterpret_cast<const f32x4 *>(a.w) + ((int64_t)k * S * NBLK + wn * NB) * 64 + lane;
+#pragma unroll
+    for (int r = 0; r < RING - 1; ++r)
+      if (r < S) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) b[r][j] = w0[((int64_t)r * NBLK + j) * 64];
+      }
+  }
+  __syncthreads();
+  gather(0);
+  land(0);
+  if (1 < NQ) gather(1);
+  __syncthreads();
+
+  f32x16 acc[MB][NB];
+  for (int q = 0; q < NQ; ++q) {
+    const int h = q % PPT;
+    if (q + 1 < NQ) land(q + 1);      // requested one phase ago
+    if (q + 2 < NQ) gather(q + 2);    // a whole phase to arrive
+    if ((q + 3) / PPT >= next_pub && next_pub < n_my) {  // indices for the gather of the phase after next
+      if (tid < TM) idxbuf[(next_pub & 3) * TM + tid] = idx_reg;
+      ++next_pub;
+      idx_reg = load_idx(next_pub);
+    }
+    if (h == 0) {
+#pragma unroll
+      for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    }
+    // ---- MFMA over this phase's channels
     const f32x4 *wk = reinterpret_cast<const f32x4 *>(a.w) + ((int64_t)k * S * NBLK + wn * NB) * 64 + lane;
-    f32x4 b[3][NB];
+    const float *arow = As + (q & 1) * TM * LDA + (32 * wm * MB + (lane & 31)) * LDA + 4 * (lane >> 5);
+    const int s0 = h * SK;
 #pragma unroll
-    for (int j = 0; j < NB; ++j) b[0][j] = wk[j * 64];
-    if (S > 1) {
-#pragma unroll
-      for (int j = 0; j < NB; ++j) b[1][j] = wk[((int64_t)NBLK + j) * 64];
-    }
-    const int tn2 = tn + nj;
-    const bool has_next2 = has_next && tn2 < t_end;
-    int k2 = 0, p2 = 0, c2 = 0, idx_next2 = -1;
-    if (has_next) gather(idxbuf + (buf ^ 1) * TM);
-    if (has_next2) {
-      locate(tn2, k2, p2, c2);
-      idx_next2 = load_idx(p2, c2);
-    }
-
-    // ---- MFMA main loop over Cin in steps of 8
-    f32x16 acc[MB][NB];
-#pragma unroll
-    for (int i = 0; i < MB; ++i)
-#pragma unroll
-      for (int j = 0; j < NB; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    const float *arow = As + (32 * wm * MB + (lane & 31)) * LDA + 4 * (lane >> 5);
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-      if (s + 2 < S) {
+    for (int s = 0; s < SK; ++s) {
+      if (s0 + s + RING - 1 < S) {
 #ifdef DGR_ABL_BONCE
 #pragma unroll
-        for (int j = 0; j < NB; ++j) b[(s + 2) % 3][j] = b[0][j];
+        for (int j = 0; j < NB; ++j) b[(s + RING - 1) % RING][j] = b[s % RING][j];
 #else
 #pragma unroll
-        for (int j = 0; j < NB; ++j) b[(s + 2) % 3][j] = wk[((int64_t)(s + 2) * NBLK + j) * 64];
+        for (int j = 0; j < NB; ++j) b[(s + RING - 1) % RING][j] = wk[((int64_t)(s0 + s + RING - 1) * NBLK + j) * 64];
 #endif
       }
       f32x4 av[MB];
@@ -379,49 +399,64 @@ __global__ void __launch_bounds__(64 * WM * WN) sparse_conv_mfma_v2(ConvKArgs a)
         for (int i = 0; i < MB; ++i)
 #pragma unroll
           for (int j = 0; j < NB; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][c], b[s % 3][j][c], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[s % RING][j][c], av[i][c], acc[i][j], 0, 0, 0);
     }
-    // ---- product rows: C layout col = lane & 31, row = (e&3) + 8 (e>>2) + 4 (lane>>5)
+    if (h == PPT - 1) {
+      // ---- tile finished: request the next tile's first B operands BEFORE this tile's stores
+      const int pst = pstart, cnt = count;
+      const int i_next = q / PPT + 1;
+      if (i_next < n_my) {
+        locate(i_next, k, pstart, count);
+        const f32x4 *w1 = reinterpret_cast<const f32x4 *>(a.w) + ((int64_t)k * S * NBLK + wn * NB) * 64 + lane;
 #pragma unroll
-    for (int i = 0; i < MB; ++i) {
+        for (int r = 0; r < RING - 1; ++r)
+          if (r < S) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int r = 32 * (wm * MB + i) + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            for (int j = 0; j < NB; ++j) b[r][j] = w1[((int64_t)r * NBLK + j) * 64];
+          }
+      }
+      // product rows: D column (pair) = lane & 31, D row (channel) = (e&3) + 8 (e>>2) + 4 (lane>>5)
+#pragma unroll
+      for (int i = 0; i < MB; ++i) {
+        const int r = 32 * (wm * MB + i) + (lane & 31);
 #ifdef DGR_ABL_NOSTORE
-        if (r < count && a.cout < 0) {
+        if (r < cnt && a.cout < 0) {
 #else
-        if (r < count) {
+        if (r < cnt) {
 #endif
-          if (identity) {
-            float *dst = a.out + (int64_t)(pstart + r) * a.out_ld;
+          float *dst = identity ? a.out + (int64_t)(pst + r) * a.out_ld : a.y + (int64_t)(pst + r) * a.y_ld;
 #pragma unroll
-            for (int j = 0; j < NB; ++j) {
-              const int col = 32 * (wn * NB + j) + (lane & 31);
-              if (col < a.cout) dst[col] = acc[i][j][e] + (a.shift ? a.shift[col] : 0.f);
-            }
-          } else {
-            float *dst = a.y + (int64_t)(pstart + r) * a.y_ld;
+          for (int j = 0; j < NB; ++j) {
 #pragma unroll
-            for (int j = 0; j < NB; ++j) {
-              const int col = 32 * (wn * NB + j) + (lane & 31);
-              if (col < a.cout) dst[col] = acc[i][j][e];
+            for (int g = 0; g < 4; ++g) {
+              const int col = 32 * (wn * NB + j) + 8 * g + 4 * (lane >> 5);
+              f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+              if (identity) {
+                if (col + 3 < a.cout && (a.out_ld & 3) == 0) {
+                  if (a.shift) v += *reinterpret_cast<const f32x4 *>(a.shift + col);
+                  *reinterpret_cast<f32x4 *>(dst + col) = v;
+                } else {
+#pragma unroll
+                  for (int u = 0; u < 4; ++u)
+                    if (col + u < a.cout) dst[col + u] = v[u] + (a.shift ? a.shift[col + u] : 0.f);
+                }
+              } else if (col < a.cout) {
+                *reinterpret_cast<f32x4 *>(dst + col) = v;  // y_ld = cout is a multiple of 32 here
+              }
             }
           }
         }
       }
     }
-    if (!has_next) break;
-    __syncthreads();  // every wave is done reading As
-    t = tn; k = kn; pstart = pn; count = cn;
-    tn = tn2; has_next = has_next2; kn = k2; pn = p2; cn = c2; idx_next = idx_next2;
-    buf ^= 1;
+    __syncthreads();  // buffer q&1 is free again; buffer (q+1)&1 and the index ring are visible
   }
 }
 
 template <int CP, int WM, int WN, int MB, int NB, bool VEC>
 static int launch_v2(const ConvKArgs &ka, int64_t tile_bound, int num_cus, hipStream_t stream) {
   constexpr int THREADS = 64 * WM * WN;
-  const size_t lds_bytes = (size_t)DGR_TILE_M * (CP + 4) * sizeof(float) + 2 * DGR_TILE_M * sizeof(int);
+  constexpr int CKL = CP > 128 ? 128 : CP;
+  const size_t lds_bytes = (size_t)2 * DGR_TILE_M * (CKL + 4) * sizeof(float) + 4 * DGR_TILE_M * sizeof(int);
   static int per_cu = 0;
   if (per_cu == 0) {
     DGR_HIP_CHECK(hipFuncSetAttribute((const void *)sparse_conv_mfma_v2<CP, WM, WN, MB, NB, VEC>,

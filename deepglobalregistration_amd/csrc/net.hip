@@ -29,10 +29,16 @@ struct DgrLayer {
   float *shift = nullptr;  // device [cout] or nullptr
 };
 
-struct LayerRun {  // bookkeeping of the last forward, for dgr_net_layer_stats
+struct LayerRun {  // bookkeeping of the last forward, for dgr_net_layer_stats / dgr_net_rerun_layer
   const int32_t *rule_ptr = nullptr;
   const int32_t *n_in = nullptr, *n_out = nullptr;
   int K = 1;
+  DgrConvLaunch launch;   // the exact launch of phase 1
+  bool has_reduce = false;  // phase 2 parameters
+  const int32_t *red_ptr = nullptr, *red_pos = nullptr;
+  int64_t n_out_cap = 0;
+  const float *res = nullptr;
+  int res_ld = 0, res_relu = 0;
 };
 
 struct DgrTensorRef {
@@ -234,6 +240,14 @@ struct Fwd {
       ctx->conv_spans.push_back({e0, e1});
     }
     LayerRun &r = net->runs[li];
+    r.launch = a;
+    r.has_reduce = km != nullptr;
+    if (km) {
+      r.red_ptr = swapped ? km->in_ptr : km->out_ptr;
+      r.red_pos = swapped ? km->in_pos : km->out_pos;
+    }
+    r.n_out_cap = cout_map.n_cap;
+    r.res = res ? res->ptr : nullptr; r.res_ld = res ? res->ld : 0; r.res_relu = res ? res->relu : 0;
     r.rule_ptr = km ? km->rule_ptr : nullptr;
     r.n_in = cin_map.n_dev; r.n_out = cout_map.n_dev; r.K = L.K;
     return DGR_OK;
@@ -450,5 +464,37 @@ extern "C" int dgr_net_layer_stats(dgr_ctx *ctx, dgr_net *net, int layer, int64_
   }
   stats[0] = P; stats[1] = kne; stats[2] = n_in; stats[3] = n_out;
   stats[4] = L.cin; stats[5] = L.cout; stats[6] = L.K; stats[7] = 0;
+  return DGR_OK;
+}
+
+// Re-run one conv layer of the last stage-wise forward `reps` times (its kernel maps and activations
+// are still in the arena) and report the mean duration of phase 1 (MFMA) and phase 2 (reduce) in ms.
+// Kernel-tuning instrument; not part of the inference path.
+extern "C" int dgr_net_rerun_layer(dgr_ctx *ctx, dgr_net *net, int layer, int reps, float *gemm_ms, float *reduce_ms) {
+  DGR_REQUIRE(ctx && net && gemm_ms && reduce_ms && reps > 0, "bad argument");
+  DGR_REQUIRE(layer >= 0 && layer < (int)net->layers.size(), "layer %d out of range", layer);
+  const LayerRun &r = net->runs[layer];
+  DGR_REQUIRE(r.n_in && r.n_out, "run a forward first");
+  const DgrLayer &L = net->layers[layer];
+  hipEvent_t e0, e1, e2;
+  DGR_HIP_CHECK(hipEventCreate(&e0)); DGR_HIP_CHECK(hipEventCreate(&e1)); DGR_HIP_CHECK(hipEventCreate(&e2));
+  float tg = 0.f, tr = 0.f;
+  for (int i = 0; i < reps + 1; ++i) {  // first iteration = warm-up
+    DGR_HIP_CHECK(hipEventRecord(e0, nullptr));
+    DGR_CHECK(dgr_conv_launch(r.launch, ctx->num_cus, nullptr));
+    DGR_HIP_CHECK(hipEventRecord(e1, nullptr));
+    if (r.has_reduce)
+      DGR_CHECK(dgr_reduce_rows(r.launch.y, L.cout, r.red_ptr, r.red_pos, r.n_out, r.n_out_cap, r.launch.out,
+                                r.launch.out_ld, L.shift, r.res, r.res_ld, r.res_relu, nullptr));
+    DGR_HIP_CHECK(hipEventRecord(e2, nullptr));
+    DGR_HIP_CHECK(hipEventSynchronize(e2));
+    float a = 0.f, b = 0.f;
+    DGR_HIP_CHECK(hipEventElapsedTime(&a, e0, e1));
+    DGR_HIP_CHECK(hipEventElapsedTime(&b, e1, e2));
+    if (i > 0) { tg += a; tr += b; }
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+  *gemm_ms = tg / reps;
+  *reduce_ms = tr / reps;
   return DGR_OK;
 }

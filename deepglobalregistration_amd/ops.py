@@ -116,6 +116,13 @@ class NetHandle:
                                            C.byref(rows), C.byref(cols)))
         return buf
 
+    def rerun_layer(self, layer, reps=5):
+        """(gemm_ms, reduce_ms) of conv layer `layer` of the last forward (kernel-tuning instrument)."""
+        lib = _lib.load()
+        g, r = C.c_float(0), C.c_float(0)
+        check(lib.dgr_net_rerun_layer(get_ctx(self.device), self.handle, layer, reps, C.byref(g), C.byref(r)))
+        return g.value, r.value
+
     def layer_stats(self):
         """Per conv layer of the last forward: dict(pairs, nonempty, n_in, n_out, cin, cout, K)."""
         lib = _lib.load()

@@ -99,6 +99,9 @@ int dgr_net_get_intermediate(dgr_ctx *ctx, dgr_net *net, const char *name, float
  * `layer` (0..22): pairs, non-empty offsets, n_in, n_out, cin, cout.  Synchronises. */
 int dgr_net_layer_stats(dgr_ctx *ctx, dgr_net *net, int layer, int64_t stats[8]);
 int dgr_net_num_layers(const dgr_net *net);
+/* kernel-tuning instrument: re-run conv layer `layer` of the last dgr_resunet_forward `reps` times on
+ * the default stream and return the mean duration (ms) of its MFMA phase and its reduce phase. */
+int dgr_net_rerun_layer(dgr_ctx *ctx, dgr_net *net, int layer, int reps, float *gemm_ms, float *reduce_ms);
 
 /* ---- coordinate / kernel maps as a stand-alone object (inspection + parity tests):
  * the coordinate manager part of ME.SparseTensor / MinkowskiConvolution. */
