@@ -85,10 +85,47 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_final(const int32_t *__rest
   }
 }
 
+// one workgroup, 1024 threads x 4 items per round with a running carry: ONE launch instead of three
+// for the many small scans of the map build (n <= a few 100 k), where launch boundaries dominate
+__global__ void __launch_bounds__(1024) scan_single_block(const int32_t *__restrict__ in, int64_t n,
+                                                          int32_t *__restrict__ out, int32_t *total_out) {
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < n; base += 4096) {
+    const int64_t i0 = base + (int64_t)threadIdx.x * 4;
+    int v[4], s = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = (i0 + j < n) ? in[i0 + j] : 0; s += v[j]; }
+    int x = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    int wbase = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const int t = wsum[w]; if (w < wave) wbase += t; tot += t; }
+    int ex = carry_s + wbase + x - s;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { if (i0 + j < n) out[i0 + j] = ex; ex += v[j]; }
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && total_out) *total_out = carry_s;
+}
+
 int dgr_exclusive_scan_i32(DgrArena &arena, const int32_t *in, int32_t *out, int64_t n,
                            int32_t *total_out, hipStream_t stream) {
   if (n <= 0) {
     if (total_out) DGR_HIP_CHECK(hipMemsetAsync(total_out, 0, sizeof(int32_t), stream));
+    return DGR_OK;
+  }
+  if (n <= (1 << 14)) {
+    scan_single_block<<<1, 1024, 0, stream>>>(in, n, out, total_out);
+    DGR_LAUNCH_CHECK();
     return DGR_OK;
   }
   int nblocks = (int)dgr_ceil_div(n, SCAN_BLOCK);

@@ -128,6 +128,17 @@ __global__ void override_idx_kernel(int64_t *idx, const int64_t *__restrict__ ov
   if (i < n && ovr[i] >= 0) idx[i] = ovr[i];
 }
 
+// both fragments of every pair as ONE sparse tensor: fragment-0 rows keep batch 2p, fragment-1 rows
+// get batch 2p+1 (the batch column only has to separate clouds; ME.utils.batched_coordinates layout)
+__global__ void concat_coords_kernel(const int32_t *__restrict__ c0, int64_t n0, const int32_t *__restrict__ c1,
+                                     int64_t n1, int32_t *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n0 + n1) return;
+  const int32_t *src = i < n0 ? c0 + i * 4 : c1 + (i - n0) * 4;
+  out[i * 4] = src[0] * 2 + (i < n0 ? 0 : 1);
+  out[i * 4 + 1] = src[1]; out[i * 4 + 2] = src[2]; out[i * 4 + 3] = src[3];
+}
+
 __global__ void add_offset_kernel(int64_t *idx, int64_t n, int64_t off) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) idx[i] += off;
@@ -180,9 +191,9 @@ extern "C" int dgr_register_batch(dgr_ctx *ctx, dgr_net *fcgf, dgr_net *inlier, 
   int64_t *idx1, *off0_dev;
   int32_t *coords6;
   DgrRegResult *res_dev;
-  DGR_ALLOC(F0, A, float, n0 * C);
-  DGR_ALLOC(F1, A, float, n1 * C);
-  DGR_ALLOC(ones, A, float, n0 > n1 ? n0 : n1);
+  DGR_ALLOC(F0, A, float, (n0 + n1) * C);
+  F1 = F0 + n0 * C;  // one forward over both fragments writes [F0; F1]
+  DGR_ALLOC(ones, A, float, n0 + n1);
   DGR_ALLOC(idx1, A, int64_t, n0);
   DGR_ALLOC(coords6, A, int32_t, n0 * 7);
   DGR_ALLOC(feats6, A, float, n0 * 6);
@@ -191,15 +202,18 @@ extern "C" int dgr_register_batch(dgr_ctx *ctx, dgr_net *fcgf, dgr_net *inlier, 
   DGR_ALLOC(off0_dev, A, int64_t, npairs + 1);
   DGR_ALLOC(res_dev, A, DgrRegResult, npairs);
   DGR_HIP_CHECK(hipMemcpyAsync(off0_dev, off0, (size_t)(npairs + 1) * sizeof(int64_t), hipMemcpyHostToDevice, stream));
-  fill_kernel<<<256, 256, 0, stream>>>(ones, n0 > n1 ? n0 : n1, 1.f);
+  fill_kernel<<<256, 256, 0, stream>>>(ones, n0 + n1, 1.f);
 
   // Step 1: FCGF features of both fragments (feats = ones[N,1], :160)
   DGR_CHECK(tm.rec(0, 0));
   {
+    // the reference runs the two fragments one after the other (:250-251); their rows never interact
+    // (different batch index), so one sparse tensor halves the number of launches and fills the GPU
     DgrArena::Mark mk = A.mark();
-    DGR_CHECK(dgr_resunet_forward_impl(ctx, fcgf, coords0, ones, n0, F0, stream));
-    A.rewind(mk);
-    DGR_CHECK(dgr_resunet_forward_impl(ctx, fcgf, coords1, ones, n1, F1, stream));
+    int32_t *coords01;
+    DGR_ALLOC(coords01, A, int32_t, (n0 + n1) * 4);
+    concat_coords_kernel<<<(int)dgr_ceil_div(n0 + n1, 256), 256, 0, stream>>>(coords0, n0, coords1, n1, coords01);
+    DGR_CHECK(dgr_resunet_forward_impl(ctx, fcgf, coords01, ones, n0 + n1, F0, stream));
     A.rewind(mk);
   }
   DGR_CHECK(tm.rec(0, 1));

@@ -14,7 +14,9 @@
 // arithmetic is f32 like the reference; the 3x3 SVD is f64 (one-sided Jacobi) like its LAPACK call.
 #include "dgr_internal.h"
 
-constexpr int REG_THREADS = 512;
+// one wave per SIMD: the 9-parameter update is computed redundantly by every wave, so co-resident
+// waves on a SIMD would only serialise it (measured: 512 threads = 10.4 us / iteration)
+constexpr int REG_THREADS = 256;
 constexpr int REG_WAVES = REG_THREADS / 64;
 
 struct RegArgs {
@@ -346,6 +348,9 @@ __global__ void __launch_bounds__(REG_THREADS) registration_kernel(RegArgs a) {
   for (int i = 0; i < 9; ++i) { am[i] = 0.f; av[i] = 0.f; }
   const float w1 = (float)S[1];  // loss_fn.w1 = weights.sum(), core/loss.py:48-49
   const float q = a.q;
+#ifdef DGR_REG_TIMING
+  long long tsum[3] = {0, 0, 0};
+#endif
   double lr = 0.1, b1t = 1.0, b2t = 1.0;
   float loss_prev = 0.f, loss = 0.f;
   int breaks = 0, it = 0;
@@ -355,11 +360,13 @@ __global__ void __launch_bounds__(REG_THREADS) registration_kernel(RegArgs a) {
     const float R00 = o.x[0], R10 = o.x[1], R20 = o.x[2];
     const float R01 = o.y[0], R11 = o.y[1], R21 = o.y[2];
     const float R02 = o.z[0], R12 = o.z[1], R22 = o.z[2];
+#ifdef DGR_REG_TIMING
+    const long long tc0 = clock64();
+#endif
     double g[13];
 #pragma unroll
     for (int i = 0; i < 13; ++i) g[i] = 0.0;
-    for (int i = tid; i < m; i += REG_THREADS) {
-      const float4 A = cA[i], B = cB[i];
+    auto point = [&](const float4 A, const float4 B) {
       const float px = A.x * R00 + A.y * R01 + A.z * R02 + prm[6];
       const float py = A.x * R10 + A.y * R11 + A.z * R12 + prm[7];
       const float pz = A.x * R20 + A.y * R21 + A.z * R22 + prm[8];
@@ -381,9 +388,33 @@ __global__ void __launch_bounds__(REG_THREADS) registration_kernel(RegArgs a) {
       g[4] += gx * A.x; g[5] += gx * A.y; g[6] += gx * A.z;
       g[7] += gy * A.x; g[8] += gy * A.y; g[9] += gy * A.z;
       g[10] += gz * A.x; g[11] += gz * A.y; g[12] += gz * A.z;
+    };
+    // four independent row loads in flight per thread (the rows are L2-resident; a dependent
+    // one-row-at-a-time loop would pay the L2 latency for every row)
+    for (int i = tid; i < m; i += 4 * REG_THREADS) {
+      float4 A[4], B[4];
+      // unconditional loads (clamped index) so that all eight are in flight together; a guarded load
+      // makes the compiler branch and wait per element (measured: ~1000 cycles per row)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = i + j * REG_THREADS;
+        const int rc = min(r, m - 1);
+        A[j] = cA[rc];
+        B[j] = cB[rc];
+        if (r >= m) A[j].w = 0.f;   // w = 0 rows contribute exactly 0 to the loss and the gradient
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) point(A[j], B[j]);
     }
+#ifdef DGR_REG_TIMING
+    const long long tc1 = clock64();
+#endif
     double Gs[13];
     block_sum_butterfly<13>(g, slab, it & 1, Gs);
+#ifdef DGR_REG_TIMING
+    const long long tc2 = clock64();
+    tsum[0] += tc1 - tc0; tsum[1] += tc2 - tc1;
+#endif
     loss = (float)(Gs[0] / (double)w1);
     if (it == 0) loss_prev = loss;  // loss_prev = loss_fn(T(points), trans_points) before the loop
     if (loss < 1e-7f) break;
@@ -406,6 +437,9 @@ __global__ void __launch_bounds__(REG_THREADS) registration_kernel(RegArgs a) {
       prm[i] = prm[i] + (float)(-step_size) * (am[i] / denom);
     }
     lr *= 0.999;
+#ifdef DGR_REG_TIMING
+    tsum[2] += clock64() - tc2;
+#endif
     if (fabs((double)loss_prev - (double)loss) < (double)loss_prev * a.ratio) {
       ++breaks;
       if (breaks >= a.max_break) break;
@@ -423,6 +457,10 @@ __global__ void __launch_bounds__(REG_THREADS) registration_kernel(RegArgs a) {
     res->iterations = it;
     res->break_count = breaks;
     res->loss = loss;
+#ifdef DGR_REG_TIMING
+    printf("reg timing: m=%d iters=%d cycles/iter: points %lld reduce %lld update %lld\n", m, it + 1,
+           tsum[0] / (it + 1), tsum[1] / (it + 1), tsum[2] / (it + 1));
+#endif
   }
 }
 

@@ -86,3 +86,17 @@ def test_forward_rejects_bad_shapes():
     del bad['norm1.bn.weight']
     with pytest.raises(ValueError):
         ops.NetHandle(bad, 3, 1, 32, 3, True)
+
+
+def test_forward_is_bit_reproducible():
+    """The conv stack has no floating-point atomics (per-pair product rows + fixed-order segmented
+    reduction), so two forwards of the same input are bitwise identical (the
+    reference's CUDA path is not, because MinkowskiEngine scatters with atomicAdd)."""
+    from deepglobalregistration_amd import ops, synth
+    rng = np.random.default_rng(1)
+    coords = torch.from_numpy(random_cloud_coords(rng, 6000, 30, 3)).cuda()
+    ones = torch.ones(len(coords), 1, device='cuda')
+    net = ops.NetHandle(synth.synth_state_dict(3, 1, 32, 7, 2), 3, 1, 32, 7, True)
+    a = net.forward(coords, ones)
+    b = net.forward(coords, ones)
+    assert torch.equal(a, b)
