@@ -35,6 +35,7 @@ struct ConvKArgs {
   const float *shift;  // identity maps: folded bias / BN shift (may be null)
   const float *w;
   const int32_t *pair_in, *pair_out, *tile_ptr, *rule_ptr, *n_rows_dev;
+  const int4 *tile_desc;
   int in_ld, out_ld, in_relu, y_ld;
   int cin, cin_pad, cout, K;
 };
@@ -232,13 +233,24 @@ static int launch_cfg(const ConvKArgs &ka, int64_t tile_bound, int num_cus, hipS
 //     channels, so product rows leave as 16-byte stores.
 //   * row indices travel through a 4-slot LDS ring, loaded two tiles ahead.
 // ------------------------------------------------------------------------------------------
+#ifndef DGR_WIDE_CK
+#define DGR_WIDE_CK 128     // phase width (input channels) of the widest configuration
+#endif
+#ifndef DGR_WIDE_WAVES
+#define DGR_WIDE_WAVES 2    // waves per SIMD the widest configuration is compiled for
+#endif
+constexpr int conv_phase_width(int cp, int acc_blocks) {
+  const int cap = acc_blocks >= 4 ? DGR_WIDE_CK : 128;
+  return cp > cap ? cap : cp;
+}
+
 template <int CP, int WM, int WN, int MB, int NB, bool VEC>
-__global__ void __launch_bounds__(64 * WM * WN, (MB * NB >= 4 ? 2 : 1)) sparse_conv_mfma_v2(ConvKArgs a) {
+__global__ void __launch_bounds__(64 * WM * WN, (MB * NB >= 4 ? DGR_WIDE_WAVES : 1)) sparse_conv_mfma_v2(ConvKArgs a) {
   constexpr int THREADS = 64 * WM * WN;
   constexpr int TM = 32 * MB * WM;
   static_assert(TM == DGR_TILE_M, "tile height must match the kernel-map tiling");
   constexpr int NBLK = NB * WN;
-  constexpr int CK = CP > 128 ? 128 : CP;     // channels per phase
+  constexpr int CK = conv_phase_width(CP, MB * NB);  // channels per phase
   constexpr int PPT = CP / CK;                // phases per tile
   static_assert(CP % CK == 0, "phase width must divide Cin");
   constexpr int C4K = CK / 4;                 // 16-byte pieces per row per phase
@@ -276,14 +288,10 @@ __global__ void __launch_bounds__(64 * WM * WN, (MB * NB >= 4 ? 2 : 1)) sparse_c
       pstart = tt * TM;
       count = min(TM, n_rows - pstart);
     } else {
-      int lo = 0, hi = a.K;
-      while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (a.tile_ptr[mid] <= tt) lo = mid; else hi = mid;
-      }
-      k = lo;
-      pstart = a.rule_ptr[k] + (tt - a.tile_ptr[k]) * TM;
-      count = min(TM, a.rule_ptr[k + 1] - pstart);
+      const int4 d = a.tile_desc[tt];  // one scalar 16-byte load (kmap.hip: tile_desc_kernel)
+      k = d.x;
+      pstart = d.y;
+      count = d.z;
     }
   };
   auto load_idx = [&](int i) -> int {  // input row of tile-row `tid` of the block's i-th tile, or -1
@@ -390,6 +398,9 @@ __global__ void __launch_bounds__(64 * WM * WN, (MB * NB >= 4 ? 2 : 1)) sparse_c
         for (int j = 0; j < NB; ++j) b[(s + RING - 1) % RING][j] = wk[((int64_t)(s0 + s + RING - 1) * NBLK + j) * 64];
 #endif
       }
+      // pin the prefetch HERE: without it the scheduler sinks each load next to its first use
+      // (load-to-use distance 0, full L2 latency exposed on every K-step; seen in the ISA)
+      __builtin_amdgcn_sched_barrier(0);
       f32x4 av[MB];
 #pragma unroll
       for (int i = 0; i < MB; ++i) av[i] = *reinterpret_cast<const f32x4 *>(arow + i * 32 * LDA + s * 8);
@@ -455,7 +466,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (MB * NB >= 4 ? 2 : 1)) sparse_c
 template <int CP, int WM, int WN, int MB, int NB, bool VEC>
 static int launch_v2(const ConvKArgs &ka, int64_t tile_bound, int num_cus, hipStream_t stream) {
   constexpr int THREADS = 64 * WM * WN;
-  constexpr int CKL = CP > 128 ? 128 : CP;
+  constexpr int CKL = conv_phase_width(CP, MB * NB);
   const size_t lds_bytes = (size_t)2 * DGR_TILE_M * (CKL + 4) * sizeof(float) + 4 * DGR_TILE_M * sizeof(int);
   static int per_cu = 0;
   if (per_cu == 0) {
@@ -479,7 +490,7 @@ int dgr_conv_launch(const DgrConvLaunch &a, int num_cus, hipStream_t stream) {
   ConvKArgs ka;
   ka.in = a.in; ka.out = a.out; ka.w = a.w; ka.y = a.y; ka.shift = a.shift; ka.y_ld = a.cout;
   ka.pair_in = a.pair_in; ka.pair_out = a.pair_out; ka.tile_ptr = a.tile_ptr; ka.rule_ptr = a.rule_ptr;
-  ka.n_rows_dev = a.n_rows_dev;
+  ka.n_rows_dev = a.n_rows_dev; ka.tile_desc = a.tile_desc;
   ka.in_ld = a.in_ld; ka.out_ld = a.out_ld; ka.in_relu = a.in_relu;
   ka.cin = a.cin; ka.cin_pad = a.cin_pad; ka.cout = a.cout; ka.K = a.K;
   DGR_REQUIRE(a.cin_pad % 8 == 0 && a.cin_pad >= a.cin && a.cin_pad <= 256, "bad cin_pad %d", a.cin_pad);
@@ -570,6 +581,77 @@ int dgr_reduce_rows(const float *y, int cout, const int32_t *ptr, const int32_t 
       return DGR_EINVAL;
   }
 #undef DGR_RR
+  DGR_LAUNCH_CHECK();
+  return DGR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// conv1 (Cin <= 8 -> 32): output stationary.  FCGF's first layer has 343 offsets, ~74 neighbours per
+// voxel and ONE input channel: as a rule-major GEMM it would write and re-read 260 MB of product rows
+// for 0.13 GFLOP.  Here 32 lanes own one output voxel (one channel each), walk its pairs in
+// ascending-k order (the same order as the reduction pass, bit-compatible) and write the row once.
+// Weights are read in place from the MFMA-tiled layout: W[k][ci][co] sits at
+// ((k * 64 + 32 * (ci / 4) + co) * 4 + ci % 4).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    conv_small_cin_kernel(const float *__restrict__ in, int in_ld, int in_relu, int cin,
+                          const float *__restrict__ w, const float *__restrict__ shift,
+                          const int32_t *__restrict__ out_ptr, const int32_t *__restrict__ out_pos,
+                          const int32_t *__restrict__ pair_in, const uint16_t *__restrict__ pair_k,
+                          const int32_t *n_out_dev, float *__restrict__ out, int out_ld) {
+  const int n = *n_out_dev;
+  const int co = threadIdx.x & 31;
+  for (int64_t o = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5); o < n; o += (int64_t)gridDim.x * 8) {
+    float acc = shift ? shift[co] : 0.f;
+    const int end = out_ptr[o + 1];
+    int j = out_ptr[o];
+    // eight pairs per round: the three dependent index loads (slot -> pair -> input row) of all eight
+    // are in flight together; the additions stay in ascending-k order
+    for (; j + 8 <= end; j += 8) {
+      int pos[8], row[8], kk[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) pos[u] = out_pos[j + u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { row[u] = pair_in[pos[u]]; kk[u] = pair_k[pos[u]]; }
+      float y[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float *wk = w + (int64_t)kk[u] * 256;
+        float t = 0.f;
+        for (int ci = 0; ci < cin; ++ci) {
+          float x = in[(int64_t)row[u] * in_ld + ci];
+          if (in_relu) x = fmaxf(x, 0.f);
+          t = fmaf(x, wk[(32 * (ci >> 2) + co) * 4 + (ci & 3)], t);
+        }
+        y[u] = t;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += y[u];
+    }
+    for (; j < end; ++j) {
+      const int pos = out_pos[j];
+      const int row = pair_in[pos];
+      const float *wk = w + (int64_t)pair_k[pos] * 256;
+      float y = 0.f;
+      for (int ci = 0; ci < cin; ++ci) {
+        float x = in[(int64_t)row * in_ld + ci];
+        if (in_relu) x = fmaxf(x, 0.f);
+        y = fmaf(x, wk[(32 * (ci >> 2) + co) * 4 + (ci & 3)], y);   // same k-ordered fma chain as the MFMA
+      }
+      acc += y;
+    }
+    out[o * out_ld + co] = acc;
+  }
+}
+
+int dgr_conv_small_cin(const float *in, int in_ld, int in_relu, int cin, const float *w_tiled, const float *shift,
+                       const DgrKernelMap &km, const int32_t *n_out_dev, int64_t n_out_cap, float *out, int out_ld,
+                       hipStream_t stream) {
+  DGR_REQUIRE(cin >= 1 && cin <= 8, "small-Cin conv: cin=%d", cin);
+  int64_t blocks = dgr_ceil_div(n_out_cap, 8);
+  if (blocks > 16384) blocks = 16384;
+  conv_small_cin_kernel<<<(int)blocks, 256, 0, stream>>>(in, in_ld, in_relu, cin, w_tiled, shift, km.out_ptr,
+                                                          km.out_pos, km.pair_in, km.pair_k, n_out_dev, out, out_ld);
   DGR_LAUNCH_CHECK();
   return DGR_OK;
 }

@@ -104,12 +104,15 @@ struct DgrKernelMap {
   int K = 0;                    // kernel volume
   int32_t *rule_ptr = nullptr;  // [K+1] exclusive prefix of pairs per offset
   int32_t *tile_ptr = nullptr;  // [K+1] exclusive prefix of DGR_TILE_M-tiles per offset
+  int4 *tile_desc = nullptr;    // [tile_cap] (k, first pair, pair count, 0) of every tile
+  int64_t tile_cap = 0;
   int32_t *pair_in = nullptr;   // [pair_cap]
   int32_t *pair_out = nullptr;  // [pair_cap]
   // output-major CSR over the same pairs (entries of a row in ascending k): the deterministic
   // segmented reduction of the sparse conv walks it.  out_* is keyed by pair_out; in_* (strided
   // maps only) by pair_in, for the transposed convs that use the map with in/out swapped.
   int32_t *out_ptr = nullptr, *out_pos = nullptr;
+  uint16_t *pair_k = nullptr;   // [pair_cap] kernel offset of every pair (for the output-stationary small-Cin conv)
   int32_t *in_ptr = nullptr, *in_pos = nullptr;
   int64_t pair_cap = 0;
   bool built = false;
@@ -149,6 +152,7 @@ struct DgrConvLaunch {
   const float *w;  // MFMA-B-fragment tiled weights of this layer
   int cin, cin_pad, cout, cout_pad, K;
   const int32_t *pair_in, *pair_out, *tile_ptr, *rule_ptr;  // nullptr pairs => identity map
+  const int4 *tile_desc;                                     // per-tile (k, first pair, count)
   const int32_t *n_rows_dev;                                 // identity map: number of rows
   int64_t tile_bound;                                        // host upper bound on the tile count (0 = unknown)
 };
@@ -157,6 +161,10 @@ int dgr_conv_launch(const DgrConvLaunch &a, int num_cus, hipStream_t stream);
 int dgr_reduce_rows(const float *y, int cout, const int32_t *ptr, const int32_t *pos, const int32_t *n_dev,
                     int64_t n_cap, float *out, int out_ld, const float *shift, const float *res, int res_ld,
                     int res_relu, hipStream_t stream);
+// output-stationary conv for Cin <= 8, Cout == 32 (conv1): no product rows, no reduction pass
+int dgr_conv_small_cin(const float *in, int in_ld, int in_relu, int cin, const float *w_tiled, const float *shift,
+                       const DgrKernelMap &km, const int32_t *n_out_dev, int64_t n_out_cap, float *out, int out_ld,
+                       hipStream_t stream);
 int dgr_l2_normalize_rows(const float *in, int in_ld, float *out, int out_ld, int c, int relu,
                           const int32_t *n_dev, int64_t n_cap, hipStream_t stream);
 

@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(KM_THREADS)
               int32_t *overflow, int KW, const uint32_t *__restrict__ mask_out,
               const int32_t *__restrict__ out_ptr, int32_t *__restrict__ out_pos,
               const uint32_t *__restrict__ mask_in, const int32_t *__restrict__ in_ptr,
-              int32_t *__restrict__ in_pos) {
+              int32_t *__restrict__ in_pos, uint16_t *__restrict__ pair_k) {
   __shared__ int wave_cnt[KM_THREADS / 64];
   const int n_out = *n_out_dev;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -171,6 +171,7 @@ __global__ void __launch_bounds__(KM_THREADS)
         if (pos < pair_cap) {
           pair_in[pos] = hit;
           pair_out[pos] = (int32_t)o;
+          pair_k[pos] = (uint16_t)k;
           // CSR slot = row start + number of this row's offsets below k (ascending-k order per row)
           out_pos[out_ptr[o] + mask_rank(mask_out + o * KW, k)] = (int32_t)pos;
           if (mask_in) in_pos[in_ptr[hit] + mask_rank(mask_in + (int64_t)hit * KW, k)] = (int32_t)pos;
@@ -209,6 +210,21 @@ __global__ void __launch_bounds__(1024)
   if (k == K - 1) tile_ptr[K] = s[k];
 }
 
+// one thread per tile: (k, first pair, pair count) so that the conv kernels fetch a tile with ONE
+// 16-byte load instead of a 10-step binary search over tile_ptr on their critical path
+__global__ void tile_desc_kernel(const int32_t *__restrict__ tile_ptr, const int32_t *__restrict__ rule_ptr, int K,
+                                 int4 *__restrict__ desc, int64_t tile_cap) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= tile_cap || t >= tile_ptr[K]) return;
+  int lo = 0, hi = K;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (tile_ptr[mid] <= t) lo = mid; else hi = mid;
+  }
+  const int pstart = rule_ptr[lo] + ((int)t - tile_ptr[lo]) * DGR_TILE_M;
+  desc[t] = make_int4(lo, pstart, min(DGR_TILE_M, rule_ptr[lo + 1] - pstart), 0);
+}
+
 template <int D>
 static int build_kernel_map_t(DgrArena &arena, const DgrCoordMap &in, const DgrCoordMap &out,
                               const DgrHalfBuckets *in_buckets, int ks, int max_pairs_per_row,
@@ -226,8 +242,11 @@ static int build_kernel_map_t(DgrArena &arena, const DgrCoordMap &in, const DgrC
   DGR_ALLOC(km->tile_ptr, arena, int32_t, K + 1);
   DGR_ALLOC(km->pair_in, arena, int32_t, km->pair_cap);
   DGR_ALLOC(km->pair_out, arena, int32_t, km->pair_cap);
+  km->tile_cap = km->pair_cap / DGR_TILE_M + K;
+  DGR_ALLOC(km->tile_desc, arena, int4, km->tile_cap);
   DGR_ALLOC(km->out_ptr, arena, int32_t, n_cap + 1);
   DGR_ALLOC(km->out_pos, arena, int32_t, km->pair_cap);
+  DGR_ALLOC(km->pair_k, arena, uint16_t, km->pair_cap);
   const int64_t n_in_cap = in.n_cap;
   if (need_in_csr) {
     DGR_ALLOC(km->in_ptr, arena, int32_t, n_in_cap + 1);
@@ -278,11 +297,13 @@ static int build_kernel_map_t(DgrArena &arena, const DgrCoordMap &in, const DgrC
   }
   DGR_CHECK(dgr_exclusive_scan_i32(arena, counts, base, (int64_t)K * RB, total, stream));
   kmap_finalize<<<1, 1024, 0, stream>>>(base, total, K, RB, km->rule_ptr, km->tile_ptr);
+  tile_desc_kernel<<<(int)dgr_ceil_div(km->tile_cap, 256), 256, 0, stream>>>(km->tile_ptr, km->rule_ptr, K,
+                                                                            km->tile_desc, km->tile_cap);
   int64_t fill_blocks = dgr_ceil_div((int64_t)K * RB, 16);
   if (fill_blocks > 16384) fill_blocks = 16384;
   kmap_fill<<<(int)fill_blocks, KM_THREADS, 0, stream>>>(out.n_dev, RB, K, n_cap, hits, counts, base, km->pair_in,
                                              km->pair_out, km->pair_cap, overflow, KW, mask_out, km->out_ptr,
-                                             km->out_pos, mask_in, km->in_ptr, km->in_pos);
+                                             km->out_pos, mask_in, km->in_ptr, km->in_pos, km->pair_k);
   DGR_LAUNCH_CHECK();
   arena.rewind(mk);
   km->built = true;

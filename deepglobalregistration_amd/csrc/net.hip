@@ -34,6 +34,8 @@ struct LayerRun {  // bookkeeping of the last forward, for dgr_net_layer_stats /
   const int32_t *n_in = nullptr, *n_out = nullptr;
   int K = 1;
   DgrConvLaunch launch;   // the exact launch of phase 1
+  bool small_cin = false;  // conv1 ran through the output-stationary kernel instead
+  DgrKernelMap km;  // copy (the map set itself lives on the forward's stack)
   bool has_reduce = false;  // phase 2 parameters
   const int32_t *red_ptr = nullptr, *red_pos = nullptr;
   int64_t n_out_cap = 0;
@@ -213,7 +215,7 @@ struct Fwd {
     if (km) {
       a.pair_in = swapped ? km->pair_out : km->pair_in;
       a.pair_out = swapped ? km->pair_in : km->pair_out;
-      a.tile_ptr = km->tile_ptr; a.rule_ptr = km->rule_ptr;
+      a.tile_ptr = km->tile_ptr; a.rule_ptr = km->rule_ptr; a.tile_desc = km->tile_desc;
       a.n_rows_dev = nullptr;
       a.tile_bound = km->pair_cap / DGR_TILE_M + km->K;
       DGR_REQUIRE(km->K == L.K, "layer %s: kernel volume mismatch", L.name.c_str());
@@ -221,6 +223,7 @@ struct Fwd {
     } else {
       DGR_REQUIRE(res == nullptr, "identity conv with residual not supported");
       a.pair_in = a.pair_out = a.tile_ptr = a.rule_ptr = nullptr;
+      a.tile_desc = nullptr;
       a.n_rows_dev = cout_map.n_dev;
       a.tile_bound = dgr_ceil_div(cout_map.n_cap, DGR_TILE_M);
     }
@@ -230,8 +233,13 @@ struct Fwd {
       if (!e0 || !e1) return DGR_EHIP;
       DGR_HIP_CHECK(hipEventRecord(e0, stream));
     }
-    DGR_CHECK(dgr_conv_launch(a, ctx->num_cus, stream));
-    if (km)
+    const bool small_cin = km && !swapped && !res && L.cin <= 8 && L.cout == 32 && L.cin_pad == 8;
+    if (small_cin)
+      DGR_CHECK(dgr_conv_small_cin(in.ptr, in.ld, in.relu, L.cin, L.w, L.shift, *km, cout_map.n_dev, cout_map.n_cap,
+                                   out.ptr, out.ld, stream));
+    else
+      DGR_CHECK(dgr_conv_launch(a, ctx->num_cus, stream));
+    if (km && !small_cin)
       DGR_CHECK(dgr_reduce_rows(ybuf, L.cout, swapped ? km->in_ptr : km->out_ptr, swapped ? km->in_pos : km->out_pos,
                                 cout_map.n_dev, cout_map.n_cap, out.ptr, out.ld, L.shift, res ? res->ptr : nullptr,
                                 res ? res->ld : 0, res ? res->relu : 0, stream));
@@ -242,6 +250,8 @@ struct Fwd {
     LayerRun &r = net->runs[li];
     r.launch = a;
     r.has_reduce = km != nullptr;
+    r.small_cin = small_cin;
+    if (km) r.km = *km;
     if (km) {
       r.red_ptr = swapped ? km->in_ptr : km->out_ptr;
       r.red_pos = swapped ? km->in_pos : km->out_pos;
@@ -481,9 +491,13 @@ extern "C" int dgr_net_rerun_layer(dgr_ctx *ctx, dgr_net *net, int layer, int re
   float tg = 0.f, tr = 0.f;
   for (int i = 0; i < reps + 1; ++i) {  // first iteration = warm-up
     DGR_HIP_CHECK(hipEventRecord(e0, nullptr));
-    DGR_CHECK(dgr_conv_launch(r.launch, ctx->num_cus, nullptr));
+    if (r.small_cin)
+      DGR_CHECK(dgr_conv_small_cin(r.launch.in, r.launch.in_ld, r.launch.in_relu, L.cin, L.w, L.shift, r.km, r.n_out,
+                                   r.n_out_cap, r.launch.out, r.launch.out_ld, nullptr));
+    else
+      DGR_CHECK(dgr_conv_launch(r.launch, ctx->num_cus, nullptr));
     DGR_HIP_CHECK(hipEventRecord(e1, nullptr));
-    if (r.has_reduce)
+    if (r.has_reduce && !r.small_cin)
       DGR_CHECK(dgr_reduce_rows(r.launch.y, L.cout, r.red_ptr, r.red_pos, r.n_out, r.n_out_cap, r.launch.out,
                                 r.launch.out_ld, L.shift, r.res, r.res_ld, r.res_relu, nullptr));
     DGR_HIP_CHECK(hipEventRecord(e2, nullptr));
