@@ -130,10 +130,11 @@ __global__ void mask_count_kernel(const uint32_t *__restrict__ mask, int KW, con
   cnt[r] = c;
 }
 
-// ---- pass 2: persistent blocks walk the (offset, row block) cells in groups of 16; one vector load
-// of the cell counts finds the non-empty ones (a few % of the cells in 6-D), and only those are
-// ranked: cached hits inside the block in row order -> pairs at block_base + rank.  Sorted by
-// (k, out), no atomics, no probing.
+// ---- pass 2: grid = (row blocks, K / 8).  A block owns 256 output rows and 8 consecutive offsets:
+// it reads the 8 cell counts, and for the non-empty cells (a few % in 6-D) ranks the cached hits
+// inside the block (row order) and writes the pairs at cell_base + rank.  Sorted by (k, out), no
+// atomics, no probing; 8x fewer (mostly empty) blocks than one block per cell.
+constexpr int KM_KGROUP = 8;
 __global__ void __launch_bounds__(KM_THREADS)
     kmap_fill(const int32_t *n_out_dev, int RB, int K, int64_t n_cap, const int32_t *__restrict__ hits,
               const int32_t *__restrict__ block_counts, const int32_t *__restrict__ block_base,
@@ -142,44 +143,39 @@ __global__ void __launch_bounds__(KM_THREADS)
               const int32_t *__restrict__ out_ptr, int32_t *__restrict__ out_pos,
               const uint32_t *__restrict__ mask_in, const int32_t *__restrict__ in_ptr,
               int32_t *__restrict__ in_pos, uint16_t *__restrict__ pair_k) {
-  __shared__ int wave_cnt[KM_THREADS / 64];
+  __shared__ int wave_cnt[2][KM_THREADS / 64];
+  const int rb = blockIdx.x;
   const int n_out = *n_out_dev;
+  if (rb * KM_THREADS >= n_out) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t n_cells = (int64_t)K * RB;
-  constexpr int GROUP = 16;  // cells per block round: enough blocks to cover the chip, few serial cells each
-  for (int64_t c0 = (int64_t)blockIdx.x * GROUP; c0 < n_cells; c0 += (int64_t)gridDim.x * GROUP) {
-    // every wave loads the same 64 counts (one coalesced 256-byte load) and keeps the non-empty set
-    const int64_t cl = c0 + lane;
-    const int cnt = (lane < GROUP && cl < n_cells) ? block_counts[cl] : 0;
-    unsigned long long live = __ballot(cnt > 0);
-    while (live) {
-      const int bit = __ffsll((long long)live) - 1;
-      live &= live - 1;
-      const int64_t cell = c0 + bit;
-      const int k = (int)(cell / RB), rb = (int)(cell - (int64_t)k * RB);
-      const int64_t o = (int64_t)rb * KM_THREADS + threadIdx.x;
-      int hit = -1;
-      if (o < n_out) hit = hits[(int64_t)k * n_cap + o];
-      const unsigned long long m = __ballot(hit >= 0);
-      __syncthreads();  // wave_cnt of the previous cell has been consumed
-      if (lane == 0) wave_cnt[wave] = __popcll(m);
-      __syncthreads();
-      if (hit >= 0) {
-        int base = block_base[cell];
-        for (int w = 0; w < wave; ++w) base += wave_cnt[w];
-        const int64_t pos = base + __popcll(m & ((1ull << lane) - 1ull));
-        if (pos < pair_cap) {
-          pair_in[pos] = hit;
-          pair_out[pos] = (int32_t)o;
-          pair_k[pos] = (uint16_t)k;
-          // CSR slot = row start + number of this row's offsets below k (ascending-k order per row)
-          out_pos[out_ptr[o] + mask_rank(mask_out + o * KW, k)] = (int32_t)pos;
-          if (mask_in) in_pos[in_ptr[hit] + mask_rank(mask_in + (int64_t)hit * KW, k)] = (int32_t)pos;
-        } else {
-          *overflow = 2;
-        }
+  const int64_t o = (int64_t)rb * KM_THREADS + threadIdx.x;
+  int parity = 0;
+  for (int kk = 0; kk < KM_KGROUP; ++kk) {
+    const int k = blockIdx.y * KM_KGROUP + kk;
+    if (k >= K) break;
+    const int64_t cell = (int64_t)k * RB + rb;
+    if (block_counts[cell] == 0) continue;      // block-uniform
+    int hit = -1;
+    if (o < n_out) hit = hits[(int64_t)k * n_cap + o];
+    const unsigned long long m = __ballot(hit >= 0);
+    if (lane == 0) wave_cnt[parity][wave] = __popcll(m);
+    __syncthreads();                            // double-buffered counts: one barrier per live cell
+    if (hit >= 0) {
+      int base = block_base[cell];
+      for (int w = 0; w < wave; ++w) base += wave_cnt[parity][w];
+      const int64_t pos = base + __popcll(m & ((1ull << lane) - 1ull));
+      if (pos < pair_cap) {
+        pair_in[pos] = hit;
+        pair_out[pos] = (int32_t)o;
+        pair_k[pos] = (uint16_t)k;
+        // CSR slot = row start + number of this row's offsets below k (ascending-k order per row)
+        out_pos[out_ptr[o] + mask_rank(mask_out + o * KW, k)] = (int32_t)pos;
+        if (mask_in) in_pos[in_ptr[hit] + mask_rank(mask_in + (int64_t)hit * KW, k)] = (int32_t)pos;
+      } else {
+        *overflow = 2;
       }
     }
+    parity ^= 1;
   }
 }
 
@@ -299,9 +295,8 @@ static int build_kernel_map_t(DgrArena &arena, const DgrCoordMap &in, const DgrC
   kmap_finalize<<<1, 1024, 0, stream>>>(base, total, K, RB, km->rule_ptr, km->tile_ptr);
   tile_desc_kernel<<<(int)dgr_ceil_div(km->tile_cap, 256), 256, 0, stream>>>(km->tile_ptr, km->rule_ptr, K,
                                                                             km->tile_desc, km->tile_cap);
-  int64_t fill_blocks = dgr_ceil_div((int64_t)K * RB, 16);
-  if (fill_blocks > 16384) fill_blocks = 16384;
-  kmap_fill<<<(int)fill_blocks, KM_THREADS, 0, stream>>>(out.n_dev, RB, K, n_cap, hits, counts, base, km->pair_in,
+  dim3 fill_grid(RB, (K + KM_KGROUP - 1) / KM_KGROUP);
+  kmap_fill<<<fill_grid, KM_THREADS, 0, stream>>>(out.n_dev, RB, K, n_cap, hits, counts, base, km->pair_in,
                                              km->pair_out, km->pair_cap, overflow, KW, mask_out, km->out_ptr,
                                              km->out_pos, mask_in, km->in_ptr, km->in_pos, km->pair_k);
   DGR_LAUNCH_CHECK();

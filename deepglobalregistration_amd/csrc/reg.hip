@@ -16,7 +16,10 @@
 
 // one wave per SIMD: the 9-parameter update is computed redundantly by every wave, so co-resident
 // waves on a SIMD would only serialise it (measured: 512 threads = 10.4 us / iteration)
-constexpr int REG_THREADS = 256;
+#ifndef DGR_REG_THREADS
+#define DGR_REG_THREADS 256
+#endif
+constexpr int REG_THREADS = DGR_REG_THREADS;
 constexpr int REG_WAVES = REG_THREADS / 64;
 
 struct RegArgs {
