@@ -4,12 +4,15 @@
     python bench.py --gpus N --steps K --warmup W [--pairs-per-step B] [--n-raw 50000]
 
 One "step" = one pass of the hot path (FCGF x2 -> 1-NN -> 6-D inputs -> 6-D inlier net -> gate ->
-weighted Procrustes -> SE(3) refinement; dgr_register_batch) over one batch of B synthetic
-3DMatch-shaped pairs (BASELINE.json configs[1]: 50k raw points per fragment, 5 cm voxels, conv1
-k=7) whose voxelised coordinates are already resident in HBM.  With N > 1 (launched through
-torch.distributed.run, one process per GPU) every rank registers its own B pairs (weak scaling,
-pairs are independent units; no collective on the data path), the weights come from rank 0 by ONE
-RCCL broadcast and the results are gathered on rank 0.
+weighted Procrustes -> SE(3) refinement; dgr_register_batch) over S x B synthetic 3DMatch-shaped
+pairs per GPU (BASELINE.json configs[1]: 50k raw points per fragment, 5 cm voxels, conv1 k=7)
+whose voxelised coordinates are already resident in HBM: S HIP streams, each driven by its own host
+thread with its own library context, each registering its own batch of B pairs (pairs are
+independent units, streams never exchange data; the second and third stream fill the holes the
+small map-building kernels of the first leave on the chip).  With N > 1 (launched through
+torch.distributed.run, one process per GPU) every rank registers its own S x B pairs (weak scaling,
+no collective on the data path), the weights come from rank 0 by ONE RCCL broadcast and the results
+are gathered on rank 0.
 
 Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for the definition of every field.
 """
@@ -101,13 +104,15 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--pairs-per-step', type=int, default=2, help='pairs per rank per step')
+    ap.add_argument('--pairs-per-step', type=int, default=4, help='pairs per stream per step')
     ap.add_argument('--n-raw', type=int, default=50000, help='raw points per fragment')
     ap.add_argument('--voxel', type=float, default=0.05)
     ap.add_argument('--kind', default='indoor', choices=['indoor', 'outdoor'])
     ap.add_argument('--conv1-ks', type=int, default=7)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-refine', action='store_true', help='ablation: stop after weighted Procrustes')
+    ap.add_argument('--streams', type=int, default=3, help='HIP streams per GPU, each driven by its own host '
+                    'thread with its own library context and its own batch of pairs (independent units)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -123,72 +128,124 @@ def main():
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
 
-    from deepglobalregistration_amd import dist as ddist, ops, synth
+    from deepglobalregistration_amd import _lib, dist as ddist, ops, synth
     from deepglobalregistration_amd.core.deep_global_registration import DeepGlobalRegistration
 
     B = args.pairs_per_step
+    S = max(1, args.streams)
     ck = synth.synth_checkpoint(seed=0, voxel_size=args.voxel, feat_conv1_kernel_size=args.conv1_ks) if rank == 0 else None
     ck = ddist.broadcast_checkpoint(ck, src=0, device=device)
     log('checkpoint ready')
-    dgr = DeepGlobalRegistration({'weights': ck, 'clip_weight_thresh': 0.05}, device)
-    dgr.fcgf_model._handle(); dgr.inlier_model._handle()
-    log('weights resident in HBM')
 
-    # this rank's pairs (seeds rank*B .. rank*B+B-1), voxelised once, resident in HBM
-    pairs = [synth.synth_pair(rank * B + i, n_raw=args.n_raw, kind=args.kind) for i in range(B)]
-    x0, c0, x1, c1, off0, off1 = [], [], [], [], [0], [0]
-    t_vox = time.time()
-    for p, (a, b, _) in enumerate(pairs):
-        xa, ca, _ = dgr.preprocess(a, batch_index=p)
-        xb, cb, _ = dgr.preprocess(b, batch_index=p)
-        x0.append(xa); c0.append(ca); x1.append(xb); c1.append(cb)
-        off0.append(off0[-1] + len(xa)); off1.append(off1[-1] + len(xb))
-    torch.cuda.synchronize()
-    t_vox = (time.time() - t_vox) / B
-    C0, X0, C1, X1 = torch.cat(c0), torch.cat(x0), torch.cat(c1), torch.cat(x1)
+    class Worker:
+        """One HIP stream + one library context + one resident batch of B pairs, driven by one host
+        thread.  Pairs are independent units, so streams never exchange data."""
 
-    # harness-only overrides (DESIGN.md "Synthetic workload"): untrained weights give ~0 % correct
-    # matches and a meaningless confidence, so a share of the 1-NN results is replaced by ground-truth
-    # matches AFTER the search ran and the logits by GT-derived ones AFTER the inlier net ran.
-    X0h, X1h = X0.cpu().numpy(), X1.cpu().numpy()
-    ovr = torch.from_numpy(np.concatenate([
-        (lambda g, o: np.where(g >= 0, g + o, -1))(
-            synth.gt_correspondences(X0h[off0[p]:off0[p + 1]], X1h[off1[p]:off1[p + 1]], pairs[p][2], args.voxel,
-                                     seed=p), off1[p]) for p in range(B)])).to(device)
+        def __init__(self, wid):
+            self.wid = wid
+            self.ctx = _lib.new_ctx(device) if S > 1 else None
+            self.stream = torch.cuda.Stream(device) if S > 1 else torch.cuda.current_stream(device)
+            self.result = None
 
-    def step(forced=None):
-        return dgr.register_voxelized(C0, X0, off0, C1, X1, off1, forced_logits=forced,
-                                      skip_refinement=args.no_refine, override_idx1=ovr)
+        def __enter__(self):
+            _lib.use_ctx(self.ctx)
+            self._sctx = torch.cuda.stream(self.stream)
+            self._sctx.__enter__()
+            return self
 
-    log(f'inputs voxelised: N0={off0[-1]} N1={off1[-1]} ({B} pairs)')
-    step()      # untimed: final correspondences for the teacher-forced logits
-    torch.cuda.synchronize()
-    log('first pass done')
-    idx1 = ops.batch_output(device, 'idx1').cpu().numpy()
-    forced = torch.from_numpy(np.concatenate([
-        synth.gt_forced_logits(X0h[off0[p]:off0[p + 1]], X1h[idx1[off0[p]:off0[p + 1]]], pairs[p][2], args.voxel)
-        for p in range(B)])).to(device)
+        def __exit__(self, *exc):
+            self._sctx.__exit__(*exc)
+            _lib.use_ctx(None)
+
+        def prepare(self):
+            with self:
+                self.dgr = DeepGlobalRegistration({'weights': ck, 'clip_weight_thresh': 0.05}, device)
+                dgr = self.dgr
+                dgr.fcgf_model._handle(); dgr.inlier_model._handle()
+                base = (rank * S + self.wid) * B          # this worker's pairs: seeds base .. base+B-1
+                self.pairs = [synth.synth_pair(base + i, n_raw=args.n_raw, kind=args.kind) for i in range(B)]
+                x0, c0, x1, c1, self.off0, self.off1 = [], [], [], [], [0], [0]
+                t0 = time.time()
+                for p, (a, b, _) in enumerate(self.pairs):
+                    xa, ca, _ = dgr.preprocess(a, batch_index=p)
+                    xb, cb, _ = dgr.preprocess(b, batch_index=p)
+                    x0.append(xa); c0.append(ca); x1.append(xb); c1.append(cb)
+                    self.off0.append(self.off0[-1] + len(xa)); self.off1.append(self.off1[-1] + len(xb))
+                torch.cuda.synchronize()
+                self.t_vox = (time.time() - t0) / B
+                self.C0, self.X0, self.C1, self.X1 = torch.cat(c0), torch.cat(x0), torch.cat(c1), torch.cat(x1)
+                off0, off1 = self.off0, self.off1
+                # harness-only overrides (DESIGN.md "Synthetic workload"): untrained weights give ~0 %
+                # correct matches and a meaningless confidence, so a share of the 1-NN results is replaced
+                # by ground-truth matches AFTER the search ran and the logits by GT-derived ones AFTER the
+                # inlier net ran.
+                X0h, X1h = self.X0.cpu().numpy(), self.X1.cpu().numpy()
+                self.ovr = torch.from_numpy(np.concatenate([
+                    (lambda g, o: np.where(g >= 0, g + o, -1))(
+                        synth.gt_correspondences(X0h[off0[p]:off0[p + 1]], X1h[off1[p]:off1[p + 1]], self.pairs[p][2],
+                                                 args.voxel, seed=p), off1[p]) for p in range(B)])).to(device)
+                self.forced = None
+                self.step()                                # untimed: final correspondences for the forced logits
+                torch.cuda.synchronize()
+                self.idx1 = ops.batch_output(device, 'idx1').cpu().numpy()
+                self.forced = torch.from_numpy(np.concatenate([
+                    synth.gt_forced_logits(X0h[off0[p]:off0[p + 1]], X1h[self.idx1[off0[p]:off0[p + 1]]],
+                                           self.pairs[p][2], args.voxel) for p in range(B)])).to(device)
+                for _ in range(args.warmup):
+                    self.step()
+                torch.cuda.synchronize()
+
+        def step(self):
+            return self.dgr.register_voxelized(self.C0, self.X0, self.off0, self.C1, self.X1, self.off1,
+                                               forced_logits=self.forced, skip_refinement=args.no_refine,
+                                               override_idx1=self.ovr)
+
+        def run(self, n):
+            with self:
+                for _ in range(n):
+                    self.result = self.step()
+
+    workers = [Worker(w) for w in range(S)]
+    for w in workers:
+        w.prepare()
+    log(f'{S} stream(s) ready: weights resident, inputs voxelised (N0={workers[0].off0[-1]} N1={workers[0].off1[-1]} '
+        f'per batch of {B}), warm-up done')
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(forced)
+    import threading
     barrier()
-    log('warmup done')
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        T, status, stats = step(forced)
+    if S == 1:
+        workers[0].run(args.steps)
+    else:
+        threads = [threading.Thread(target=w.run, args=(args.steps,)) for w in workers]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    log(f'timed region done: {elapsed / args.steps * 1e3:.1f} ms/step')
+    log(f'timed region done: {elapsed / args.steps * 1e3:.1f} ms/step ({S * B} pairs/step/GPU)')
+    T = np.concatenate([w.result[0] for w in workers]); status = np.concatenate([w.result[1] for w in workers])
+    stats = np.concatenate([w.result[2] for w in workers])
     gathered = ddist.gather_results(T, status, stats, dst=0, device=device)
+    w0 = workers[0]
+    dgr, pairs, off0, off1, C0, X0, C1, X1, idx1 = w0.dgr, w0.pairs, w0.off0, w0.off1, w0.C0, w0.X0, w0.C1, w0.X1, w0.idx1
+    t_vox = w0.t_vox
+    all_pairs = [p for w in workers for p in w.pairs]
+
+    def step(forced=None):
+        return w0.step()
+    forced = w0.forced
+    _lib.use_ctx(w0.ctx)
 
     # ---- profiled re-run of the same K steps: HIP events around every sparse-conv launch --------
     ops.set_profiling(device, True)
@@ -220,23 +277,24 @@ def main():
         achieved = flop / (conv_ms * 1e-3) / 1e12
         T_all, status_all, stats_all = gathered
         te, re = [], []
-        for p in range(B):
+        for p in range(S * B):
             if status_all[p] == 0:
-                Tg = pairs[p][2]
+                Tg = all_pairs[p][2]
                 te.append(float(np.linalg.norm(T_all[p][:3, 3] - Tg[:3, 3])))
                 c = (np.trace(T_all[p][:3, :3].T @ Tg[:3, :3]) - 1) / 2
                 re.append(float(np.degrees(np.arccos(np.clip(c, -1, 1)))))
         ms_per_step = elapsed / args.steps * 1e3
         out = {
             'metric': 'pair registrations/sec (FCGF x2 + 1-NN + 6-D inlier net + gate + weighted Procrustes + SE(3) refinement)',
-            'value': world * B * args.steps / elapsed, 'unit': 'pairs/s', 'n_gpus': world,
+            'value': world * S * B * args.steps / elapsed, 'unit': 'pairs/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic 3DMatch-shaped pairs, seeded synthetic weights, teacher-forced matches (20% GT) and inlier logits',
-            'config': {'workload': f'{B} pairs/step/GPU, {args.n_raw} raw pts/fragment, {args.kind}, voxel {args.voxel}, '
-                                   f'conv1 k={args.conv1_ks} (BASELINE configs[1])',
+            'config': {'workload': f'{S * B} pairs/step/GPU ({S} stream(s) x {B}), {args.n_raw} raw pts/fragment, '
+                                   f'{args.kind}, voxel {args.voxel}, conv1 k={args.conv1_ks} (BASELINE configs[1])',
+                       'streams_per_gpu': S,
                        'voxels_per_pair': [int(off0[-1] / B), int(off1[-1] / B)],
-                       'pairs_per_step_per_gpu': B, 'refinement': not args.no_refine,
+                       'pairs_per_step_per_gpu': S * B, 'refinement': not args.no_refine,
                        'parallelism': f'pair-sharded x{world}, no data-path collective'},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,

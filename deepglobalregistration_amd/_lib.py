@@ -7,6 +7,7 @@ NEEDED entry by SONAME).
 """
 import ctypes as C
 import os
+import threading
 
 import torch  # noqa: F401  (must be loaded before libdgr_hip.so, see module docstring)
 
@@ -112,10 +113,29 @@ def check(rc):
 # one context per device
 # ----------------------------------------------------------------------------
 _ctxs = {}
+_tls = threading.local()   # optional per-thread context (one context per stream / host thread)
+
+
+def new_ctx(device):
+    """A fresh library context on `device` (own workspace).  A context is not thread-safe: a host
+    thread that drives its own HIP stream installs its own with `use_ctx`."""
+    lib = load()
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    h = vp()
+    check(lib.dgr_ctx_create(idx, C.byref(h)))
+    return h
+
+
+def use_ctx(handle):
+    """Install `handle` as the calling thread's context (None = back to the per-device default)."""
+    _tls.ctx = handle
 
 
 def get_ctx(device=None):
     lib = load()
+    if getattr(_tls, 'ctx', None) is not None:
+        return _tls.ctx
     if not torch.cuda.is_available():
         raise RuntimeError('deepglobalregistration_amd needs a ROCm GPU (torch.cuda.is_available() is '
                            'False); there is no CPU fallback')
