@@ -283,6 +283,13 @@ def main():
                 te.append(float(np.linalg.norm(T_all[p][:3, 3] - Tg[:3, 3])))
                 c = (np.trace(T_all[p][:3, :3].T @ Tg[:3, :3]) - 1) / 2
                 re.append(float(np.degrees(np.arccos(np.clip(c, -1, 1)))))
+        # HBM traffic of the conv kernels from PMC counters (FETCH_SIZE x 2 + WRITE_SIZE, see
+        # profiles/r01_conv_hbm_traffic.json): collected in separate rocprofv3 --pmc passes on the same
+        # per-stream workload (4 pairs per batch); not measurable from inside this process
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'r01_conv_hbm_traffic.json')
+        if os.path.exists(tpath) and B == 4 and args.n_raw == 50000 and args.conv1_ks == 7:
+            traffic = json.load(open(tpath))['per_conv_launch_bytes']['total']
         ms_per_step = elapsed / args.steps * 1e3
         out = {
             'metric': 'pair registrations/sec (FCGF x2 + 1-NN + 6-D inlier net + gate + weighted Procrustes + SE(3) refinement)',
@@ -297,7 +304,9 @@ def main():
                        'pairs_per_step_per_gpu': S * B, 'refinement': not args.no_refine,
                        'parallelism': f'pair-sharded x{world}, no data-path collective'},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                         'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
+                         'traffic_unit': 'HBM bytes per conv launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE)',
+                         'algorithmic_bytes_per_launch': byts / n_launch,
                          'kernel': 'sparse_conv_mfma', 'launches_per_step': n_launch,
                          'avg_launch_us': conv_ms * 1e3 / n_launch, 'gflop_per_step': flop / 1e9,
                          'compulsory_gbytes_per_step': byts / 1e9,
