@@ -24,6 +24,7 @@
 #include <map>
 
 #include "dgr_internal.h"
+#include "hash.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -652,6 +653,99 @@ int dgr_conv_small_cin(const float *in, int in_ld, int in_relu, int cin, const f
   if (blocks > 16384) blocks = 16384;
   conv_small_cin_kernel<<<(int)blocks, 256, 0, stream>>>(in, in_ld, in_relu, cin, w_tiled, shift, km.out_ptr,
                                                           km.out_pos, km.pair_in, km.pair_k, n_out_dev, out, out_ld);
+  DGR_LAUNCH_CHECK();
+  return DGR_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// conv1 of the FCGF net fused with its neighbour search (3-D, ks^3 = 343 offsets for 3DMatch, Cin <= 8
+// -> 32): the ks^3 kernel map is used by this ONE layer, so building it (343 N probes, a dense hit
+// table, ranking, CSR) only to gather ~74 single-channel neighbours per voxel is pure overhead.  Here
+// a wave owns one output voxel at a time: its 64 lanes probe 64 offsets at once; the hits are then
+// replayed in ascending-k order (ballot + readlane) with lane = output channel accumulating
+// x[hit] * W[k][ci][co] -- the same k-ordered sum as the map-based path, bit for bit.
+// ------------------------------------------------------------------------------------------
+template <bool W_IN_LDS>
+__global__ void __launch_bounds__(256)
+    conv1_probe_kernel(const int32_t *__restrict__ coords, const int32_t *n_dev, const int32_t *__restrict__ table,
+                       uint32_t mask, int ks, const float *__restrict__ in, int in_ld, int cin,
+                       const float *__restrict__ w, const float *__restrict__ shift, float *__restrict__ out,
+                       int out_ld, int32_t *pair_count) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];   // [K][cin][32] compact copy of the weights
+  const int n = *n_dev;
+  const int lane = threadIdx.x & 63;
+  const int co = lane & 31;
+  const int K = ks * ks * ks, half = ks >> 1;
+  if (W_IN_LDS) {
+    for (int e = threadIdx.x; e < K * cin * 32; e += blockDim.x) {
+      const int c = e & 31, ci = (e >> 5) % cin, k = e / (32 * cin);
+      wl[e] = w[(int64_t)k * 256 + (32 * (ci >> 2) + c) * 4 + (ci & 3)];
+    }
+    __syncthreads();
+  }
+  const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  int pairs = 0;
+  for (int64_t o = wave_id; o < n; o += n_waves) {
+    const int32_t b = coords[o * 4], x = coords[o * 4 + 1], y = coords[o * 4 + 2], z = coords[o * 4 + 3];
+    float acc = shift ? shift[co] : 0.f;
+    for (int k0 = 0; k0 < K; k0 += 64) {
+      const int k = k0 + lane;
+      int hit = -1;
+      if (k < K) {
+        // offset enumeration: first spatial dimension fastest (same convention as kmap.hip: offset_of)
+        int32_t q[4] = {b, x + (k % ks) - half, y + ((k / ks) % ks) - half, z + (k / (ks * ks)) - half};
+        hit = dgr_lookup<4>(table, mask, coords, q);
+      }
+      // every lane fetches the input channels of ITS hit now (lane parallel); the serial replay below
+      // then only moves registers (readlane) and reads weights
+      // (unconditional clamped loads: a per-lane guard would make the compiler branch and wait per load)
+      float xv[8];
+      const int64_t hrow = (int64_t)max(hit, 0) * in_ld;
+#pragma unroll
+      for (int ci = 0; ci < 8; ++ci) {
+        xv[ci] = 0.f;
+        if (ci < cin) xv[ci] = in[hrow + ci];   // cin is wave-uniform
+      }
+      unsigned long long live = __ballot(hit >= 0);
+      pairs += __popcll(live);
+      while (live) {
+        const int src = __ffsll((long long)live) - 1;
+        live &= live - 1;
+        float t = 0.f;
+#pragma unroll
+        for (int ci = 0; ci < 8; ++ci) {
+          if (ci < cin) {
+            const float xs = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xv[ci]), src));
+            const float wv = W_IN_LDS ? wl[((k0 + src) * cin + ci) * 32 + co]
+                                      : w[(int64_t)(k0 + src) * 256 + (32 * (ci >> 2) + co) * 4 + (ci & 3)];
+            t = fmaf(xs, wv, t);   // same k-ordered fma chain as the MFMA path
+          }
+        }
+        acc += t;
+      }
+    }
+    if (lane < 32) out[o * out_ld + co] = acc;
+  }
+  if (lane == 0 && pair_count) atomicAdd(pair_count, pairs);
+}
+
+int dgr_conv1_probe(const DgrCoordMap &cm, int ks, const float *in, int in_ld, int cin, const float *w_tiled,
+                    const float *shift, float *out, int out_ld, int32_t *pair_count, hipStream_t stream) {
+  DGR_REQUIRE(cin >= 1 && cin <= 8 && ks % 2 == 1, "conv1 probe: cin=%d ks=%d", cin, ks);
+  if (pair_count) DGR_HIP_CHECK(hipMemsetAsync(pair_count, 0, sizeof(int32_t), stream));
+  const size_t wbytes = (size_t)ks * ks * ks * cin * 32 * sizeof(float);
+  static const bool lds_w = getenv("DGR_CONV1_LDS") != nullptr;  // measured slower than L1-cached global reads
+  if (lds_w && wbytes <= 64 * 1024) {
+    int64_t blocks = 768;      // 3 per CU (44 KB of LDS each): copy the weights once, then walk many voxels
+    conv1_probe_kernel<true><<<(int)blocks, 256, wbytes, stream>>>(cm.coords, cm.n_dev, cm.table, cm.table_mask, ks, in,
+                                                                   in_ld, cin, w_tiled, shift, out, out_ld, pair_count);
+  } else {
+    int64_t blocks = dgr_ceil_div(cm.n_cap, 4);
+    if (blocks > 16384) blocks = 16384;
+    conv1_probe_kernel<false><<<(int)blocks, 256, 0, stream>>>(cm.coords, cm.n_dev, cm.table, cm.table_mask, ks, in, in_ld,
+                                                               cin, w_tiled, shift, out, out_ld, pair_count);
+  }
   DGR_LAUNCH_CHECK();
   return DGR_OK;
 }

@@ -310,7 +310,7 @@ int dgr_build_coord_maps(DgrArena &arena, const int32_t *coords, int64_t N, DgrM
 int dgr_build_half_buckets(DgrArena &arena, const DgrCoordMap &cm, DgrHalfBuckets *hb, hipStream_t stream);
 
 int dgr_build_maps(DgrArena &arena, const int32_t *coords, int64_t N, int D, int conv1_ks,
-                   DgrMapSet *ms, hipStream_t stream) {
+                   DgrMapSet *ms, hipStream_t stream, bool skip_conv1_map) {
   DGR_REQUIRE(D == 3 || D == 6, "D=%d not supported (the DGR path uses D=3 and D=6)", D);
   DGR_REQUIRE(conv1_ks % 2 == 1 && conv1_ks >= 1, "conv1 kernel size must be odd");
   DGR_REQUIRE(N > 0 && N < (1ll << 30), "N=%lld out of range", (long long)N);
@@ -338,7 +338,7 @@ int dgr_build_maps(DgrArena &arena, const int32_t *coords, int64_t N, int D, int
   for (int l = 0; l < 4; ++l) DGR_CHECK(build(ms->cm[l], ms->cm[l], &ms->hb[l], 3, false, &ms->same[l]));
   if (conv1_ks == 3)
     ms->conv1 = ms->same[0];
-  else
+  else if (!skip_conv1_map)
     DGR_CHECK(build(ms->cm[0], ms->cm[0], nullptr, conv1_ks, false, &ms->conv1));
   // strided maps are also used swapped by the transposed convs: build the in-major CSR too
   for (int l = 0; l < 3; ++l) DGR_CHECK(build(ms->cm[l], ms->cm[l + 1], &ms->hb[l], 3, true, &ms->down[l]));

@@ -35,6 +35,7 @@ struct LayerRun {  // bookkeeping of the last forward, for dgr_net_layer_stats /
   int K = 1;
   DgrConvLaunch launch;   // the exact launch of phase 1
   bool small_cin = false;  // conv1 ran through the output-stationary kernel instead
+  const int32_t *fused_pairs = nullptr;  // conv1 fused with its neighbour search: device pair counter
   DgrKernelMap km;  // copy (the map set itself lives on the forward's stack)
   bool has_reduce = false;  // phase 2 parameters
   const int32_t *red_ptr = nullptr, *red_pos = nullptr;
@@ -275,7 +276,9 @@ int dgr_resunet_forward_impl(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, 
     DGR_HIP_CHECK(hipEventRecord(m0, stream));
   }
   f.ms.overflow = ctx->flag_dev;
-  DGR_CHECK(dgr_build_maps(A, coords, N, net->D, net->conv1_ks, &f.ms, stream));
+  // FCGF conv1 (ks^3 offsets, <= 8 input channels) is fused with its neighbour search: no map for it
+  const bool conv1_fused = net->D == 3 && net->conv1_ks != 3 && net->cin <= 8;
+  DGR_CHECK(dgr_build_maps(A, coords, N, net->D, net->conv1_ks, &f.ms, stream, conv1_fused));
   if (f.prof) {
     DGR_HIP_CHECK(hipEventRecord(m1, stream));
     (net->D == 3 ? ctx->map3_spans : ctx->map6_spans).push_back({m0, m1});
@@ -318,7 +321,29 @@ int dgr_resunet_forward_impl(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, 
 
   int li = 0;
   // encoder
-  DGR_CHECK(f.conv(li++, X, &ms.conv1, false, 0, 0, T1, nullptr));     // conv1 + norm1
+  if (conv1_fused) {                                                   // conv1 + norm1
+    const DgrLayer &L0 = net->layers[0];
+    int32_t *pc;
+    DGR_ALLOC(pc, A, int32_t, 1);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (f.prof) {
+      e0 = ctx->events.next(); e1 = ctx->events.next();
+      DGR_HIP_CHECK(hipEventRecord(e0, stream));
+    }
+    DGR_CHECK(dgr_conv1_probe(ms.cm[0], net->conv1_ks, feats, net->cin, net->cin, L0.w, L0.shift, t1, 32, pc, stream));
+    if (f.prof) {
+      DGR_HIP_CHECK(hipEventRecord(e1, stream));
+      ctx->conv_spans.push_back({e0, e1});
+    }
+    LayerRun &r0 = net->runs[0];
+    r0 = LayerRun();
+    r0.n_in = r0.n_out = ms.cm[0].n_dev;
+    r0.K = L0.K;
+    r0.fused_pairs = pc;
+    li++;
+  } else {
+    DGR_CHECK(f.conv(li++, X, &ms.conv1, false, 0, 0, T1, nullptr));
+  }
   DGR_CHECK(f.conv(li++, T1, &ms.same[0], false, 0, 0, Y1, nullptr));  // block1
   DGR_CHECK(f.conv(li++, Y1, &ms.same[0], false, 0, 0, S1, &T1));
   DGR_CHECK(f.conv(li++, S1, &ms.down[0], false, 0, 1, T2, nullptr));  // conv2 (stride 2) + norm2
@@ -465,7 +490,12 @@ extern "C" int dgr_net_layer_stats(dgr_ctx *ctx, dgr_net *net, int layer, int64_
   DGR_HIP_CHECK(hipMemcpy(&n_in, r.n_in, sizeof(int32_t), hipMemcpyDeviceToHost));
   DGR_HIP_CHECK(hipMemcpy(&n_out, r.n_out, sizeof(int32_t), hipMemcpyDeviceToHost));
   int64_t P = n_out, kne = 1;
-  if (r.rule_ptr) {
+  if (r.fused_pairs) {
+    int32_t pc = 0;
+    DGR_HIP_CHECK(hipMemcpy(&pc, r.fused_pairs, sizeof(int32_t), hipMemcpyDeviceToHost));
+    P = pc;
+    kne = r.K;
+  } else if (r.rule_ptr) {
     std::vector<int32_t> rp(r.K + 1);
     DGR_HIP_CHECK(hipMemcpy(rp.data(), r.rule_ptr, (size_t)(r.K + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
     P = rp[r.K];
@@ -485,6 +515,7 @@ extern "C" int dgr_net_rerun_layer(dgr_ctx *ctx, dgr_net *net, int layer, int re
   DGR_REQUIRE(layer >= 0 && layer < (int)net->layers.size(), "layer %d out of range", layer);
   const LayerRun &r = net->runs[layer];
   DGR_REQUIRE(r.n_in && r.n_out, "run a forward first");
+  DGR_REQUIRE(!r.fused_pairs, "layer %d ran fused with its neighbour search; not re-runnable", layer);
   const DgrLayer &L = net->layers[layer];
   hipEvent_t e0, e1, e2;
   DGR_HIP_CHECK(hipEventCreate(&e0)); DGR_HIP_CHECK(hipEventCreate(&e1)); DGR_HIP_CHECK(hipEventCreate(&e2));

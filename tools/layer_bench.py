@@ -26,7 +26,11 @@ for name, net, args in (('6-D', dgr.inlier_model._handle(), (c6, f6)), ('3-D', d
     for li, s in enumerate(st):
         if layers is not None and li not in layers:
             continue
-        g, r = net.rerun_layer(li, 5)
+        try:
+            g, r = net.rerun_layer(li, 5)
+        except ValueError:   # conv1 fused with its neighbour search: not re-runnable in isolation
+            print(f"{li:2d} {s['pairs']:8d} (fused with the neighbour search)")
+            continue
         fl = 2.0 * s['pairs'] * s['cin'] * s['cout']
         gb = 4.0 * s['pairs'] * s['cin']
         yb = 4.0 * s['pairs'] * s['cout']
