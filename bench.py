@@ -99,6 +99,14 @@ def log(msg):
         print(f'[bench +{time.time() - _T0:6.1f}s] {msg}', file=sys.stderr, flush=True)
 
 
+def cfg_label(args):
+    """Which BASELINE.json config the chosen flags correspond to (only the default is the headline)."""
+    key = (args.kind, args.n_raw, args.voxel, args.conv1_ks)
+    return {('indoor', 50000, 0.05, 7): 'BASELINE configs[1]',
+            ('outdoor', 120000, 0.3, 5): 'BASELINE configs[2]',
+            ('indoor', 200000, 0.025, 7): 'BASELINE configs[4]'}.get(key, 'non-BASELINE configuration')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -298,7 +306,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic 3DMatch-shaped pairs, seeded synthetic weights, teacher-forced matches (20% GT) and inlier logits',
             'config': {'workload': f'{S * B} pairs/step/GPU ({S} stream(s) x {B}), {args.n_raw} raw pts/fragment, '
-                                   f'{args.kind}, voxel {args.voxel}, conv1 k={args.conv1_ks} (BASELINE configs[1])',
+                                   f'{args.kind}, voxel {args.voxel}, conv1 k={args.conv1_ks} ({cfg_label(args)})',
                        'streams_per_gpu': S,
                        'voxels_per_pair': [int(off0[-1] / B), int(off1[-1] / B)],
                        'pairs_per_step_per_gpu': S * B, 'refinement': not args.no_refine,
