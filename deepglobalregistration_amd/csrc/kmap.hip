@@ -75,18 +75,73 @@ __global__ void __launch_bounds__(KM_THREADS)
   }
 }
 
-// ---- pass 1, D = 6 pruned: one thread per (output row, first-half offset).  A 6-D neighbour
-// (ca + da, cb + db) can only exist among the rows whose first half equals ca + da: look that bucket
-// up once (27 lookups per row instead of 729 probes) and test the second half of its rows.  hits[]
-// is pre-set to -1 and block_counts to 0 by the caller.
+__device__ __forceinline__ int mask_rank(const uint32_t *__restrict__ m, int k) {
+  int r = 0;
+  const int w = k >> 5;
+  for (int i = 0; i < w; ++i) r += __popc(m[i]);
+  return r + __popc(m[w] & ((1u << (k & 31)) - 1u));
+}
+
+__global__ void mask_count_kernel(const uint32_t *__restrict__ mask, int KW, const int32_t *n_dev, int64_t n_cap,
+                                  int32_t *__restrict__ cnt) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_cap) return;
+  int c = 0;
+  if (r < *n_dev)
+    for (int i = 0; i < KW; ++i) c += __popc(mask[r * KW + i]);
+  cnt[r] = c;
+}
+
+// =========================== D = 6: bit-matrix pipeline =====================================
+// A 6-D map has 729 offsets but only 2..45 neighbours per row (0.3..6 % density), so nothing of
+// size [K, N] is ever materialised except ONE BIT per (row, offset):
+//   bits     search (pruned or generic) sets mask_out[o][k] (and mask_in[i][k] for maps that are
+//            also used swapped).  Same-stride maps are symmetric -- (o, k) -> i  <=>  (i, K-1-k) -> o
+//            -- so only offsets below the centre are searched and every hit sets both bits.
+//   colmask  transposes the bit matrix per 64-row group (one ballot per offset) and counts the
+//            pairs of every (offset, 256-row block) cell -> exclusive scan = cell bases.
+//   place    one thread per non-zero mask word: re-probes the (few) set offsets, ranks each pair
+//            inside its row (CSR slot) and inside its cell (rule-major position) with popcounts.
+// Result identical to the generic path: pairs sorted by (k, out), CSR slots in ascending k.
+
+// generic search, bits only: grid = (row blocks, offsets to probe)
+template <int D>
 __global__ void __launch_bounds__(KM_THREADS)
-    kmap_search_pruned6(const int32_t *__restrict__ out_coords, const int32_t *n_out_dev,
-                        const int32_t *__restrict__ in_coords, DgrHalfBuckets hb, int ts_in, int RB,
-                        int64_t n_cap, int32_t *__restrict__ hits, int32_t *block_counts, int KW,
-                        uint32_t *mask_out, uint32_t *mask_in) {
+    kmap_bits(const int32_t *__restrict__ out_coords, const int32_t *n_out_dev,
+              const int32_t *__restrict__ in_coords, const int32_t *__restrict__ in_table, uint32_t in_mask,
+              int ks, int ts_in, int K, int KW, int symmetric, uint32_t *mask_out, uint32_t *mask_in) {
+  const int k = blockIdx.y;
+  const int64_t o = (int64_t)blockIdx.x * KM_THREADS + threadIdx.x;
+  if (o >= *n_out_dev) return;
+  if (symmetric && k == 0) {  // the centre offset always maps a row onto itself
+    const int c = K >> 1;
+    atomicOr(&mask_out[o * KW + (c >> 5)], 1u << (c & 31));
+  }
+  int32_t delta[D];
+  offset_of<D>(k, ks, ts_in, delta);
+  const int hit = probe<D>(out_coords, o, delta, in_coords, in_table, in_mask);
+  if (hit < 0) return;
+  atomicOr(&mask_out[o * KW + (k >> 5)], 1u << (k & 31));
+  if (symmetric) {
+    const int km = K - 1 - k;
+    atomicOr(&mask_out[(int64_t)hit * KW + (km >> 5)], 1u << (km & 31));
+  } else if (mask_in) {
+    atomicOr(&mask_in[(int64_t)hit * KW + (k >> 5)], 1u << (k & 31));
+  }
+}
+
+// pruned search, bits only: one thread per (output row, first-half offset).  A 6-D neighbour
+// (ca + da, cb + db) can only exist among the rows whose first half equals ca + da: look that bucket
+// up once (27 -- symmetric: 14 -- lookups per row instead of 729 probes) and test the second half
+// of its rows.
+__global__ void __launch_bounds__(KM_THREADS)
+    kmap_bits_pruned6(const int32_t *__restrict__ out_coords, const int32_t *n_out_dev,
+                      const int32_t *__restrict__ in_coords, DgrHalfBuckets hb, int ts_in, int KW,
+                      int symmetric, uint32_t *mask_out, uint32_t *mask_in) {
+  const int NJ = symmetric ? 14 : 27;
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t o = t / 27;
-  const int ja = (int)(t - o * 27);
+  const int64_t o = t / NJ;
+  const int ja = (int)(t - o * NJ);
   if (o >= *n_out_dev) return;
   const int32_t *co = out_coords + o * 7;
   int32_t q[4];
@@ -105,29 +160,108 @@ __global__ void __launch_bounds__(KM_THREADS)
     // every component must be -ts, 0 or +ts (all coordinates of a level are multiples of ts)
     if (abs(d4) <= ts_in && abs(d5) <= ts_in && abs(d6) <= ts_in) {
       const int k = ja + 27 * ((d4 / ts_in + 1) + 3 * (d5 / ts_in + 1) + 9 * (d6 / ts_in + 1));
-      hits[(int64_t)k * n_cap + o] = r;
-      atomicAdd(&block_counts[(int64_t)k * RB + (int)(o / KM_THREADS)], 1);
+      if (symmetric && ja == 13 && k > 364) continue;  // ja == 13 mirrors onto itself: upper half found from the other row
       atomicOr(&mask_out[o * KW + (k >> 5)], 1u << (k & 31));
-      if (mask_in) atomicOr(&mask_in[(int64_t)r * KW + (k >> 5)], 1u << (k & 31));
+      if (symmetric) {
+        const int km = 728 - k;
+        if (km != k) atomicOr(&mask_out[(int64_t)r * KW + (km >> 5)], 1u << (km & 31));
+      } else if (mask_in) {
+        atomicOr(&mask_in[(int64_t)r * KW + (k >> 5)], 1u << (k & 31));
+      }
     }
   }
 }
 
-__device__ __forceinline__ int mask_rank(const uint32_t *__restrict__ m, int k) {
-  int r = 0;
-  const int w = k >> 5;
-  for (int i = 0; i < w; ++i) r += __popc(m[i]);
-  return r + __popc(m[w] & ((1u << (k & 31)) - 1u));
+// transposed bit matrix: colmask[g * K + k] = rows of 64-row group g that have offset k (one
+// ballot), colsub[g * K + k] = pairs of offset k in the earlier groups of the same 256-row block,
+// counts[k * RB + rb] = pairs of the (offset, block) cell
+constexpr int KM_KMAX = 736;
+__global__ void __launch_bounds__(KM_THREADS)
+    kmap_colmask(const uint32_t *__restrict__ mask_out, const int32_t *n_out_dev, int K, int KW, int RB,
+                 unsigned long long *__restrict__ colmask, uint8_t *__restrict__ colsub,
+                 int32_t *__restrict__ counts) {
+  __shared__ unsigned long long bal[KM_THREADS / 64][KM_KMAX];
+  const int rb = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n_out = *n_out_dev;
+  const int64_t o = (int64_t)rb * KM_THREADS + threadIdx.x;
+  for (int w = 0; w < KW; ++w) {
+    const uint32_t word = (o < n_out) ? mask_out[o * KW + w] : 0u;
+    unsigned long long mine = 0;
+#pragma unroll
+    for (int b = 0; b < 32; ++b) {
+      const unsigned long long m = __ballot((word >> b) & 1u);
+      if (lane == b) mine = m;
+    }
+    if (lane < 32 && 32 * w + lane < KM_KMAX) bal[wave][32 * w + lane] = mine;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += KM_THREADS) {
+    int run = 0;
+#pragma unroll
+    for (int g = 0; g < KM_THREADS / 64; ++g) {
+      const unsigned long long m = bal[g][k];
+      const int64_t cell = ((int64_t)rb * (KM_THREADS / 64) + g) * K + k;
+      colmask[cell] = m;
+      colsub[cell] = (uint8_t)run;
+      run += __popcll(m);
+    }
+    counts[(int64_t)k * RB + rb] = run;
+  }
 }
 
-__global__ void mask_count_kernel(const uint32_t *__restrict__ mask, int KW, const int32_t *n_dev, int64_t n_cap,
-                                  int32_t *__restrict__ cnt) {
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= n_cap) return;
-  int c = 0;
-  if (r < *n_dev)
-    for (int i = 0; i < KW; ++i) c += __popc(mask[r * KW + i]);
-  cnt[r] = c;
+// one thread per (row, mask word): places the pairs of the set offsets
+__global__ void __launch_bounds__(KM_THREADS)
+    kmap_place6(const int32_t *__restrict__ out_coords, const int32_t *n_out_dev,
+                const int32_t *__restrict__ in_coords, const int32_t *__restrict__ in_table, uint32_t in_mask,
+                int ts_in, int K, int KW, int RB, const uint32_t *__restrict__ mask_out,
+                const int32_t *__restrict__ out_ptr, const unsigned long long *__restrict__ colmask,
+                const uint8_t *__restrict__ colsub, const int32_t *__restrict__ base,
+                int32_t *__restrict__ pair_in, int32_t *__restrict__ pair_out, uint16_t *__restrict__ pair_k,
+                int32_t *__restrict__ out_pos, int64_t pair_cap, int32_t *overflow,
+                const uint32_t *__restrict__ mask_in, const int32_t *__restrict__ in_ptr,
+                int32_t *__restrict__ in_pos) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t o = t / KW;
+  const int w = (int)(t - o * KW);
+  if (o >= *n_out_dev) return;
+  const uint32_t *mrow = mask_out + o * KW;
+  uint32_t m = mrow[w];
+  if (m == 0u) return;
+  int64_t slot = out_ptr[o];
+  for (int i = 0; i < w; ++i) slot += __popc(mrow[i]);
+  int32_t co[7];
+#pragma unroll
+  for (int d = 0; d < 7; ++d) co[d] = out_coords[o * 7 + d];
+  const int64_t g = o >> 6;
+  const int rb = (int)(o >> 8);
+  const unsigned long long below = (1ull << (o & 63)) - 1ull;
+  while (m) {
+    const int b = __ffs(m) - 1;
+    m &= m - 1u;
+    const int k = 32 * w + b;
+    int32_t q[7];
+    q[0] = co[0];
+    int kk = k;
+#pragma unroll
+    for (int d = 0; d < 6; ++d) {
+      q[1 + d] = co[1 + d] + ((kk % 3) - 1) * ts_in;
+      kk /= 3;
+    }
+    const int in = dgr_lookup<7>(in_table, in_mask, in_coords, q);
+    const int64_t cell = g * K + k;
+    const int64_t pos = (int64_t)base[(int64_t)k * RB + rb] + colsub[cell] + __popcll(colmask[cell] & below);
+    if (pos < pair_cap && slot < pair_cap && in >= 0) {
+      pair_in[pos] = in;
+      pair_out[pos] = (int32_t)o;
+      pair_k[pos] = (uint16_t)k;
+      out_pos[slot] = (int32_t)pos;
+      if (mask_in) in_pos[in_ptr[in] + mask_rank(mask_in + (int64_t)in * KW, k)] = (int32_t)pos;
+    } else {
+      *overflow = 2;
+    }
+    ++slot;
+  }
 }
 
 // ---- pass 2: grid = (row blocks, K / 8).  A block owns 256 output rows and 8 consecutive offsets:
@@ -249,13 +383,13 @@ static int build_kernel_map_t(DgrArena &arena, const DgrCoordMap &in, const DgrC
     DGR_ALLOC(km->in_pos, arena, int32_t, km->pair_cap);
   }
   const int KW = (K + 31) / 32;
-  // transient: dense hit cache [K, n_cap] + per-(offset, block) counts; released after pass 2
+  // transients (released after the last pass): per-(offset, block) counts, row bitmasks and either the
+  // dense hit cache [K, n_cap] (D = 3) or the transposed bit matrix (D = 6)
   DgrArena::Mark mk = arena.mark();
-  int32_t *counts, *base, *total, *hits;
+  int32_t *counts, *base, *total;
   DGR_ALLOC(counts, arena, int32_t, (int64_t)K * RB);
   DGR_ALLOC(base, arena, int32_t, (int64_t)K * RB);
   DGR_ALLOC(total, arena, int32_t, 1);
-  DGR_ALLOC(hits, arena, int32_t, (int64_t)K * n_cap);
   uint32_t *mask_out, *mask_in = nullptr;
   int32_t *cnt_out, *cnt_in = nullptr;
   DGR_ALLOC(mask_out, arena, uint32_t, (n_cap + 1) * KW);
@@ -266,22 +400,34 @@ static int build_kernel_map_t(DgrArena &arena, const DgrCoordMap &in, const DgrC
     DGR_ALLOC(cnt_in, arena, int32_t, n_in_cap + 1);
     DGR_HIP_CHECK(hipMemsetAsync(mask_in, 0, (size_t)(n_in_cap + 1) * KW * sizeof(uint32_t), stream));
   }
-  dim3 grid(RB, K);
-  bool pruned = false;
+  int32_t *hits = nullptr;
+  unsigned long long *colmask = nullptr;
+  uint8_t *colsub = nullptr;
   if constexpr (D == 6) {
+    DGR_REQUIRE(ks == 3, "6-D kernel maps support kernel size 3 only (got %d)", ks);
+    const int64_t cells = (int64_t)RB * (KM_THREADS / 64) * K;
+    DGR_ALLOC(colmask, arena, unsigned long long, cells);
+    DGR_ALLOC(colsub, arena, uint8_t, cells);
+    // same-stride maps (in and out are the SAME coordinate set) are symmetric: search half the offsets
+    const int symmetric = (in.coords == out.coords && !need_in_csr) ? 1 : 0;
     if (in_buckets && in_buckets->built && ks == 3) {
-      pruned = true;
-      DGR_HIP_CHECK(hipMemsetAsync(hits, 0xff, (size_t)K * n_cap * sizeof(int32_t), stream));
-      DGR_HIP_CHECK(hipMemsetAsync(counts, 0, (size_t)K * RB * sizeof(int32_t), stream));
-      const int64_t threads = n_cap * 27;
-      kmap_search_pruned6<<<(int)dgr_ceil_div(threads, KM_THREADS), KM_THREADS, 0, stream>>>(
-          out.coords, out.n_dev, in.coords, *in_buckets, in.ts, RB, n_cap, hits, counts, KW, mask_out, mask_in);
+      const int64_t threads = n_cap * (symmetric ? 14 : 27);
+      kmap_bits_pruned6<<<(int)dgr_ceil_div(threads, KM_THREADS), KM_THREADS, 0, stream>>>(
+          out.coords, out.n_dev, in.coords, *in_buckets, in.ts, KW, symmetric, mask_out, mask_in);
+    } else {
+      dim3 grid(RB, symmetric ? K / 2 : K);
+      kmap_bits<D><<<grid, KM_THREADS, 0, stream>>>(out.coords, out.n_dev, in.coords, in.table, in.table_mask, ks,
+                                                    in.ts, K, KW, symmetric, mask_out, mask_in);
     }
-  }
-  if (!pruned)
+    DGR_LAUNCH_CHECK();
+    kmap_colmask<<<RB, KM_THREADS, 0, stream>>>(mask_out, out.n_dev, K, KW, RB, colmask, colsub, counts);
+  } else {
+    DGR_ALLOC(hits, arena, int32_t, (int64_t)K * n_cap);
+    dim3 grid(RB, K);
     kmap_search<D><<<grid, KM_THREADS, 0, stream>>>(out.coords, out.n_dev, in.coords, in.table,
                                                     in.table_mask, ks, in.ts, RB, n_cap, hits, counts, KW,
                                                     mask_out, mask_in);
+  }
   DGR_LAUNCH_CHECK();
   // per-row pair counts -> CSR row pointers (out rows; in rows for maps used swapped)
   mask_count_kernel<<<(int)dgr_ceil_div(n_cap + 1, 256), 256, 0, stream>>>(mask_out, KW, out.n_dev, n_cap + 1, cnt_out);
@@ -295,10 +441,18 @@ static int build_kernel_map_t(DgrArena &arena, const DgrCoordMap &in, const DgrC
   kmap_finalize<<<1, 1024, 0, stream>>>(base, total, K, RB, km->rule_ptr, km->tile_ptr);
   tile_desc_kernel<<<(int)dgr_ceil_div(km->tile_cap, 256), 256, 0, stream>>>(km->tile_ptr, km->rule_ptr, K,
                                                                             km->tile_desc, km->tile_cap);
-  dim3 fill_grid(RB, (K + KM_KGROUP - 1) / KM_KGROUP);
-  kmap_fill<<<fill_grid, KM_THREADS, 0, stream>>>(out.n_dev, RB, K, n_cap, hits, counts, base, km->pair_in,
-                                             km->pair_out, km->pair_cap, overflow, KW, mask_out, km->out_ptr,
-                                             km->out_pos, mask_in, km->in_ptr, km->in_pos, km->pair_k);
+  if constexpr (D == 6) {
+    const int64_t threads = n_cap * KW;
+    kmap_place6<<<(int)dgr_ceil_div(threads, KM_THREADS), KM_THREADS, 0, stream>>>(
+        out.coords, out.n_dev, in.coords, in.table, in.table_mask, in.ts, K, KW, RB, mask_out, km->out_ptr, colmask,
+        colsub, base, km->pair_in, km->pair_out, km->pair_k, km->out_pos, km->pair_cap, overflow, mask_in,
+        km->in_ptr, km->in_pos);
+  } else {
+    dim3 fill_grid(RB, (K + KM_KGROUP - 1) / KM_KGROUP);
+    kmap_fill<<<fill_grid, KM_THREADS, 0, stream>>>(out.n_dev, RB, K, n_cap, hits, counts, base, km->pair_in,
+                                                    km->pair_out, km->pair_cap, overflow, KW, mask_out, km->out_ptr,
+                                                    km->out_pos, mask_in, km->in_ptr, km->in_pos, km->pair_k);
+  }
   DGR_LAUNCH_CHECK();
   arena.rewind(mk);
   km->built = true;
