@@ -303,32 +303,40 @@ __global__ void __launch_bounds__(64 * WM * WN, (MB * NB >= 4 ? DGR_WIDE_WAVES :
     return identity ? pstart + tid : a.pair_in[pstart + tid];
   };
   f32x4 G[NCH];
+  uint32_t g_ok = 0;  // bit i: piece i of the requested phase is a real (row, channel) piece
+  // Requests only: NOTHING here may consume a loaded value (a consumer right behind the load costs an
+  // s_waitcnt vmcnt(0) per piece -- the gather then runs serialised, and behind every B operand in
+  // flight).  Invalid pieces are loaded from a clamped address and zeroed in land(); the ReLU-on-read
+  // is applied in land() too, one phase later, when the data has long arrived.
   auto gather = [&](int q) {  // request the rows of phase q (tile q / PPT, channels (q % PPT) * CK ..)
     const int *idx = idxbuf + ((q / PPT) & 3) * TM;
     const int cbase = (q % PPT) * CK;
+    g_ok = 0;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int ch = tid + i * THREADS;
       const int r = ch / C4K, c = cbase + (ch % C4K) * 4;
-      const int row = idx[r];
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-#ifdef DGR_ABL_NOGATHER
-      if (row >= 0 && a.cin < 0) {
-#else
-      if (row >= 0) {
+      int row = idx[r];
+#ifdef DGR_ABL_GATHER_L2
+      if (row >= 0) row &= 63;  // timing ablation: same instruction stream, L2-resident rows
 #endif
-        const float *src = a.in + (int64_t)row * a.in_ld + c;
-        if (VEC) {
-          if (c < a.cin) v = *reinterpret_cast<const f32x4 *>(src);
-        } else {
+      if (VEC) {
+        const int rr = max(row, 0);
+        const int cc = min(c, a.cin - 4);
+        G[i] = *reinterpret_cast<const f32x4 *>(a.in + (int64_t)rr * a.in_ld + cc);
+        g_ok |= (row >= 0 && c < a.cin) ? (1u << i) : 0u;
+      } else {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row >= 0) {
+          const float *src = a.in + (int64_t)row * a.in_ld + c;
           if (c + 0 < a.cin) v.x = src[0];
           if (c + 1 < a.cin) v.y = src[1];
           if (c + 2 < a.cin) v.z = src[2];
           if (c + 3 < a.cin) v.w = src[3];
         }
-        if (a.in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        G[i] = v;
+        g_ok |= 1u << i;
       }
-      G[i] = v;
     }
   };
   auto land = [&](int q) {  // registers -> A buffer q & 1
@@ -336,7 +344,14 @@ __global__ void __launch_bounds__(64 * WM * WN, (MB * NB >= 4 ? DGR_WIDE_WAVES :
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int ch = tid + i * THREADS;
-      *reinterpret_cast<f32x4 *>(dst + (ch / C4K) * LDA + (ch % C4K) * 4) = G[i];
+      f32x4 v = G[i];
+      if (a.in_relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      const bool ok = (g_ok >> i) & 1u;
+      v.x = ok ? v.x : 0.f;
+      v.y = ok ? v.y : 0.f;
+      v.z = ok ? v.z : 0.f;
+      v.w = ok ? v.w : 0.f;
+      *reinterpret_cast<f32x4 *>(dst + (ch / C4K) * LDA + (ch % C4K) * 4) = v;
     }
   };
 
@@ -388,6 +403,11 @@ __global__ void __launch_bounds__(64 * WM * WN, (MB * NB >= 4 ? DGR_WIDE_WAVES :
     const f32x4 *wk = reinterpret_cast<const f32x4 *>(a.w) + ((int64_t)k * S * NBLK + wn * NB) * 64 + lane;
     const float *arow = As + (q & 1) * TM * LDA + (32 * wm * MB + (lane & 31)) * LDA + 4 * (lane >> 5);
     const int s0 = h * SK;
+#ifdef DGR_A_PREFETCH
+    f32x4 av_next[MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) av_next[i] = *reinterpret_cast<const f32x4 *>(arow + i * 32 * LDA);
+#endif
 #pragma unroll
     for (int s = 0; s < SK; ++s) {
       if (s0 + s + RING - 1 < S) {
@@ -402,9 +422,21 @@ __global__ void __launch_bounds__(64 * WM * WN, (MB * NB >= 4 ? DGR_WIDE_WAVES :
       // pin the prefetch HERE: without it the scheduler sinks each load next to its first use
       // (load-to-use distance 0, full L2 latency exposed on every K-step; seen in the ISA)
       __builtin_amdgcn_sched_barrier(0);
+#ifdef DGR_A_PREFETCH
+      // A fragments one K-step ahead: the ds_read latency hides behind this step's MFMAs
+      f32x4 av[MB];
+#pragma unroll
+      for (int i = 0; i < MB; ++i) av[i] = av_next[i];
+      if (s + 1 < SK) {
+#pragma unroll
+        for (int i = 0; i < MB; ++i) av_next[i] = *reinterpret_cast<const f32x4 *>(arow + i * 32 * LDA + (s + 1) * 8);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#else
       f32x4 av[MB];
 #pragma unroll
       for (int i = 0; i < MB; ++i) av[i] = *reinterpret_cast<const f32x4 *>(arow + i * 32 * LDA + s * 8);
+#endif
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -436,7 +468,11 @@ __global__ void __launch_bounds__(64 * WM * WN, (MB * NB >= 4 ? DGR_WIDE_WAVES :
 #else
         if (r < cnt) {
 #endif
+#ifdef DGR_ABL_STORE0
+          float *dst = a.y + (int64_t)(r + 64 * (blockIdx.x & 1023)) * a.y_ld;  // timing ablation: L2-resident product rows
+#else
           float *dst = identity ? a.out + (int64_t)(pst + r) * a.out_ld : a.y + (int64_t)(pst + r) * a.y_ld;
+#endif
 #pragma unroll
           for (int j = 0; j < NB; ++j) {
 #pragma unroll
@@ -460,7 +496,9 @@ __global__ void __launch_bounds__(64 * WM * WN, (MB * NB >= 4 ? DGR_WIDE_WAVES :
         }
       }
     }
+#ifndef DGR_ABL_NOBARRIER
     __syncthreads();  // buffer q&1 is free again; buffer (q+1)&1 and the index ring are visible
+#endif
   }
 }
 

@@ -16,7 +16,10 @@ p0, c0, f0 = dgr.preprocess(x0); p1, c1, f1 = dgr.preprocess(x1)
 F0 = dgr.fcgf_feature_extraction(f0, c0); F1 = dgr.fcgf_feature_extraction(f1, c1)
 _, idx1 = dgr.fcgf_feature_matching(F0, F1)
 gt = torch.from_numpy(synth.gt_correspondences(p0.cpu().numpy(), p1.cpu().numpy(), T, 0.05)).cuda()
-idx1 = torch.where(gt >= 0, gt, idx1)
+# workload independent of the feature values (so that timing ablations of the conv kernel, which
+# produce garbage features, still see the same kernel maps): non-GT rows get a fixed pseudo-random match
+fallback = (torch.arange(len(gt), device=gt.device) * 7919) % len(p1)
+idx1 = torch.where(gt >= 0, gt, fallback)
 c6, f6 = ops.inlier_inputs(c0, p0, c1, p1, idx1, 'coords')
 for name, net, args in (('6-D', dgr.inlier_model._handle(), (c6, f6)), ('3-D', dgr.fcgf_model._handle(), (c0, f0))):
     net.forward(*args)
