@@ -17,8 +17,9 @@ constexpr int KNN_TB = 64;  // F1 rows per LDS tile
 template <int C, int QPT>
 __global__ void __launch_bounds__(KNN_THREADS)
     knn1_kernel(const float *__restrict__ F0, int64_t N0, const float *__restrict__ F1, int64_t N1,
-                int rows_per_split, unsigned long long *__restrict__ best) {
+                int rows_per_split, unsigned long long *__restrict__ best, const int32_t *run_flag) {
   __shared__ __attribute__((aligned(16))) float tile[KNN_TB * C];
+  if (run_flag && *run_flag == 0) return;  // fallback launch of the prefiltered path: nothing overflowed
   const int64_t q0 = ((int64_t)blockIdx.x * KNN_THREADS + threadIdx.x) * QPT;
   const int64_t j_begin = (int64_t)blockIdx.y * rows_per_split;
   const int64_t j_end = min(N1, j_begin + rows_per_split);
@@ -95,7 +96,7 @@ __global__ void knn1_finish(const unsigned long long *__restrict__ best, int64_t
 
 template <int C>
 static int knn_launch(dgr_ctx *ctx, const float *F0, int64_t N0, const float *F1, int64_t N1,
-                      unsigned long long *best, hipStream_t stream) {
+                      unsigned long long *best, const int32_t *run_flag, hipStream_t stream) {
   constexpr int QPT = (C <= 32) ? 4 : 2;
   const int qblocks = (int)dgr_ceil_div(N0, (int64_t)KNN_THREADS * QPT);
   // enough (query block, F1 split) workgroups to cover every CU a few times over
@@ -106,9 +107,245 @@ static int knn_launch(dgr_ctx *ctx, const float *F0, int64_t N0, const float *F1
   int rows_per_split = (int)dgr_ceil_div(dgr_ceil_div(N1, splits), KNN_TB) * KNN_TB;
   splits = (int)dgr_ceil_div(N1, rows_per_split);
   dim3 grid(qblocks, splits);
-  knn1_kernel<C, QPT><<<grid, KNN_THREADS, 0, stream>>>(F0, N0, F1, N1, rows_per_split, best);
+  knn1_kernel<C, QPT><<<grid, KNN_THREADS, 0, stream>>>(F0, N0, F1, N1, rows_per_split, best, run_flag);
   DGR_LAUNCH_CHECK();
   return DGR_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------
+// C = 32: bf16-MFMA prefilter + exact re-evaluation.  Same result as the brute-force kernel above,
+// bit for bit, at ~1/6 of its time:
+//   pack     every feature row is split x = hi + lo (+ r, |r| <= 2^-18 |x|) into two bf16 rows, stored
+//            in MFMA operand order (32-row tiles); reference rows are pre-scaled by -2 (exact) and
+//            carry their squared norm nb.
+//   pass 1   d~'(i,j) = nb_i - 2 (hi.hi + hi.lo + lo.hi)  on v_mfma_f32_32x32x16_bf16 (6 per 32 x 32
+//            block, accumulator initialised with nb through the C operand); per-query minimum m~_j.
+//   pass 2   the same products again (identical bits); every (i, j) with d~' <= m~_j + tau_j goes to
+//            a candidate list.  tau_j = 2 c (na_j + max nb), c = 4e-5, bounds twice the worst-case
+//            difference between d~ and the f32 value the brute-force kernel computes (split residual
+//            3 * 2^-18, f32 accumulation of 96 products, f32 norms), so the brute-force
+//            arg-min -- including its first-index tie-break among equal f32 distances -- is always
+//            in the list.
+//   exact    one thread per candidate evaluates sum (a - b)^2 exactly like knn1_kernel and merges with
+//            the same 64-bit atomicMin key.
+// If a query collects more than KNN_SLOTS candidates (degenerate inputs: many near-ties) or any feature is
+// non-finite / huge, a flag makes the brute-force kernel, launched behind it, do the work instead.
+// ------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+constexpr float KNN_TAU_C = 8e-5f;  // 2 c
+constexpr int KNN_SLOTS = 8;        // candidate slots per query
+
+__device__ __forceinline__ unsigned short knn_f2bf(float x) {  // round to nearest even
+  uint32_t u = __float_as_uint(x);
+  if ((u & 0x7f800000u) == 0x7f800000u) return (unsigned short)((u >> 16) | ((u & 0xffffu) ? 0x40u : 0u));
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float knn_bf2f(unsigned short h) { return __uint_as_float((uint32_t)h << 16); }
+__device__ __forceinline__ uint32_t knn_ord(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
+}
+__device__ __forceinline__ float knn_unord(uint32_t k) {
+  return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu));
+}
+
+// packed[(tile * 4 + f) * 64 + r + 32 g] = 8 bf16: dims 16 (f & 1) + 8 g .. + 7 of row 32 tile + r,
+// f >> 1 = 0: hi, 1: lo.  One thread per (row, g, chunk); the (g = 0, chunk = 0) thread also writes the norm.
+__global__ void __launch_bounds__(256)
+    knn_pack_kernel(const float *__restrict__ F, int64_t N, int64_t n_pad, float scale, float pad_norm,
+                    bf16x8 *__restrict__ packed, float *__restrict__ norms, uint32_t *norm_max, int32_t *fallback) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t row = t >> 2;
+  if (row >= n_pad) return;
+  const int g = (int)(t & 1), ch = (int)((t >> 1) & 1);
+  bf16x8 hi, lo;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { hi[e] = 0; lo[e] = 0; }
+  if (row < N) {
+    const float *src = F + row * 32 + 16 * ch + 8 * g;
+    const float4 v0 = *reinterpret_cast<const float4 *>(src), v1 = *reinterpret_cast<const float4 *>(src + 4);
+    const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      // non-finite or huge values (squared norms would overflow): leave the search to the exact kernel
+      if (!(fabsf(x[e]) < 1e18f)) *fallback = 1;
+      const unsigned short h = knn_f2bf(x[e]);
+      const unsigned short l = knn_f2bf(x[e] - knn_bf2f(h));
+      hi[e] = (short)knn_f2bf(knn_bf2f(h) * scale);  // scale is a power of two: exact
+      lo[e] = (short)knn_f2bf(knn_bf2f(l) * scale);
+    }
+  }
+  const int64_t tile = row >> 5;
+  const int r = (int)(row & 31);
+  packed[(tile * 4 + ch) * 64 + r + 32 * g] = hi;
+  packed[(tile * 4 + 2 + ch) * 64 + r + 32 * g] = lo;
+  if (g == 0 && ch == 0) {
+    float n = pad_norm;
+    if (row < N) {
+      n = 0.f;
+      for (int c = 0; c < 32; ++c) n = fmaf(F[row * 32 + c], F[row * 32 + c], n);
+      if (norm_max) atomicMax(norm_max, __float_as_uint(n));  // n >= 0: bit patterns order like values
+    }
+    norms[row] = n;
+  }
+}
+
+template <bool PASS2>
+__global__ void __launch_bounds__(256, 2)
+    knn_mfma_kernel(const bf16x8 *__restrict__ Q, const bf16x8 *__restrict__ R, const float *__restrict__ nb,
+                    int n_qblocks, int n_rtiles, int tiles_per_split, uint32_t *__restrict__ mt,
+                    const float *__restrict__ na, const uint32_t *__restrict__ nb_max, int64_t N0, int64_t N1,
+                    int32_t *__restrict__ cand, int32_t *__restrict__ cand_cnt, int32_t *overflow) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = lane >> 5;
+  const int qb0 = (blockIdx.x * 4 + wave) * 4;
+  if (qb0 >= n_qblocks) return;
+  bf16x8 bq[4][4];
+  float m[4], thr[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int qb = min(qb0 + u, n_qblocks - 1);
+#pragma unroll
+    for (int f = 0; f < 4; ++f) bq[u][f] = Q[((int64_t)qb * 4 + f) * 64 + lane];
+    m[u] = __builtin_inff();
+    thr[u] = 0.f;
+    if (PASS2) {
+      const int64_t q = (int64_t)qb * 32 + (lane & 31);
+      const float nmax = __uint_as_float(*nb_max);
+      thr[u] = (q < N0) ? knn_unord(mt[q]) + KNN_TAU_C * (na[q] + nmax) : -__builtin_inff();
+    }
+  }
+  const int t_begin = blockIdx.y * tiles_per_split;
+  const int t_end = min(n_rtiles, t_begin + tiles_per_split);
+  if (t_begin >= t_end) return;
+  bf16x8 ar[4];
+  f32x16_t nbv;
+  auto fetch = [&](int t) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) ar[f] = R[((int64_t)t * 4 + f) * 64 + lane];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 v = *reinterpret_cast<const float4 *>(nb + (int64_t)t * 32 + 8 * g + 4 * h);
+      nbv[4 * g] = v.x; nbv[4 * g + 1] = v.y; nbv[4 * g + 2] = v.z; nbv[4 * g + 3] = v.w;
+    }
+  };
+  fetch(t_begin);
+  for (int t = t_begin; t < t_end; ++t) {
+    bf16x8 a0 = ar[0], a1 = ar[1], a2 = ar[2], a3 = ar[3];
+    const f32x16_t c0 = nbv;
+    if (t + 1 < t_end) fetch(t + 1);   // next tile's operands land behind this tile's MFMAs
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      f32x16_t acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[u][0], c0, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bq[u][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bq[u][2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bq[u][3], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bq[u][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, bq[u][1], acc, 0, 0, 0);
+      float bm = fminf(fminf(acc[0], acc[1]), fminf(acc[2], acc[3]));
+#pragma unroll
+      for (int e = 4; e < 16; e += 4) bm = fminf(bm, fminf(fminf(acc[e], acc[e + 1]), fminf(acc[e + 2], acc[e + 3])));
+      if (!PASS2) {
+        m[u] = fminf(m[u], bm);
+      } else {
+        if (!(bm > thr[u])) {   // rare: some reference of this block is within tau of the query's minimum
+          const int64_t q = (int64_t)(qb0 + u) * 32 + (lane & 31);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int64_t i = (int64_t)t * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (!(acc[e] > thr[u]) && q < N0 && i < N1 && qb0 + u < n_qblocks) {
+              const int slot = atomicAdd(cand_cnt + q, 1);   // per-query counters: no hot address
+              if (slot < KNN_SLOTS) cand[q * KNN_SLOTS + slot] = (int32_t)i;
+              else *overflow = 1;
+            }
+          }
+        }
+      }
+    }
+  }
+  if (!PASS2) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float o = __shfl_xor(m[u], 32, 64);
+      const float mm = fminf(m[u], o);
+      const int64_t q = (int64_t)(qb0 + u) * 32 + (lane & 31);
+      if (lane < 32 && qb0 + u < n_qblocks && q < N0) atomicMin(mt + q, knn_ord(mm));
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    knn_exact_kernel(const float *__restrict__ F0, const float *__restrict__ F1, const int32_t *__restrict__ cand,
+                     const int32_t *__restrict__ cand_cnt, int64_t N0, unsigned long long *__restrict__ best) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t q = t / KNN_SLOTS;
+  const int slot = (int)(t % KNN_SLOTS);
+  if (q >= N0 || slot >= cand_cnt[q]) return;
+  const int i = cand[t];
+  const float *a = F0 + q * 32, *b = F1 + (int64_t)i * 32;
+  float d0 = 0.f, d1 = 0.f;  // the very chain of knn1_kernel
+#pragma unroll
+  for (int k = 0; k < 32; k += 4) {
+    const float4 av = *reinterpret_cast<const float4 *>(a + k), bv = *reinterpret_cast<const float4 *>(b + k);
+    const float e0 = av.x - bv.x, e1 = av.y - bv.y, e2 = av.z - bv.z, e3 = av.w - bv.w;
+    d0 = fmaf(e0, e0, d0);
+    d1 = fmaf(e1, e1, d1);
+    d0 = fmaf(e2, e2, d0);
+    d1 = fmaf(e3, e3, d1);
+  }
+  const float d = d0 + d1;
+  if (d < __builtin_inff()) {
+    const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)i;
+    atomicMin(best + q, key);
+  }
+}
+
+static int knn_prefiltered(dgr_ctx *ctx, const float *F0, int64_t N0, const float *F1, int64_t N1,
+                           unsigned long long *best, hipStream_t stream) {
+  DgrArena &arena = ctx->arena;
+  const int n_qblocks = (int)dgr_ceil_div(N0, 32), n_rtiles = (int)dgr_ceil_div(N1, 32);
+  bf16x8 *Qp, *Rp;
+  float *na, *nb;
+  uint32_t *mt, *nb_max;
+  int32_t *cand, *cand_cnt;
+  DGR_ALLOC(Qp, arena, bf16x8, (int64_t)n_qblocks * 256);
+  DGR_ALLOC(Rp, arena, bf16x8, (int64_t)n_rtiles * 256);
+  DGR_ALLOC(na, arena, float, (int64_t)n_qblocks * 32);
+  DGR_ALLOC(nb, arena, float, (int64_t)n_rtiles * 32);
+  DGR_ALLOC(mt, arena, uint32_t, N0);
+  DGR_ALLOC(cand_cnt, arena, int32_t, N0 + 4);   // + [N0]: max nb bits, [N0 + 1]: fallback flag
+  DGR_ALLOC(cand, arena, int32_t, N0 * KNN_SLOTS);
+  nb_max = reinterpret_cast<uint32_t *>(cand_cnt + N0);
+  int32_t *fallback = cand_cnt + N0 + 1;
+  DGR_HIP_CHECK(hipMemsetAsync(cand_cnt, 0, (size_t)(N0 + 4) * sizeof(int32_t), stream));
+  DGR_HIP_CHECK(hipMemsetAsync(mt, 0xff, (size_t)N0 * sizeof(uint32_t), stream));
+  const int64_t q_pad = (int64_t)n_qblocks * 32, r_pad = (int64_t)n_rtiles * 32;
+  knn_pack_kernel<<<(int)dgr_ceil_div(q_pad * 4, 256), 256, 0, stream>>>(F0, N0, q_pad, 1.f, 0.f, Qp, na, nullptr,
+                                                                         fallback);
+  knn_pack_kernel<<<(int)dgr_ceil_div(r_pad * 4, 256), 256, 0, stream>>>(F1, N1, r_pad, -2.f, __builtin_inff(), Rp,
+                                                                         nb, nb_max, fallback);
+  DGR_LAUNCH_CHECK();
+  const int qgroups = (int)dgr_ceil_div(n_qblocks, 16);
+  int splits = (int)dgr_ceil_div((int64_t)ctx->num_cus * 4, qgroups);
+  if (splits > n_rtiles / 4) splits = n_rtiles / 4;
+  if (splits < 1) splits = 1;
+  const int tps = (int)dgr_ceil_div(n_rtiles, splits);
+  splits = (int)dgr_ceil_div(n_rtiles, tps);
+  dim3 grid(qgroups, splits);
+  knn_mfma_kernel<false><<<grid, 256, 0, stream>>>(Qp, Rp, nb, n_qblocks, n_rtiles, tps, mt, na, nb_max, N0, N1,
+                                                   cand, cand_cnt, fallback);
+  knn_mfma_kernel<true><<<grid, 256, 0, stream>>>(Qp, Rp, nb, n_qblocks, n_rtiles, tps, mt, na, nb_max, N0, N1, cand,
+                                                  cand_cnt, fallback);
+  DGR_LAUNCH_CHECK();
+  knn_exact_kernel<<<(int)dgr_ceil_div(N0 * KNN_SLOTS, 256), 256, 0, stream>>>(F0, F1, cand, cand_cnt, N0, best);
+  DGR_LAUNCH_CHECK();
+  // too many near-ties for the slots, or non-finite input: the brute-force kernel redoes the search
+  // (it exits at once otherwise)
+  return knn_launch<32>(ctx, F0, N0, F1, N1, best, fallback, stream);
 }
 
 int dgr_knn1_impl(dgr_ctx *ctx, const float *F0, int64_t N0, const float *F1, int64_t N1, int C,
@@ -120,9 +357,14 @@ int dgr_knn1_impl(dgr_ctx *ctx, const float *F0, int64_t N0, const float *F1, in
   DGR_ALLOC(best, ctx->arena, unsigned long long, N0);
   DGR_HIP_CHECK(hipMemsetAsync(best, 0xff, (size_t)N0 * sizeof(unsigned long long), stream));
   switch (C) {
-    case 16: DGR_CHECK(knn_launch<16>(ctx, F0, N0, F1, N1, best, stream)); break;
-    case 32: DGR_CHECK(knn_launch<32>(ctx, F0, N0, F1, N1, best, stream)); break;
-    case 64: DGR_CHECK(knn_launch<64>(ctx, F0, N0, F1, N1, best, stream)); break;
+    case 16: DGR_CHECK(knn_launch<16>(ctx, F0, N0, F1, N1, best, nullptr, stream)); break;
+    case 32: {
+      static const bool brute = getenv("DGR_KNN_BRUTE") != nullptr;
+      if (brute || N1 < 1024) DGR_CHECK(knn_launch<32>(ctx, F0, N0, F1, N1, best, nullptr, stream));
+      else DGR_CHECK(knn_prefiltered(ctx, F0, N0, F1, N1, best, stream));
+      break;
+    }
+    case 64: DGR_CHECK(knn_launch<64>(ctx, F0, N0, F1, N1, best, nullptr, stream)); break;
     default:
       dgr_set_error("find_knn: feature width %d not supported (16, 32, 64)", C);
       return DGR_EINVAL;

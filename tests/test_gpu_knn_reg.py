@@ -67,6 +67,59 @@ def test_knn_large_vs_oracle_and_properties():
         ops.knn1(torch.zeros(0, 32).cuda(), Gt)
 
 
+_KNN_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from deepglobalregistration_amd import ops
+rng = np.random.default_rng(7)
+out = {}
+def unit(x):
+    return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+cases = {}
+# (a) unit-norm random features, ragged sizes (not multiples of 32)
+cases['unit'] = (unit(rng.standard_normal((6001, 32))), unit(rng.standard_normal((9013, 32))))
+# (b) concentrated features: a common direction plus small noise -> thousands of near-ties per query
+base = rng.standard_normal((1, 32))
+cases['concentrated'] = (unit(base + 0.02 * rng.standard_normal((3000, 32))),
+                         unit(base + 0.02 * rng.standard_normal((5000, 32))))
+# (c) exact duplicates in F1 (first index must win) and F0 rows copied from F1 (distance 0)
+F1 = unit(rng.standard_normal((4096, 32))); F1[2048:] = F1[:2048]
+cases['duplicates'] = (np.concatenate([F1[100:1100], unit(rng.standard_normal((500, 32)))]), F1)
+# (d) un-normalised features with a wide range of magnitudes
+cases['scaled'] = ((rng.standard_normal((2500, 32)) * 10.0 ** rng.uniform(-3, 3, (2500, 1))).astype(np.float32),
+                   (rng.standard_normal((3500, 32)) * 10.0 ** rng.uniform(-3, 3, (3500, 1))).astype(np.float32))
+# (e) the BASELINE size
+cases['full'] = (unit(rng.standard_normal((27462, 32))), unit(rng.standard_normal((21376, 32))))
+for name, (F0, F1) in cases.items():
+    idx, dist = ops.knn1(torch.from_numpy(F0).cuda(), torch.from_numpy(F1).cuda(), return_distance=True)
+    out[name + '_idx'] = idx.cpu().numpy(); out[name + '_dist'] = dist.cpu().numpy()
+np.savez(sys.argv[2], **out)
+"""
+
+
+def test_knn_prefilter_equals_brute_force(tmp_path):
+    """The bf16-MFMA prefiltered search must return exactly what the exact brute-force kernel returns
+    (indices AND distance bits), including on near-tie-heavy, duplicate and badly scaled inputs."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'knn_cases.py'
+    script.write_text(_KNN_SCRIPT)
+    res = {}
+    for mode in ('prefilter', 'brute'):
+        env = dict(os.environ)
+        env.pop('DGR_KNN_BRUTE', None)
+        if mode == 'brute':
+            env['DGR_KNN_BRUTE'] = '1'
+        out = tmp_path / f'{mode}.npz'
+        subprocess.run([sys.executable, str(script), root, str(out)], check=True, env=env, timeout=600)
+        res[mode] = np.load(out)
+    for k in res['brute'].files:
+        a, b = res['prefilter'][k], res['brute'][k]
+        assert a.dtype == b.dtype and np.array_equal(a.view(np.uint8), b.view(np.uint8)), k
+
+
 def test_procrustes_golden(golden):
     from deepglobalregistration_amd.core.registration import weighted_procrustes
     g = golden('procrustes')
