@@ -708,8 +708,9 @@ __global__ void __launch_bounds__(256)
     conv1_probe_kernel(const int32_t *__restrict__ coords, const int32_t *n_dev, const int32_t *__restrict__ table,
                        uint32_t mask, int ks, const float *__restrict__ in, int in_ld, int cin,
                        const float *__restrict__ w, const float *__restrict__ shift, float *__restrict__ out,
-                       int out_ld, int32_t *pair_count) {
+                       int out_ld, int32_t *pair_count, const int32_t *skip_flag) {
   extern __shared__ __attribute__((aligned(16))) float wl[];   // [K][cin][32] compact copy of the weights
+  if (skip_flag && *skip_flag) return;   // the dense-grid kernel did the layer
   const int n = *n_dev;
   const int lane = threadIdx.x & 63;
   const int co = lane & 31;
@@ -768,21 +769,249 @@ __global__ void __launch_bounds__(256)
   if (lane == 0 && pair_count) atomicAdd(pair_count, pairs);
 }
 
-int dgr_conv1_probe(const DgrCoordMap &cm, int ks, const float *in, int in_ld, int cin, const float *w_tiled,
-                    const float *shift, float *out, int out_ld, int32_t *pair_count, hipStream_t stream) {
+// ------------------------------------------------------------------------------------------
+// Dense-grid variant of the fused conv1.  A 3-D fragment is compact: the bounding boxes of the batch
+// elements (padded by ks/2) hold a few million cells, so the voxel -> row map fits a plain int32 grid
+// and a neighbour probe is ONE load of ks consecutive cells per (ky, kz) row -- no hashing, no probe
+// chains, 49 independent 28-byte reads per voxel instead of 343 dependent table + key reads.
+//   bbox    per-batch-element min / max (block-reduced, 6 atomics per block)
+//   layout  grid dims, per-element bases, total cell count; `ok` = fits the cell budget and every batch
+//           index is in [0, 64) -- otherwise the hash-probe kernel (launched behind) does the layer
+//   clear / fill
+//   conv    a wave takes TWO voxels at a time.  Phase A (all lanes, one voxel after the other): lane =
+//           (ky, kz) row reads its ks cells; ballots rank the hits in ascending k; (k, row) lists go to
+//           LDS.  Phase B: half-wave = voxel, lane = output channel walks its list -- the loads of a step
+//           do not depend on the running sum, only the adds are serial -- same k-ordered sum as the
+//           map-based path, bit for bit.
+// ------------------------------------------------------------------------------------------
+constexpr int GRID_MAXB = 64;
+struct DgrGridMeta {
+  int32_t ok, bad;
+  long long total;
+  int32_t mn[GRID_MAXB][3], mx[GRID_MAXB][3], dim[GRID_MAXB][3];
+  long long base[GRID_MAXB];
+};
+
+__global__ void grid_init_kernel(DgrGridMeta *m) {
+  const int b = threadIdx.x;
+  if (b == 0) { m->ok = 0; m->bad = 0; m->total = 0; }
+  if (b < GRID_MAXB) {
+    for (int d = 0; d < 3; ++d) { m->mn[b][d] = INT32_MAX; m->mx[b][d] = INT32_MIN; m->dim[b][d] = 0; }
+    m->base[b] = 0;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    grid_bbox_kernel(const int32_t *__restrict__ coords, const int32_t *n_dev, DgrGridMeta *m) {
+  __shared__ int32_t red[6][256 / 64];
+  __shared__ int32_t b0s, mixed;
+  const int n = *n_dev;
+  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if ((int64_t)blockIdx.x * 256 >= n) return;
+  const bool live = o < n;
+  const int4 c = live ? *reinterpret_cast<const int4 *>(coords + o * 4) : make_int4(0, 0, 0, 0);
+  if (threadIdx.x == 0) { b0s = c.x; mixed = 0; }
+  __syncthreads();
+  if (live && c.x != b0s) mixed = 1;
+  if (live && (c.x < 0 || c.x >= GRID_MAXB)) m->bad = 1;
+  __syncthreads();
+  if (mixed) {   // block straddles batch elements: plain atomics
+    if (live && c.x >= 0 && c.x < GRID_MAXB) {
+      atomicMin(&m->mn[c.x][0], c.y); atomicMax(&m->mx[c.x][0], c.y);
+      atomicMin(&m->mn[c.x][1], c.z); atomicMax(&m->mx[c.x][1], c.z);
+      atomicMin(&m->mn[c.x][2], c.w); atomicMax(&m->mx[c.x][2], c.w);
+    }
+    return;
+  }
+  int32_t v[6] = {live ? c.y : INT32_MAX, live ? c.z : INT32_MAX, live ? c.w : INT32_MAX,
+                  live ? c.y : INT32_MIN, live ? c.z : INT32_MIN, live ? c.w : INT32_MIN};
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      v[d] = min(v[d], __shfl_xor(v[d], s, 64));
+      v[3 + d] = max(v[3 + d], __shfl_xor(v[3 + d], s, 64));
+    }
+  }
+  if ((threadIdx.x & 63) == 0)
+    for (int d = 0; d < 6; ++d) red[d][threadIdx.x >> 6] = v[d];
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int d = threadIdx.x;
+    int32_t r = red[d][0];
+    for (int w = 1; w < 4; ++w) r = d < 3 ? min(r, red[d][w]) : max(r, red[d][w]);
+    const int b = b0s;
+    if (b >= 0 && b < GRID_MAXB) {
+      if (d < 3) atomicMin(&m->mn[b][d], r); else atomicMax(&m->mx[b][d - 3], r);
+    }
+  }
+}
+
+__global__ void grid_layout_kernel(DgrGridMeta *m, int pad, long long cap) {
+  if (threadIdx.x != 0) return;
+  long long total = 0;
+  bool ok = !m->bad;
+  for (int b = 0; b < GRID_MAXB; ++b) {
+    m->base[b] = total;
+    if (m->mx[b][0] < m->mn[b][0]) continue;   // no rows
+    long long vol = 1;
+    for (int d = 0; d < 3; ++d) {
+      const long long e = (long long)m->mx[b][d] - m->mn[b][d] + 1 + 2 * pad;
+      m->dim[b][d] = (int32_t)(e < (1ll << 30) ? e : (1ll << 30));
+      vol = (vol <= cap && e <= cap) ? vol * e : cap + 1;
+    }
+    if (vol > cap) { ok = false; break; }
+    total += vol;
+    if (total > cap) { ok = false; break; }
+  }
+  m->total = total;
+  m->ok = ok ? 1 : 0;
+}
+
+__global__ void grid_clear_kernel(const DgrGridMeta *m, int32_t *__restrict__ cells) {
+  if (!m->ok) return;
+  const long long total = m->total;
+  for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < total; i += (long long)gridDim.x * blockDim.x * 4)
+    *reinterpret_cast<int4 *>(cells + i) = make_int4(-1, -1, -1, -1);   // capacity is padded to a multiple of 4
+}
+
+__device__ __forceinline__ long long grid_cell(const DgrGridMeta *m, int b, int x, int y, int z, int pad) {
+  const long long dx = m->dim[b][0], dy = m->dim[b][1];
+  return m->base[b] + ((long long)(z - m->mn[b][2] + pad) * dy + (y - m->mn[b][1] + pad)) * dx + (x - m->mn[b][0] + pad);
+}
+
+__global__ void grid_fill_kernel(const int32_t *__restrict__ coords, const int32_t *n_dev, const DgrGridMeta *m, int pad,
+                                 int32_t *__restrict__ cells) {
+  if (!m->ok) return;
+  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= *n_dev) return;
+  const int4 c = *reinterpret_cast<const int4 *>(coords + o * 4);
+  cells[grid_cell(m, c.x, c.y, c.z, c.w, pad)] = (int32_t)o;
+}
+
+constexpr int C1_MAXK = 343;   // ks <= 7
+__global__ void __launch_bounds__(256)
+    conv1_grid_kernel(const int32_t *__restrict__ coords, const int32_t *n_dev, const DgrGridMeta *__restrict__ m,
+                      const int32_t *__restrict__ cells, int ks, const float *__restrict__ in, int in_ld, int cin,
+                      const float *__restrict__ w, const float *__restrict__ shift, float *__restrict__ out,
+                      int out_ld, int32_t *pair_count) {
+  __shared__ int2 lists[256 / 64][2][C1_MAXK + 1];
+  if (!m->ok) return;
+  const int n = *n_dev;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int half = ks >> 1, ks2 = ks * ks;
+  const int ky = lane % ks, kz = lane / ks;
+  const int vsel = lane >> 5, co = lane & 31;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  int pairs = 0;
+  for (int64_t o0 = wave_id * 2; o0 < n; o0 += n_waves * 2) {
+    int nh[2] = {0, 0};
+    // ---- phase A: hit lists of the two voxels, ascending k
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const int64_t o = o0 + v;
+      if (o >= n) break;   // wave-uniform
+      const int4 c = *reinterpret_cast<const int4 *>(coords + o * 4);
+      int hit[7];
+#pragma unroll
+      for (int kx = 0; kx < 7; ++kx) hit[kx] = -1;
+      if (lane < ks2) {
+        const long long c0 = grid_cell(m, c.x, c.y - half, c.z + ky - half, c.w + kz - half, half);
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx)
+          if (kx < ks) hit[kx] = cells[c0 + kx];
+      }
+      unsigned long long mk[7];
+      int before = 0;
+#pragma unroll
+      for (int kx = 0; kx < 7; ++kx) {
+        mk[kx] = __ballot(hit[kx] >= 0);
+        before += __popcll(mk[kx] & below);
+        nh[v] += __popcll(mk[kx]);
+      }
+      int r = before;
+#pragma unroll
+      for (int kx = 0; kx < 7; ++kx)
+        if (hit[kx] >= 0) lists[wv][v][r++] = make_int2(kx + ks * lane, hit[kx]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- phase B: half-wave = voxel, lane = output channel
+    pairs += nh[0] + nh[1];
+    const int my_n = vsel ? nh[1] : nh[0];
+    const int trips = max(nh[0], nh[1]);
+    float acc = shift ? shift[co] : 0.f;
+    for (int r0 = 0; r0 < trips; r0 += 4) {
+      float t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool ok = r0 + u < my_n;
+        const int2 e = ok ? lists[wv][vsel][r0 + u] : make_int2(0, 0);
+        float tt = 0.f;
+#pragma unroll
+        for (int ci = 0; ci < 8; ++ci) {
+          if (ci < cin) {   // cin is wave-uniform
+            const float xs = in[(int64_t)e.y * in_ld + ci];
+            const float wvv = w[(int64_t)e.x * 256 + (32 * (ci >> 2) + co) * 4 + (ci & 3)];
+            tt = fmaf(xs, wvv, tt);   // same k-ordered fma chain as the MFMA path
+          }
+        }
+        t[u] = tt;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = (r0 + u < my_n) ? acc + t[u] : acc;
+    }
+    const int64_t o = o0 + vsel;
+    if (o < n) out[o * out_ld + co] = acc;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();   // the lists are rewritten by the next pair of voxels
+  }
+  if (lane == 0 && pair_count) atomicAdd(pair_count, pairs);
+}
+
+int dgr_conv1_probe(DgrArena &arena, const DgrCoordMap &cm, int ks, const float *in, int in_ld, int cin,
+                    const float *w_tiled, const float *shift, float *out, int out_ld, int32_t *pair_count,
+                    hipStream_t stream) {
   DGR_REQUIRE(cin >= 1 && cin <= 8 && ks % 2 == 1, "conv1 probe: cin=%d ks=%d", cin, ks);
   if (pair_count) DGR_HIP_CHECK(hipMemsetAsync(pair_count, 0, sizeof(int32_t), stream));
+  const int32_t *grid_done = nullptr;
+  static const bool no_grid = getenv("DGR_CONV1_HASH") != nullptr;
+  if (ks <= 7 && !no_grid) {
+    // dense grid: up to 64 M cells (256 MB) of transient arena memory
+    static const long long cap = 64ll << 20;
+    DgrArena::Mark mk = arena.mark();
+    DgrGridMeta *meta;
+    int32_t *cells;
+    DGR_ALLOC(meta, arena, DgrGridMeta, 1);
+    DGR_ALLOC(cells, arena, int32_t, cap + 4);
+    grid_init_kernel<<<1, 64, 0, stream>>>(meta);
+    grid_bbox_kernel<<<(int)dgr_ceil_div(cm.n_cap, 256), 256, 0, stream>>>(cm.coords, cm.n_dev, meta);
+    grid_layout_kernel<<<1, 64, 0, stream>>>(meta, ks >> 1, cap);
+    grid_clear_kernel<<<2048, 256, 0, stream>>>(meta, cells);
+    grid_fill_kernel<<<(int)dgr_ceil_div(cm.n_cap, 256), 256, 0, stream>>>(cm.coords, cm.n_dev, meta, ks >> 1, cells);
+    int64_t blocks = dgr_ceil_div(cm.n_cap, 8);
+    if (blocks > 8192) blocks = 8192;
+    conv1_grid_kernel<<<(int)blocks, 256, 0, stream>>>(cm.coords, cm.n_dev, meta, cells, ks, in, in_ld, cin, w_tiled, shift,
+                                                       out, out_ld, pair_count);
+    DGR_LAUNCH_CHECK();
+    grid_done = &meta->ok;
+    arena.rewind(mk);   // stream order keeps the grid alive until the kernels above are done
+  }
   const size_t wbytes = (size_t)ks * ks * ks * cin * 32 * sizeof(float);
   static const bool lds_w = getenv("DGR_CONV1_LDS") != nullptr;  // measured slower than L1-cached global reads
   if (lds_w && wbytes <= 64 * 1024) {
     int64_t blocks = 768;      // 3 per CU (44 KB of LDS each): copy the weights once, then walk many voxels
     conv1_probe_kernel<true><<<(int)blocks, 256, wbytes, stream>>>(cm.coords, cm.n_dev, cm.table, cm.table_mask, ks, in,
-                                                                   in_ld, cin, w_tiled, shift, out, out_ld, pair_count);
+                                                                   in_ld, cin, w_tiled, shift, out, out_ld, pair_count,
+                                                                   grid_done);
   } else {
     int64_t blocks = dgr_ceil_div(cm.n_cap, 4);
     if (blocks > 16384) blocks = 16384;
     conv1_probe_kernel<false><<<(int)blocks, 256, 0, stream>>>(cm.coords, cm.n_dev, cm.table, cm.table_mask, ks, in, in_ld,
-                                                               cin, w_tiled, shift, out, out_ld, pair_count);
+                                                               cin, w_tiled, shift, out, out_ld, pair_count, grid_done);
   }
   DGR_LAUNCH_CHECK();
   return DGR_OK;

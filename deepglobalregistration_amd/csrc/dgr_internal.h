@@ -132,8 +132,9 @@ struct DgrMapSet {
 int dgr_build_maps(DgrArena &arena, const int32_t *coords, int64_t N, int D, int conv1_ks,
                    DgrMapSet *ms, hipStream_t stream, bool skip_conv1_map = false);
 // conv1 fused with its neighbour search (D = 3, Cin <= 8, Cout = 32): no kernel map for the ks^3 offsets
-int dgr_conv1_probe(const DgrCoordMap &cm, int ks, const float *in, int in_ld, int cin, const float *w_tiled,
-                    const float *shift, float *out, int out_ld, int32_t *pair_count, hipStream_t stream);
+int dgr_conv1_probe(DgrArena &arena, const DgrCoordMap &cm, int ks, const float *in, int in_ld, int cin,
+                    const float *w_tiled, const float *shift, float *out, int out_ld, int32_t *pair_count,
+                    hipStream_t stream);
 // voxelise helper (coordmap.hip)
 int dgr_unique_rows(DgrArena &arena, const int32_t *keys, int64_t n, int nc, int32_t *first_flag,
                     int32_t *rank, int32_t *n_unique_dev, int32_t **table_out, uint32_t *mask_out,

@@ -330,7 +330,7 @@ int dgr_resunet_forward_impl(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, 
       e0 = ctx->events.next(); e1 = ctx->events.next();
       DGR_HIP_CHECK(hipEventRecord(e0, stream));
     }
-    DGR_CHECK(dgr_conv1_probe(ms.cm[0], net->conv1_ks, feats, net->cin, net->cin, L0.w, L0.shift, t1, 32, pc, stream));
+    DGR_CHECK(dgr_conv1_probe(A, ms.cm[0], net->conv1_ks, feats, net->cin, net->cin, L0.w, L0.shift, t1, 32, pc, stream));
     if (f.prof) {
       DGR_HIP_CHECK(hipEventRecord(e1, stream));
       ctx->conv_spans.push_back({e0, e1});
