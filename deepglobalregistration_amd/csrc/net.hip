@@ -408,6 +408,12 @@ int dgr_ctx_collect_profile(dgr_ctx *ctx) {
   DGR_CHECK(total(ctx->map6_spans, &ctx->stage_ms[6]));
   DGR_CHECK(total(ctx->conv_spans, &ctx->stage_ms[7]));
   ctx->conv_launches = (int64_t)ctx->conv_spans.size();
+  ctx->conv_span_ms.clear();
+  for (auto &sp : ctx->conv_spans) {
+    float t = 0.f;
+    DGR_HIP_CHECK(hipEventElapsedTime(&t, sp.first, sp.second));
+    ctx->conv_span_ms.push_back(t);
+  }
   return DGR_OK;
 }
 

@@ -337,3 +337,12 @@ def stage_times(device):
     out = dict(zip(names, [float(v) for v in t]))
     out['conv_launches'] = int(_lib.load().dgr_ctx_conv_launches(get_ctx(device)))
     return out
+
+
+def conv_launch_times(device):
+    """Per-launch durations (ms) of the sparse-conv layers of the last profiled batch, launch order."""
+    cap = 4096
+    t = (C.c_float * cap)()
+    n = C.c_int64(0)
+    check(_lib.load().dgr_ctx_conv_launch_times(get_ctx(device), t, cap, C.byref(n)))
+    return [float(t[i]) for i in range(n.value)]
