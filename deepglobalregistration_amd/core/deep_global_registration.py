@@ -1,11 +1,12 @@
 """`DeepGlobalRegistration` with the reference's constructor / `register()` / stage-method
 surface (core/deep_global_registration.py:67-324), executed on one MI355X by libdgr_hip.so.
 
-Scope: steps 0-5 "case 0" of `register()` -- voxelisation, FCGF features,
-feature matching, 6-D inlier network, confidence gate, weighted Procrustes + robust refinement.
-The Open3D parts (safeguard RANSAC :302-315, ICP :317-322) are out of scope: when the gate fails
-`register()` returns the identity like the reference does before its safeguard, and records
-`last_status = 'low_confidence'`; `use_icp` defaults to False.
+Scope: steps 0-5 of `register()` -- voxelisation, FCGF features, feature
+matching, 6-D inlier network, confidence gate, weighted Procrustes + robust refinement -- plus the two
+Open3D steps around it, re-implemented on the GPU: the safeguard RANSAC from the
+putative correspondences (:50-64, 302-315) when the gate fails or the SVD does not converge, and the
+final point-to-point ICP (:317-322) when `use_icp` is set (the reference's default, :75).  The
+`fcgf_feature_matching` safeguard variant (:31-46) is not implemented.
 """
 import os
 
@@ -39,7 +40,8 @@ class DeepGlobalRegistration:
             raise RuntimeError('DeepGlobalRegistration (MI355X build) runs on the GPU only')
         _lib.load()                      # fail loudly here if the HIP extension is missing
         self.safeguard_method = 'correspondence'
-        self.use_icp = False             # Open3D ICP is out of scope
+        self.use_icp = bool(_cfg_get(config, 'use_icp', True))   # reference: self.use_icp = True (:75)
+        self.ransac_seed = int(_cfg_get(config, 'ransac_seed', 0))
         self.feat_timer = Timer()
         self.reg_timer = Timer()
         self.last_status = None
@@ -131,14 +133,25 @@ class DeepGlobalRegistration:
         sinput = SparseTensor(inlier_feats, coordinates=coords, device=self.device)
         return self.inlier_model(sinput).F
 
-    def safeguard_registration(self, *args, **kwargs):
-        raise NotImplementedError('Open3D RANSAC safeguard is out of scope of the MI355X hot path '
-                                  '(SURVEY.md section 8f rank 2)')
+    def safeguard_registration(self, pcd0, pcd1, idx0, idx1, feats0, feats1, distance_threshold,
+                               num_iterations):
+        """Safeguard (:219-236): RANSAC over the putative correspondences.  `pcd0` / `pcd1` are the
+        voxelised xyz tensors (the reference wraps them into Open3D clouds).  Like the reference's call
+        (RANSACConvergenceCriteria(4000000, num_iterations) with the second argument clamped to
+        confidence 1.0), all 4 000 000 hypotheses are evaluated; `num_iterations` is accepted and unused."""
+        if self.safeguard_method != 'correspondence':
+            raise ValueError('Undefined')   # :235; 'fcgf_feature_matching' (:31-46) is not implemented
+        idx0 = torch.as_tensor(idx0, device=self.device).long()
+        X = pcd0 if len(idx0) == len(pcd0) and bool((idx0 == torch.arange(len(idx0), device=self.device)).all()) \
+            else ops.gather_rows3(pcd0, idx0)
+        Y = ops.gather_rows3(pcd1, torch.as_tensor(idx1, device=self.device).long())
+        T, h, count, rmse = ops.ransac_correspondence(X, Y, distance_threshold, 4000000, seed=self.ransac_seed)
+        self.last_stats = {'ransac_hypothesis': h, 'ransac_inliers': count, 'ransac_rmse': rmse}
+        return T
 
     # ---- main entry ------------------------------------------------------------------------------
     def register(self, xyz0, xyz1, inlier_thr=0.00):
-        """Main algorithm (:238-324) without the Open3D safeguard / ICP.  Returns a 4x4 float64
-        numpy transformation."""
+        """Main algorithm (:238-324).  Returns a 4x4 float64 numpy transformation."""
         self.reg_timer.tic()
         xyz0, coords0, feats0 = self.preprocess(xyz0)
         xyz1, coords1, feats1 = self.preprocess(xyz1)
@@ -157,7 +170,8 @@ class DeepGlobalRegistration:
 
         wsum_threshold = max(200, len(weights) * 0.05)
         T = np.identity(4)
-        if wsum >= wsum_threshold:
+        safeguard = wsum < wsum_threshold
+        if not safeguard:
             try:
                 rot, trans, opt_output = GlobalRegistration(xyz0, ops.gather_rows3(xyz1, corres_idx1),
                                                             weights=weights, break_threshold_ratio=1e-4,
@@ -167,10 +181,17 @@ class DeepGlobalRegistration:
                 T[0:3, 3] = trans.detach().cpu().numpy()
                 self.last_status, self.last_stats = 'ok', opt_output
             except RuntimeError:
-                self.last_status = 'svd_failed'   # reference: "Will directly go to Safeguard" (:295-300)
+                self.last_status = 'svd_failed'   # reference: "Will directly go to Safeguard" (:295-300);
+                # there T simply stays the identity -- the SVD branch never reaches the `else` below
         else:
-            self.last_status = 'low_confidence'    # reference: safeguard RANSAC (:302-315), out of scope
+            # Case 1 (:302-315): safeguard RANSAC on the putative correspondences
+            T = self.safeguard_registration(xyz0, xyz1, corres_idx0, corres_idx1, feats0, feats1,
+                                            2 * self.voxel_size, num_iterations=80000)
+            self.last_status = 'safeguard'
         self.reg_timer.toc()
+        if self.use_icp:                       # :317-322
+            T, fitness, rmse, iters = ops.icp_point_to_point(xyz0, xyz1, self.voxel_size * 2, init=T)
+            self.last_icp = {'fitness': fitness, 'inlier_rmse': rmse, 'iterations': iters}
         return T
 
     # ---- batched throughput path (no reference counterpart) ---------------

@@ -269,6 +269,52 @@ def se3_refine(X, Y, w, quantization_size=1.0, max_iter=1000, max_break_count=20
             {'iterations': it.value, 'loss': loss.value, 'break_count': bc.value})
 
 
+def _xyz_dev(a, dev=None):
+    t = a if torch.is_tensor(a) else torch.as_tensor(np.asarray(a))
+    if dev is None:
+        dev = t.device if t.is_cuda else torch.device('cuda', torch.cuda.current_device())
+    t = t.to(device=dev, dtype=torch.float32).contiguous()
+    if t.dim() != 2 or t.shape[1] != 3:
+        raise ValueError(f'expected [N,3] points, got {tuple(t.shape)}')
+    return t
+
+
+def icp_point_to_point(source, target, max_correspondence_distance, init=None, max_iter=30,
+                       relative_fitness=1e-6, relative_rmse=1e-6):
+    """Point-to-point ICP (dgr_icp_point_to_point).  Returns (T [4,4] float64, fitness, inlier_rmse,
+    iterations)."""
+    lib = _lib.load()
+    src = _xyz_dev(source)
+    dst = _xyz_dev(target, src.device)
+    Ti = None
+    if init is not None:
+        init = np.ascontiguousarray(np.asarray(init, np.float64))
+        if init.shape != (4, 4):
+            raise ValueError('init must be a 4x4 matrix')
+        Ti = (C.c_double * 16)(*init.reshape(-1))
+    T = (C.c_double * 16)()
+    st = (C.c_double * 3)()
+    check(lib.dgr_icp_point_to_point(get_ctx(src.device), ptr(src), src.shape[0], ptr(dst), dst.shape[0],
+                                     float(max_correspondence_distance), Ti, int(max_iter), float(relative_fitness),
+                                     float(relative_rmse), T, st, stream_ptr(src.device.index)))
+    return np.array(T, np.float64).reshape(4, 4), float(st[0]), float(st[1]), int(st[2])
+
+
+def ransac_correspondence(X, Y, distance_threshold, num_hypotheses, seed=0):
+    """RANSAC over corresponding points X[i] <-> Y[i] (dgr_ransac_correspondence).  Returns
+    (T [4,4] float64, best hypothesis index, inlier count, inlier rmse)."""
+    lib = _lib.load()
+    X = _xyz_dev(X)
+    Y = _xyz_dev(Y, X.device)
+    if X.shape != Y.shape:
+        raise ValueError('X and Y must have the same shape')
+    T = (C.c_double * 16)()
+    st = (C.c_double * 3)()
+    check(lib.dgr_ransac_correspondence(get_ctx(X.device), ptr(X), ptr(Y), X.shape[0], float(distance_threshold),
+                                        int(num_hypotheses), int(seed) & 0xffffffff, T, st, stream_ptr(X.device.index)))
+    return np.array(T, np.float64).reshape(4, 4), int(st[0]), int(st[1]), float(st[2])
+
+
 # ----------------------------------------------------------------------------
 def register_batch(fcgf, inlier, coords0, xyz0, off0, coords1, xyz1, off1, voxel_size,
                    clip_weight_thresh=0.05, inlier_feature_type='coords', max_iter=1000,

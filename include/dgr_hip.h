@@ -159,6 +159,27 @@ int dgr_se3_refine(dgr_ctx *ctx, const float *X, const float *Y, const float *w,
                    double break_threshold_ratio, float *R9, float *t3, int32_t *iterations,
                    float *loss, int32_t *break_count, dgr_stream stream);
 
+/* ---- ICP: replaces o3d.pipelines.registration.registration_icp(source, target,
+ * max_correspondence_distance = 2 * voxel, init = T) at core/deep_global_registration.py:317-322
+ * (point-to-point without scaling; Open3D defaults max_iter 30, relative_fitness = relative_rmse = 1e-6).
+ * src dev f32 [N0,3], dst dev f32 [N1,3]; T_init host f64[16] row-major or NULL (identity).
+ * Host outputs: T_out f64[16]; stats_out f64[3] = {fitness, inlier_rmse, iterations} or NULL.  Synchronises. */
+int dgr_icp_point_to_point(dgr_ctx *ctx, const float *src, int64_t N0, const float *dst, int64_t N1,
+                           double max_correspondence_distance, const double *T_init, int max_iter,
+                           double relative_fitness, double relative_rmse, double *T_out, double *stats_out,
+                           dgr_stream stream);
+
+/* ---- safeguard: replaces registration_ransac_based_on_correspondence(pcd0, pcd1, idx0, idx1,
+ * distance_threshold, num_iterations) at core/deep_global_registration.py:50-64 (called from :302-315 when the
+ * confidence gate fails): ransac_n = 4, point-to-point estimation, no checkers, every hypothesis evaluated,
+ * the best 4-point hypothesis returned.  X = xyz0[idx0], Y = xyz1[idx1] dev f32 [N,3] (dgr_gather_rows3).
+ * Samples come from a counter-based generator (seed) instead of Open3D's per-thread mt19937 streams and the
+ * consensus test runs in f32 without fma, so that the result is reproducible (oracle/open3d_reg.py).
+ * Host outputs: T_out f64[16]; stats_out f64[3] = {best hypothesis index, inlier count, inlier rmse}.  Synchronises. */
+int dgr_ransac_correspondence(dgr_ctx *ctx, const float *X, const float *Y, int64_t N, double distance_threshold,
+                              int64_t num_hypotheses, uint32_t seed, double *T_out, double *stats_out,
+                              dgr_stream stream);
+
 /* ---- fused pipeline: replaces DeepGlobalRegistration.register() steps 1-5 case 0
  * (core/deep_global_registration.py:248-300) for a batch of already voxelised pairs, without
  * intermediate host synchronisation.  Pair p uses rows [off0[p], off0[p+1]) of coords0/xyz0 and

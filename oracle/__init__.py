@@ -21,4 +21,9 @@ Parity status (see DESIGN.md "Oracle"):
   `model/common.py:11-21`); the conventions that cannot be verified here
   (kernel-offset enumeration order, transposed-map convention, quantize
   ordering) live in exactly one function each in `me_semantics.py`.
+* `oracle.open3d_reg`: **parity unpinned** -- Open3D==0.17.0 is not installed
+  and not vendored; restates `RegistrationICP` and
+  `RegistrationRANSACBasedOnCorrespondence` as the reference calls them
+  (`core/deep_global_registration.py:50-64, 302-322`), with a counter-based
+  sampler in place of Open3D's mt19937 streams.
 """

@@ -80,7 +80,7 @@ def test_register_api(setup):
     T = dgr.register(xyz0, xyz1)
     assert T.shape == (4, 4) and T.dtype == np.float64
     np.testing.assert_array_equal(T[3], [0, 0, 0, 1])
-    assert dgr.last_status in ('ok', 'low_confidence')
+    assert dgr.last_status in ('ok', 'safeguard')
     assert dgr.feat_timer.diff > 0 and dgr.reg_timer.avg > 0
     with pytest.raises(Exception, match='Unrecognized pcd type'):
         dgr.register([1, 2, 3], xyz1)
