@@ -208,6 +208,28 @@ class DeepGlobalRegistration:
         return self.register_voxelized(torch.cat(c0), torch.cat(x0), off0, torch.cat(c1), torch.cat(x1), off1,
                                        forced_logits=forced_logits, skip_refinement=skip_refinement)
 
+    def register_collated(self, input_dict, **kw):
+        """Registers every pair of a collated batch in the reference's data-loader layout
+        (`CollationFunctionFactory.collate_pair_fn`, dataloader/base_loader.py:40-98): `sinput0_C` /
+        `sinput1_C` int [N,4] batched coordinates (batch column first, `ME.utils.batched_coordinates`),
+        `pcd0` / `pcd1` sequences of per-pair xyz [Ni,3] aligned with those rows, `len_batch` [[N0,N1],...].
+        Returns T [n,4,4] float64, status [n], stats [n,4]."""
+        len_batch = [(int(a), int(b)) for a, b in input_dict['len_batch']]
+        off0, off1 = [0], [0]
+        for n0, n1 in len_batch:
+            off0.append(off0[-1] + n0)
+            off1.append(off1[-1] + n1)
+        c0 = torch.as_tensor(input_dict['sinput0_C']).to(self.device).int()
+        c1 = torch.as_tensor(input_dict['sinput1_C']).to(self.device).int()
+        x0 = torch.cat([torch.as_tensor(np.asarray(x)).float() for x in input_dict['pcd0']]).to(self.device)
+        x1 = torch.cat([torch.as_tensor(np.asarray(x)).float() for x in input_dict['pcd1']]).to(self.device)
+        if len(c0) != off0[-1] or len(c1) != off1[-1] or len(x0) != off0[-1] or len(x1) != off1[-1]:
+            raise ValueError('len_batch does not match the concatenated coordinates / points')
+        for p in range(len(len_batch)):   # the batch column must be the pair index of the row block
+            if off0[p + 1] > off0[p] and (int(c0[off0[p], 0]) != p or int(c0[off0[p + 1] - 1, 0]) != p):
+                raise ValueError('sinput0_C is not in batched_coordinates order')
+        return self.register_voxelized(c0, x0, off0, c1, x1, off1, **kw)
+
     def register_voxelized(self, coords0, xyz0, off0, coords1, xyz1, off1, forced_logits=None,
                            skip_refinement=False, override_idx1=None):
         T, status, stats = ops.register_batch(

@@ -17,3 +17,33 @@ def find_knn_gpu(F0, F1, nn_max_n=-1, knn=1, return_distance=False):
     else:
         dist = dist.unsqueeze(1)
     return (idx, dist) if return_distance else idx
+
+
+def find_knn_gpu_batch(F0, F1, len_batch, nn_max_n=-1, knn=1, return_distance=False, concat_results=False):
+    """Interface of core/knn.py:106-140: one independent search per pair of a collated batch.  F0 / F1 hold
+    the rows of all pairs back to back and `len_batch` lists (N0, N1) per pair
+    (dataloader/base_loader.py:63-81).  Returns per-pair lists, or -- with `concat_results` -- single
+    tensors whose indices address rows of the concatenated F1."""
+    import itertools
+    import torch
+    sizes = [(int(a), int(b)) for a, b in len_batch]
+    first0 = [0] + list(itertools.accumulate(n0 for n0, _ in sizes))
+    first1 = [0] + list(itertools.accumulate(n1 for _, n1 in sizes))
+    results = [find_knn_gpu(F0[s0:s0 + n0], F1[s1:s1 + n1], nn_max_n=nn_max_n, knn=knn, return_distance=True)
+               for (n0, n1), s0, s1 in zip(sizes, first0, first1)]
+    idx = [i + s1 if concat_results else i for (i, _), s1 in zip(results, first1)]
+    dist = [d for _, d in results]
+    if concat_results:
+        idx, dist = torch.cat(idx), torch.cat(dist)
+    return (idx, dist) if return_distance else idx
+
+
+def find_knn_batch(F0, F1, len_batch, return_distance=False, nn_max_n=-1, knn=1, search_method=None,
+                   concat_results=False):
+    """core/knn.py:76-103.  Only the GPU method exists in this build."""
+    if search_method is None or search_method == 'gpu':
+        return find_knn_gpu_batch(F0, F1, len_batch=len_batch, nn_max_n=nn_max_n, knn=knn,
+                                  return_distance=return_distance, concat_results=concat_results)
+    if search_method == 'cpu':
+        raise ValueError("Search method cpu is not available in the MI355X build (use 'gpu')")
+    raise ValueError(f'Search method {search_method} not defined')

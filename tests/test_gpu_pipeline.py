@@ -152,3 +152,33 @@ def test_low_confidence_status(setup):
     T, status, stats = dgr.register_voxelized(ca, xa, [0, len(xa)], cb, xb, [0, len(xb)], forced_logits=forced)
     assert status.tolist() == [1]
     np.testing.assert_array_equal(T[0], np.eye(4))
+
+
+def test_collated_batch_and_batched_knn(setup):
+    """The data-loader layout (dataloader/base_loader.py:40-98) and find_knn_gpu_batch (core/knn.py:106-140)."""
+    from deepglobalregistration_amd.core.knn import find_knn_batch, find_knn_gpu, find_knn_gpu_batch
+    ck, dgr, pairs = setup
+    x0, c0, x1, c1, len_batch = [], [], [], [], []
+    for p, (a, b, _) in enumerate(pairs):
+        xa, ca, _ = dgr.preprocess(a, batch_index=p)
+        xb, cb, _ = dgr.preprocess(b, batch_index=p)
+        x0.append(xa.cpu().numpy()); c0.append(ca); x1.append(xb.cpu().numpy()); c1.append(cb)
+        len_batch.append([len(xa), len(xb)])
+    batch = {'pcd0': x0, 'pcd1': x1, 'sinput0_C': torch.cat(c0), 'sinput1_C': torch.cat(c1), 'len_batch': len_batch}
+    forced = torch.full((sum(n for n, _ in len_batch),), -6.0).cuda()
+    T, status, stats = dgr.register_collated(batch, forced_logits=forced)
+    assert T.shape == (len(pairs), 4, 4) and status.tolist() == [1] * len(pairs)
+    with pytest.raises(ValueError):
+        dgr.register_collated(dict(batch, len_batch=[[1, 1]]))
+    # batched 1-NN = per-pair 1-NN, shifted by the pair's first row when concatenated
+    rng = np.random.default_rng(0)
+    lens = [[700, 900], [1300, 1100]]
+    F0 = torch.from_numpy(rng.standard_normal((2000, 32)).astype(np.float32)).cuda()
+    F1 = torch.from_numpy(rng.standard_normal((2000, 32)).astype(np.float32)).cuda()
+    per = find_knn_gpu_batch(F0, F1, lens, nn_max_n=250)
+    assert [tuple(t.shape) for t in per] == [(700, 1), (1300, 1)]
+    cat, dist = find_knn_batch(F0, F1, lens, nn_max_n=250, return_distance=True, concat_results=True)
+    ref1 = find_knn_gpu(F0[700:], F1[900:], nn_max_n=250)
+    assert torch.equal(cat[700:], ref1 + 900) and torch.equal(per[1], ref1) and dist.shape == (2000, 1)
+    with pytest.raises(ValueError):
+        find_knn_batch(F0, F1, lens, search_method='tree')
