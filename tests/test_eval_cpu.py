@@ -1,0 +1,108 @@
+"""Evaluation harness and file formats -- host-side, CPU only."""
+import numpy as np
+import pytest
+
+from deepglobalregistration_amd import eval as ev
+
+
+def _pose(rng):
+    q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+    if np.linalg.det(q) < 0:
+        q[:, 0] *= -1
+    T = np.eye(4); T[:3, :3] = q; T[:3, 3] = rng.standard_normal(3)
+    return T
+
+
+def test_rte_rre_matches_reference_definition():
+    import math
+    import sys
+    rng = np.random.default_rng(0)
+    A, B = _pose(rng), _pose(rng)
+    s, rte, rre = ev.rte_rre(A, B, 0.3, 15)
+    assert rte == pytest.approx(np.linalg.norm(A[:3, 3] - B[:3, 3]))
+    assert rre == pytest.approx(math.degrees(math.acos((np.trace(A[:3, :3].T @ B[:3, :3]) - 1) / 2)))
+    assert s == 0
+    np.testing.assert_array_equal(ev.rte_rre(None, B, 0.3, 15), [0, np.inf, np.inf])
+    assert ev.rte_rre(B, B, 0.3, 15)[0] == 1 and ev.rte_rre(B, B, 0.3, 15)[2] < 1e-5
+    try:   # the reference's own function, when the reference tree is present (not on the GPU box)
+        sys.path.insert(0, '/root/reference/scripts')
+        src = open('/root/reference/scripts/test_3dmatch.py').read()
+    except OSError:
+        return
+    ns = {'np': np, 'math': math}
+    start = src.index('def rte_rre'); end = src.index('def analyze_stats')
+    exec(src[start:end], ns)
+    np.testing.assert_allclose(ev.rte_rre(A, B, 0.3, 15), ns['rte_rre'](A, B, 0.3, 15), rtol=1e-12)
+
+
+def test_trajectory_kitti_and_ply_round_trips(tmp_path):
+    rng = np.random.default_rng(1)
+    recs = [([0, 1, 37], _pose(rng)), ([5, 12, 37], _pose(rng))]
+    ev.write_trajectory(tmp_path / 'gt.log', recs)
+    back = ev.read_trajectory(tmp_path / 'gt.log')
+    assert [m for m, _ in back] == [m for m, _ in recs]
+    for (_, a), (_, b) in zip(back, recs):
+        np.testing.assert_array_equal(a, b)
+    # the layout the reference parses: tab / space separated, 4 rows per record
+    (tmp_path / 'hand.log').write_text('0\t 1 \t 2\n1 0 0 0.5\n0 1 0 0\n 0 0 1 0\n0 0 0 1\n')
+    (meta, pose), = ev.read_trajectory(tmp_path / 'hand.log')
+    assert meta == [0, 1, 2] and pose[0, 3] == 0.5
+    with pytest.raises(ValueError):
+        (tmp_path / 'bad.log').write_text('0 1 2\n1 0 0 0\n')
+        ev.read_trajectory(tmp_path / 'bad.log')
+    xyz = rng.standard_normal((100, 3)).astype(np.float32)
+    ev.write_kitti_bin(tmp_path / 'a.bin', xyz, rng.random(100))
+    np.testing.assert_array_equal(ev.read_kitti_bin(tmp_path / 'a.bin'), xyz)
+    pts = rng.standard_normal((57, 3))
+    for binary in (True, False):
+        ev.write_ply(tmp_path / 'c.ply', pts, binary=binary)
+        np.testing.assert_array_equal(ev.read_ply(tmp_path / 'c.ply'), pts)
+        np.testing.assert_array_equal(ev.load_cloud(str(tmp_path / 'c.ply')), pts)
+    # float vertices with extra properties and a face element, as 3DMatch fragments have
+    v = np.zeros(3, dtype=[('x', '<f4'), ('y', '<f4'), ('z', '<f4'), ('red', 'u1'), ('nx', '<f4')])
+    v['x'], v['y'], v['z'] = [1, 2, 3], [4, 5, 6], [7, 8, 9]
+    hdr = (b'ply\nformat binary_little_endian 1.0\ncomment made by hand\nelement vertex 3\nproperty float x\n'
+           b'property float y\nproperty float z\nproperty uchar red\nproperty float nx\nelement face 0\n'
+           b'property list uchar int vertex_indices\nend_header\n')
+    (tmp_path / 'f.ply').write_bytes(hdr + v.tobytes())
+    np.testing.assert_array_equal(ev.read_ply(tmp_path / 'f.ply'), [[1, 4, 7], [2, 5, 8], [3, 6, 9]])
+    with pytest.raises(ValueError):
+        ev.load_cloud('cloud.pcd')
+
+
+class _Oracle:
+    """Stand-in method: returns the ground truth for even pairs and the identity for odd ones."""
+
+    def __init__(self, answers):
+        self.answers, self.k = answers, 0
+
+    def register(self, xyz0, xyz1):
+        T = self.answers[self.k]
+        self.k += 1
+        return T
+
+
+def test_harness_on_a_synthetic_trajectory_dataset(tmp_path):
+    rng = np.random.default_rng(2)
+    root = tmp_path / 'threedmatch'
+    poses = {}
+    for s in ('kitchen', 'lab'):
+        (root / s).mkdir(parents=True)
+        (root / f'{s}-evaluation').mkdir()
+        for i in range(3):
+            ev.write_ply(root / s / f'cloud_bin_{i}.ply', rng.standard_normal((40, 3)))
+        recs = [([0, 1, 3], _pose(rng)), ([1, 2, 3], _pose(rng))]
+        poses[s] = recs
+        ev.write_trajectory(root / f'{s}-evaluation' / 'gt.log', recs)
+    ds = ev.ThreeDMatchTrajectory(str(root))
+    assert len(ds) == 4 and ds.scenes == ['kitchen', 'lab']
+    s, a, b, T = ds[3]
+    assert s == 'lab' and a.shape == (40, 3) and np.array_equal(T, poses['lab'][1][1])
+    answers = [np.linalg.inv(ds.files[k][3]) if k % 2 == 0 else np.eye(4) for k in range(4)]
+    lines = []
+    stats, scene_means, summary = ev.evaluate([_Oracle(answers)], ['stub'], ds, out=lines.append)
+    assert stats.shape == (1, 4, 5)
+    np.testing.assert_array_equal(stats[0, :, 0], [1, 0, 1, 0])
+    np.testing.assert_array_equal(stats[0, :, 4], [0, 0, 1, 1])
+    assert summary['stub']['recall'] == 0.5 and summary['stub']['mean_successful'][1] < 1e-9
+    assert scene_means.shape == (1, 2, 3) and scene_means[0, 0, 0] == 0.5 and lines
