@@ -263,7 +263,7 @@ def main():
         st = ops.stage_times(device)
         for k, v in st.items():
             prof[k] = prof.get(k, 0.0) + v
-    launch_ms = ops.conv_launch_times(device)   # last profiled step: FCGF layers, then the inlier net's
+    launch_ms, gemm_ms = ops.conv_launch_times(device)   # last profiled step: FCGF layers, then the inlier net's
     ops.set_profiling(device, False)
     prof = {k: v / args.steps for k, v in prof.items()}
     log(f'profiled region done: {prof}')
@@ -284,7 +284,7 @@ def main():
         n_launch = max(1, int(prof['conv_launches']))
         # the layers SURVEY.md 8d calls HBM-bound (C <= 64): compulsory bytes and gather-scatter traffic
         # (4 P (Cin + 2 Cout) + 8 P + 4 Kne Cin Cout) over their measured launch durations
-        c64 = None
+        c64 = dominant = None
         if len(launch_ms) == len(s_a) + len(s_c):
             per_layer = [dict(a, pairs=a['pairs'] + b['pairs'], n_in=a['n_in'] + b['n_in'], n_out=a['n_out'] + b['n_out'],
                               nonempty=max(a['nonempty'], b['nonempty'])) for a, b in zip(s_a, s_b)] + list(s_c)
@@ -294,6 +294,17 @@ def main():
                     ms64 += ms
                     comp64 += 4.0 * (st['n_in'] * st['cin'] + st['n_out'] * st['cout'] + st['nonempty'] * st['cin'] * st['cout']) + 8.0 * st['pairs']
                     gath64 += 4.0 * st['pairs'] * (st['cin'] + 2 * st['cout']) + 8.0 * st['pairs'] + 4.0 * st['nonempty'] * st['cin'] * st['cout']
+            # the dominant kernel instance: sparse_conv_mfma_v2<256, 1, 4, 2, 2, true> = every 256 -> 256 layer
+            # (block4 of both nets); its average launch duration is what `rocprofv3 --kernel-trace --stats` of
+            # the single-stream command reports for that kernel name (profiles/)
+            dom = [(2.0 * st['pairs'] * st['cin'] * st['cout'], g) for st, g in zip(per_layer, gemm_ms)
+                   if st['cin'] == 256 and st['cout'] == 256]
+            if dom:
+                dominant = {'name': 'sparse_conv_mfma_v2<256, 1, 4, 2, 2, true>', 'launches_per_step': len(dom),
+                            'avg_launch_us': 1e3 * sum(g for _, g in dom) / len(dom),
+                            'gflop_per_step': sum(f for f, _ in dom) / 1e9,
+                            'achieved_tflops': sum(f for f, _ in dom) / (sum(g for _, g in dom) * 1e-3) / 1e12,
+                            'share_of_conv_flop': sum(f for f, _ in dom) / flop}
             if ms64 > 0:
                 c64 = {'layers': sum(1 for st in per_layer if max(st['cin'], st['cout']) <= 64), 'ms_per_step': ms64,
                        'compulsory_gbps': comp64 / ms64 / 1e6, 'gather_scatter_gbps': gath64 / ms64 / 1e6,
@@ -337,7 +348,8 @@ def main():
                          'compulsory_gbytes_per_step': byts / 1e9,
                          'hbm_gbps_compulsory': byts / (conv_ms * 1e-3) / 1e9,
                          'hbm_frac_compulsory': byts / (conv_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
-                         'c_le_64_layers': dict({'gflop': flop64 / 1e9, 'gbytes': byts64 / 1e9}, **(c64 or {}))},
+                         'c_le_64_layers': dict({'gflop': flop64 / 1e9, 'gbytes': byts64 / 1e9}, **(c64 or {})),
+                         'dominant_kernel': dominant},
             'stage_ms_per_step': {k: round(v, 3) for k, v in prof.items() if k != 'conv_launches'},
             'te_m_mean': float(np.mean(te)) if te else None, 're_deg_mean': float(np.mean(re)) if re else None,
             'status': [int(s) for s in status_all.tolist()],

@@ -150,11 +150,14 @@ extern "C" int dgr_ctx_stage_times(dgr_ctx *ctx, float times_ms[8]) {
 
 extern "C" int64_t dgr_ctx_conv_launches(dgr_ctx *ctx) { return ctx ? ctx->conv_launches : 0; }
 
-extern "C" int dgr_ctx_conv_launch_times(dgr_ctx *ctx, float *times_ms, int64_t capacity, int64_t *n) {
+extern "C" int dgr_ctx_conv_launch_times(dgr_ctx *ctx, float *times_ms, float *gemm_ms, int64_t capacity, int64_t *n) {
   DGR_REQUIRE(ctx != nullptr && times_ms != nullptr && n != nullptr, "bad argument");
   int64_t m = (int64_t)ctx->conv_span_ms.size();
   if (m > capacity) m = capacity;
-  for (int64_t i = 0; i < m; ++i) times_ms[i] = ctx->conv_span_ms[i];
+  for (int64_t i = 0; i < m; ++i) {
+    times_ms[i] = ctx->conv_span_ms[i];
+    if (gemm_ms) gemm_ms[i] = i < (int64_t)ctx->gemm_span_ms.size() ? ctx->gemm_span_ms[i] : 0.f;
+  }
   *n = m;
   return DGR_OK;
 }

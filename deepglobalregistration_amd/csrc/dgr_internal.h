@@ -197,8 +197,8 @@ struct dgr_ctx {
   DgrBatchOutputs last;
   DgrEventPool events;
   // event spans recorded while profiling; resolved by dgr_ctx_collect_profile after a sync
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> conv_spans, map3_spans, map6_spans;
-  std::vector<float> conv_span_ms;  // per-launch durations of the last collected profile
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> conv_spans, gemm_spans, map3_spans, map6_spans;
+  std::vector<float> conv_span_ms, gemm_span_ms;  // per-launch durations of the last collected profile
   int32_t *flag_dev = nullptr;  // error flag word of the current top-level call (arena)
 };
 

@@ -228,10 +228,10 @@ struct Fwd {
       a.n_rows_dev = cout_map.n_dev;
       a.tile_bound = dgr_ceil_div(cout_map.n_cap, DGR_TILE_M);
     }
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipEvent_t e0 = nullptr, em = nullptr, e1 = nullptr;
     if (prof) {
-      e0 = ctx->events.next(); e1 = ctx->events.next();
-      if (!e0 || !e1) return DGR_EHIP;
+      e0 = ctx->events.next(); em = ctx->events.next(); e1 = ctx->events.next();
+      if (!e0 || !em || !e1) return DGR_EHIP;
       DGR_HIP_CHECK(hipEventRecord(e0, stream));
     }
     const bool small_cin = km && !swapped && !res && L.cin <= 8 && L.cout == 32 && L.cin_pad == 8;
@@ -240,6 +240,7 @@ struct Fwd {
                                    out.ptr, out.ld, stream));
     else
       DGR_CHECK(dgr_conv_launch(a, ctx->num_cus, stream));
+    if (prof) DGR_HIP_CHECK(hipEventRecord(em, stream));   // end of the MFMA phase
     if (km && !small_cin)
       DGR_CHECK(dgr_reduce_rows(ybuf, L.cout, swapped ? km->in_ptr : km->out_ptr, swapped ? km->in_pos : km->out_pos,
                                 cout_map.n_dev, cout_map.n_cap, out.ptr, out.ld, L.shift, res ? res->ptr : nullptr,
@@ -247,6 +248,7 @@ struct Fwd {
     if (prof) {
       DGR_HIP_CHECK(hipEventRecord(e1, stream));
       ctx->conv_spans.push_back({e0, e1});
+      ctx->gemm_spans.push_back({e0, em});
     }
     LayerRun &r = net->runs[li];
     r.launch = a;
@@ -334,6 +336,7 @@ int dgr_resunet_forward_impl(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, 
     if (f.prof) {
       DGR_HIP_CHECK(hipEventRecord(e1, stream));
       ctx->conv_spans.push_back({e0, e1});
+      ctx->gemm_spans.push_back({e0, e1});
     }
     LayerRun &r0 = net->runs[0];
     r0 = LayerRun();
@@ -389,6 +392,7 @@ int dgr_resunet_forward_impl(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, 
 void dgr_ctx_begin_profile(dgr_ctx *ctx) {
   ctx->events.used = 0;
   ctx->conv_spans.clear();
+  ctx->gemm_spans.clear();
   ctx->map3_spans.clear();
   ctx->map6_spans.clear();
   ctx->conv_launches = 0;
@@ -409,10 +413,16 @@ int dgr_ctx_collect_profile(dgr_ctx *ctx) {
   DGR_CHECK(total(ctx->conv_spans, &ctx->stage_ms[7]));
   ctx->conv_launches = (int64_t)ctx->conv_spans.size();
   ctx->conv_span_ms.clear();
+  ctx->gemm_span_ms.clear();
   for (auto &sp : ctx->conv_spans) {
     float t = 0.f;
     DGR_HIP_CHECK(hipEventElapsedTime(&t, sp.first, sp.second));
     ctx->conv_span_ms.push_back(t);
+  }
+  for (auto &sp : ctx->gemm_spans) {
+    float t = 0.f;
+    DGR_HIP_CHECK(hipEventElapsedTime(&t, sp.first, sp.second));
+    ctx->gemm_span_ms.push_back(t);
   }
   return DGR_OK;
 }

@@ -386,9 +386,10 @@ def stage_times(device):
 
 
 def conv_launch_times(device):
-    """Per-launch durations (ms) of the sparse-conv layers of the last profiled batch, launch order."""
+    """Per-launch durations (ms) of the sparse-conv layers of the last profiled batch in launch order:
+    (MFMA phase + reduce phase, MFMA phase alone)."""
     cap = 4096
-    t = (C.c_float * cap)()
+    t, g = (C.c_float * cap)(), (C.c_float * cap)()
     n = C.c_int64(0)
-    check(_lib.load().dgr_ctx_conv_launch_times(get_ctx(device), t, cap, C.byref(n)))
-    return [float(t[i]) for i in range(n.value)]
+    check(_lib.load().dgr_ctx_conv_launch_times(get_ctx(device), t, g, cap, C.byref(n)))
+    return [float(t[i]) for i in range(n.value)], [float(g[i]) for i in range(n.value)]

@@ -221,9 +221,10 @@ int dgr_ctx_set_profiling(dgr_ctx *ctx, int enable);
 int dgr_ctx_stage_times(dgr_ctx *ctx, float times_ms[8]);
 /* number of sparse-conv kernel launches covered by times_ms[7] */
 int64_t dgr_ctx_conv_launches(dgr_ctx *ctx);
-/* duration (ms) of every sparse-conv layer launch (MFMA phase + reduce phase) of the last profiled
- * batch, in launch order (FCGF layers 0..22, then the inlier net's); *n = number written (<= capacity) */
-int dgr_ctx_conv_launch_times(dgr_ctx *ctx, float *times_ms, int64_t capacity, int64_t *n);
+/* duration (ms) of every sparse-conv layer launch of the last profiled batch, in launch order (FCGF layers
+ * 0..22, then the inlier net's): times_ms = MFMA phase + reduce phase, gemm_ms (nullable) = MFMA phase alone
+ * (the sparse_conv_mfma kernel); *n = number written (<= capacity) */
+int dgr_ctx_conv_launch_times(dgr_ctx *ctx, float *times_ms, float *gemm_ms, int64_t capacity, int64_t *n);
 
 #ifdef __cplusplus
 }
