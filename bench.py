@@ -304,7 +304,10 @@ def main():
                             'avg_launch_us': 1e3 * sum(g for _, g in dom) / len(dom),
                             'gflop_per_step': sum(f for f, _ in dom) / 1e9,
                             'achieved_tflops': sum(f for f, _ in dom) / (sum(g for _, g in dom) * 1e-3) / 1e12,
-                            'share_of_conv_flop': sum(f for f, _ in dom) / flop}
+                            'share_of_conv_flop': sum(f for f, _ in dom) / flop,
+                            'algorithmic_bytes_per_launch': sum(
+                                4.0 * (st['n_in'] * st['cin'] + st['n_out'] * st['cout'] + st['nonempty'] * st['cin'] * st['cout'])
+                                + 8.0 * st['pairs'] for st in per_layer if st['cin'] == 256 and st['cout'] == 256) / len(dom)}
             if ms64 > 0:
                 c64 = {'layers': sum(1 for st in per_layer if max(st['cin'], st['cout']) <= 64), 'ms_per_step': ms64,
                        'compulsory_gbps': comp64 / ms64 / 1e6, 'gather_scatter_gbps': gath64 / ms64 / 1e6,
@@ -322,10 +325,15 @@ def main():
         # HBM traffic of the conv kernels from PMC counters (FETCH_SIZE x 2 + WRITE_SIZE, see
         # profiles/r01_conv_hbm_traffic.json): collected in separate rocprofv3 --pmc passes on the same
         # per-stream workload (4 pairs per batch); not measurable from inside this process
-        traffic = None
+        # (a) the dominant kernel instance (roofline headline) and (b) all conv launches of the batch
+        traffic = traffic_all = None
         tpath = os.path.join(ROOT, 'profiles', 'r01_conv_hbm_traffic.json')
         if os.path.exists(tpath) and B == 4 and args.n_raw == 50000 and args.conv1_ks == 7:
-            traffic = json.load(open(tpath))['per_conv_launch_bytes']['total']
+            tj = json.load(open(tpath))
+            traffic_all = tj['per_conv_launch_bytes']['total']
+            for kname, kv in tj['kernels'].items():
+                if dominant and dominant['name'] in kname and kv['dispatches']:
+                    traffic = (2.0 * kv['FETCH_SIZE_KB'] + kv['WRITE_SIZE_KB']) * 1024.0 / kv['dispatches']
         ms_per_step = elapsed / args.steps * 1e3
         out = {
             'metric': 'pair registrations/sec (FCGF x2 + 1-NN + 6-D inlier net + gate + weighted Procrustes + SE(3) refinement)',
@@ -339,17 +347,26 @@ def main():
                        'voxels_per_pair': [int(off0[-1] / B), int(off1[-1] / B)],
                        'pairs_per_step_per_gpu': S * B, 'refinement': not args.no_refine,
                        'parallelism': f'pair-sharded x{world}, no data-path collective'},
-            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
-                         'traffic_unit': 'HBM bytes per conv launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE)',
-                         'algorithmic_bytes_per_launch': byts / n_launch,
-                         'kernel': 'sparse_conv_mfma', 'launches_per_step': n_launch,
-                         'avg_launch_us': conv_ms * 1e3 / n_launch, 'gflop_per_step': flop / 1e9,
-                         'compulsory_gbytes_per_step': byts / 1e9,
-                         'hbm_gbps_compulsory': byts / (conv_ms * 1e-3) / 1e9,
-                         'hbm_frac_compulsory': byts / (conv_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
-                         'c_le_64_layers': dict({'gflop': flop64 / 1e9, 'gbytes': byts64 / 1e9}, **(c64 or {})),
-                         'dominant_kernel': dominant},
+            # roofline of the DOMINANT kernel (76 % of the conv FLOPs): algorithmic FLOP per launch / its average
+            # launch duration (HIP events on the launch stream); `all_conv_layers` is the same over all 46 launches
+            'roofline': {'bound': 'mfma', 'achieved': dominant['achieved_tflops'] if dominant else achieved,
+                         'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': (dominant['achieved_tflops'] if dominant else achieved) / PEAK_FP32_MFMA_TFLOPS,
+                         'traffic': traffic,
+                         'traffic_unit': 'HBM bytes per launch of the kernel (PMC: 2 x FETCH_SIZE + WRITE_SIZE)',
+                         'kernel': dominant['name'] if dominant else 'sparse_conv_mfma (all instances)',
+                         'launches_per_step': dominant['launches_per_step'] if dominant else n_launch,
+                         'avg_launch_us': dominant['avg_launch_us'] if dominant else conv_ms * 1e3 / n_launch,
+                         'gflop_per_launch': (dominant['gflop_per_step'] / dominant['launches_per_step']) if dominant else flop / 1e9 / n_launch,
+                         'share_of_conv_flop': dominant['share_of_conv_flop'] if dominant else 1.0,
+                         'algorithmic_bytes_per_launch': dominant['algorithmic_bytes_per_launch'] if dominant else byts / n_launch,
+                         'all_conv_layers': {'achieved': achieved, 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
+                                             'kernel': 'sparse_conv_mfma_v2<*> + reduce_rows (every layer launch)',
+                                             'launches_per_step': n_launch, 'avg_launch_us': conv_ms * 1e3 / n_launch,
+                                             'gflop_per_step': flop / 1e9, 'compulsory_gbytes_per_step': byts / 1e9,
+                                             'traffic': traffic_all, 'algorithmic_bytes_per_launch': byts / n_launch,
+                                             'hbm_gbps_compulsory': byts / (conv_ms * 1e-3) / 1e9},
+                         'c_le_64_layers': dict({'gflop': flop64 / 1e9, 'gbytes': byts64 / 1e9}, **(c64 or {}))},
             'stage_ms_per_step': {k: round(v, 3) for k, v in prof.items() if k != 'conv_launches'},
             'te_m_mean': float(np.mean(te)) if te else None, 're_deg_mean': float(np.mean(re)) if re else None,
             'status': [int(s) for s in status_all.tolist()],

@@ -195,7 +195,7 @@ class DeepGlobalRegistration:
         return T
 
     # ---- batched throughput path (no reference counterpart) ---------------
-    def register_batch(self, pairs, forced_logits=None, skip_refinement=False):
+    def register_batch(self, pairs, forced_logits=None, skip_refinement=False, safeguard=False, icp=False):
         """Registers a list of (xyz0, xyz1) pairs with ONE sparse tensor per network (pairs are
         distinguished by the batch column, the layout of ME.utils.batched_coordinates).  Returns
         T [n,4,4] float64, status [n] (0 ok / 1 low confidence / 2 SVD failed), stats [n,4]."""
@@ -206,7 +206,8 @@ class DeepGlobalRegistration:
             x0.append(xa); c0.append(ca); x1.append(xb); c1.append(cb)
             off0.append(off0[-1] + len(xa)); off1.append(off1[-1] + len(xb))
         return self.register_voxelized(torch.cat(c0), torch.cat(x0), off0, torch.cat(c1), torch.cat(x1), off1,
-                                       forced_logits=forced_logits, skip_refinement=skip_refinement)
+                                       forced_logits=forced_logits, skip_refinement=skip_refinement,
+                                       safeguard=safeguard, icp=icp)
 
     def register_collated(self, input_dict, **kw):
         """Registers every pair of a collated batch in the reference's data-loader layout
@@ -231,10 +232,29 @@ class DeepGlobalRegistration:
         return self.register_voxelized(c0, x0, off0, c1, x1, off1, **kw)
 
     def register_voxelized(self, coords0, xyz0, off0, coords1, xyz1, off1, forced_logits=None,
-                           skip_refinement=False, override_idx1=None):
+                           skip_refinement=False, override_idx1=None, safeguard=False, icp=False):
+        """Fused batched path (one `dgr_register_batch`).  With `safeguard`, pairs that fail the confidence
+        gate (status 1) or the SVD (status 2) are re-estimated by the RANSAC safeguard over their putative
+        correspondences and get status 3; with `icp`, every pair is finally refined by point-to-point ICP
+        -- the two Open3D steps of `register()` (:302-322), run per pair after the batched call."""
         T, status, stats = ops.register_batch(
             self.fcgf_model._handle(), self.inlier_model._handle(), coords0, xyz0, off0, coords1, xyz1, off1,
             self.voxel_size, clip_weight_thresh=self.clip_weight_thresh,
             inlier_feature_type=self.inlier_feature_type, break_threshold_ratio=1e-4,
             skip_refinement=skip_refinement, forced_logit=forced_logits, override_idx1=override_idx1)
-        return T.astype(np.float64), status, stats
+        T = T.astype(np.float64)
+        if safeguard or icp:
+            # the correspondences live in the context's workspace: take them before the next library call
+            idx1 = ops.batch_output(self.device, 'idx1') if safeguard and (status != 0).any() else None
+            xyz0 = torch.as_tensor(xyz0).to(self.device).float()
+            xyz1 = torch.as_tensor(xyz1).to(self.device).float()
+            for p in range(len(status)):
+                s0, e0, s1, e1 = int(off0[p]), int(off0[p + 1]), int(off1[p]), int(off1[p + 1])
+                if safeguard and status[p] != 0:
+                    Y = ops.gather_rows3(xyz1, idx1[s0:e0])
+                    T[p], _, _, _ = ops.ransac_correspondence(xyz0[s0:e0], Y, 2 * self.voxel_size, 4000000,
+                                                              seed=self.ransac_seed)
+                    status[p] = 3
+                if icp:
+                    T[p] = ops.icp_point_to_point(xyz0[s0:e0], xyz1[s1:e1], 2 * self.voxel_size, init=T[p])[0]
+        return T, status, stats

@@ -119,3 +119,28 @@ def test_register_runs_safeguard_and_icp():
     assert dgr.last_status in ('ok', 'safeguard')
     assert abs(np.linalg.det(T[:3, :3]) - 1) < 1e-6      # f32 rotation when the learned path ran
     assert 'iterations' in dgr.last_icp
+
+
+def test_batched_call_with_safeguard_and_icp():
+    """Pairs rejected by the gate inside the fused batched call are rescued by the safeguard (status 3) and
+    refined by ICP; with 20 % ground-truth matches among the putative correspondences RANSAC finds the pose."""
+    from deepglobalregistration_amd import synth
+    from deepglobalregistration_amd.core.deep_global_registration import DeepGlobalRegistration
+    dgr = DeepGlobalRegistration({'weights': synth.synth_checkpoint(0)}, torch.device('cuda'))
+    pairs = [synth.synth_pair(s, 20000) for s in (0, 1)]
+    x0, c0, x1, c1, off0, off1, ov = [], [], [], [], [0], [0], []
+    for p, (a, b, T_gt) in enumerate(pairs):
+        xa, ca, _ = dgr.preprocess(a, batch_index=p)
+        xb, cb, _ = dgr.preprocess(b, batch_index=p)
+        gt = synth.gt_correspondences(xa.cpu().numpy(), xb.cpu().numpy(), T_gt, 0.05)
+        keep = np.random.default_rng(p).random(len(gt)) < 0.5
+        ov.append(np.where((gt >= 0) & keep, gt + off1[-1], -1))
+        x0.append(xa); c0.append(ca); x1.append(xb); c1.append(cb)
+        off0.append(off0[-1] + len(xa)); off1.append(off1[-1] + len(xb))
+    forced = torch.full((off0[-1],), -6.0).cuda()          # the gate rejects everything
+    T, status, _ = dgr.register_voxelized(torch.cat(c0), torch.cat(x0), off0, torch.cat(c1), torch.cat(x1), off1,
+                                          forced_logits=forced, override_idx1=torch.from_numpy(np.concatenate(ov)).cuda(),
+                                          safeguard=True, icp=True)
+    assert status.tolist() == [3, 3]
+    for p, (_, _, T_gt) in enumerate(pairs):
+        assert rot_angle_deg(T[p, :3, :3], T_gt[:3, :3]) < 2.0 and np.linalg.norm(T[p, :3, 3] - T_gt[:3, 3]) < 0.1
