@@ -140,7 +140,9 @@ class DeepGlobalRegistration:
         (RANSACConvergenceCriteria(4000000, num_iterations) with the second argument clamped to
         confidence 1.0), all 4 000 000 hypotheses are evaluated; `num_iterations` is accepted and unused."""
         if self.safeguard_method != 'correspondence':
-            raise ValueError('Undefined')   # :235; 'fcgf_feature_matching' (:31-46) is not implemented
+            # :235.  The reference's other branch, 'fcgf_feature_matching' (:31-46), calls the pre-0.10
+            # `o3d.registration` namespace, which does not exist in the pinned open3d==0.17.0: dead code there.
+            raise ValueError('Undefined')
         idx0 = torch.as_tensor(idx0, device=self.device).long()
         X = pcd0 if len(idx0) == len(pcd0) and bool((idx0 == torch.arange(len(idx0), device=self.device)).all()) \
             else ops.gather_rows3(pcd0, idx0)

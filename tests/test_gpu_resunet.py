@@ -1,6 +1,6 @@
 """GPU parity: ResUNetBN2C forward (3-D FCGF and 6-D inlier net) against the CPU oracle.
 Tolerance: f32 conv stack, |err| <= 1e-4 * max|activation| per compared tensor (the HIP path
-folds batch norm into the kernels and accumulates with f32 atomics in arbitrary order)."""
+folds batch norm into the kernels; its sums run in the oracle's order and are bit-reproducible)."""
 import numpy as np
 import pytest
 import torch
@@ -100,3 +100,24 @@ def test_forward_is_bit_reproducible():
     a = net.forward(coords, ones)
     b = net.forward(coords, ones)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('case', ['batch_index_70', 'far_apart', 'cin3_k5'])
+def test_fused_conv1_fallback_and_variants(case):
+    """FCGF conv1 is fused with its neighbour search over a dense voxel grid; batch indices >= 64 or a
+    bounding box beyond the cell budget fall back (on the device, no host sync) to the hash-probe kernel.
+    All variants must agree with the oracle."""
+    rng = np.random.default_rng(13)
+    a = random_cloud_coords(rng, 1500, 16, 3, batch=0)
+    b = random_cloud_coords(rng, 1500, 16, 3, batch=1)
+    cin, ks = 1, 7
+    if case == 'batch_index_70':
+        b[:, 0] = 70
+    elif case == 'far_apart':            # 2 points 3e6 voxels apart: bbox volume >> 64 M cells
+        b[:, 1:] += np.array([0, 3000000, 0], np.int32)
+        b[:, 0] = 0
+    else:
+        cin, ks = 3, 5
+    coords = np.concatenate([a, b])
+    feats = np.ones((len(coords), 1), np.float32) if cin == 1 else rng.standard_normal((len(coords), cin)).astype(np.float32)
+    _check(3, cin, 32, ks, True, coords, feats, seed=3)
