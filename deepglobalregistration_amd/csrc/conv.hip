@@ -233,6 +233,9 @@ static int launch_cfg(const ConvKArgs &ka, int64_t tile_bound, int num_cus, hipS
 //   * MFMA operands are swapped (D = W^T . In^T): a lane owns one pair and 4 x 4 consecutive output
 //     channels, so product rows leave as 16-byte stores.
 //   * row indices travel through a 4-slot LDS ring, loaded two tiles ahead.
+// Timing ablations for tools/layer_bench.py (results in DESIGN.md 4.2; outputs are garbage): -DDGR_ABL_NOGATHER,
+// -DDGR_ABL_BONCE (weight operands loaded once), -DDGR_ABL_STORE0 (product rows to an L2-resident slab),
+// -DDGR_ABL_NOBARRIER; -DDGR_WIDE_CK=64 -DDGR_WIDE_WAVES=3 builds the widest configuration for 3 waves/SIMD.
 // ------------------------------------------------------------------------------------------
 #ifndef DGR_WIDE_CK
 #define DGR_WIDE_CK 128     // phase width (input channels) of the widest configuration
@@ -317,13 +320,14 @@ __global__ void __launch_bounds__(64 * WM * WN, (MB * NB >= 4 ? DGR_WIDE_WAVES :
       const int ch = tid + i * THREADS;
       const int r = ch / C4K, c = cbase + (ch % C4K) * 4;
       int row = idx[r];
-#ifdef DGR_ABL_GATHER_L2
-      if (row >= 0) row &= 63;  // timing ablation: same instruction stream, L2-resident rows
-#endif
       if (VEC) {
         const int rr = max(row, 0);
         const int cc = min(c, a.cin - 4);
+#ifdef DGR_ABL_NOGATHER   // timing ablation: no gather traffic, same landing code
+        G[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#else
         G[i] = *reinterpret_cast<const f32x4 *>(a.in + (int64_t)rr * a.in_ld + cc);
+#endif
         g_ok |= (row >= 0 && c < a.cin) ? (1u << i) : 0u;
       } else {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -403,11 +407,6 @@ __global__ void __launch_bounds__(64 * WM * WN, (MB * NB >= 4 ? DGR_WIDE_WAVES :
     const f32x4 *wk = reinterpret_cast<const f32x4 *>(a.w) + ((int64_t)k * S * NBLK + wn * NB) * 64 + lane;
     const float *arow = As + (q & 1) * TM * LDA + (32 * wm * MB + (lane & 31)) * LDA + 4 * (lane >> 5);
     const int s0 = h * SK;
-#ifdef DGR_A_PREFETCH
-    f32x4 av_next[MB];
-#pragma unroll
-    for (int i = 0; i < MB; ++i) av_next[i] = *reinterpret_cast<const f32x4 *>(arow + i * 32 * LDA);
-#endif
 #pragma unroll
     for (int s = 0; s < SK; ++s) {
       if (s0 + s + RING - 1 < S) {
@@ -422,21 +421,9 @@ __global__ void __launch_bounds__(64 * WM * WN, (MB * NB >= 4 ? DGR_WIDE_WAVES :
       // pin the prefetch HERE: without it the scheduler sinks each load next to its first use
       // (load-to-use distance 0, full L2 latency exposed on every K-step; seen in the ISA)
       __builtin_amdgcn_sched_barrier(0);
-#ifdef DGR_A_PREFETCH
-      // A fragments one K-step ahead: the ds_read latency hides behind this step's MFMAs
-      f32x4 av[MB];
-#pragma unroll
-      for (int i = 0; i < MB; ++i) av[i] = av_next[i];
-      if (s + 1 < SK) {
-#pragma unroll
-        for (int i = 0; i < MB; ++i) av_next[i] = *reinterpret_cast<const f32x4 *>(arow + i * 32 * LDA + (s + 1) * 8);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#else
       f32x4 av[MB];
 #pragma unroll
       for (int i = 0; i < MB; ++i) av[i] = *reinterpret_cast<const f32x4 *>(arow + i * 32 * LDA + s * 8);
-#endif
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -463,11 +450,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (MB * NB >= 4 ? DGR_WIDE_WAVES :
 #pragma unroll
       for (int i = 0; i < MB; ++i) {
         const int r = 32 * (wm * MB + i) + (lane & 31);
-#ifdef DGR_ABL_NOSTORE
-        if (r < cnt && a.cout < 0) {
-#else
         if (r < cnt) {
-#endif
 #ifdef DGR_ABL_STORE0
           float *dst = a.y + (int64_t)(r + 64 * (blockIdx.x & 1023)) * a.y_ld;  // timing ablation: L2-resident product rows
 #else
