@@ -93,7 +93,6 @@ __global__ void __launch_bounds__(64 * WM * WN) sparse_conv_mfma(ConvKArgs a) {
       int vi = -1, vo = -1;
       if (r < count) {
         vi = identity ? pstart + r : a.pair_in[pstart + r];
-        vo = identity ? pstart + r : a.pair_out[pstart + r];
       }
       idx_in[r] = vi;
       idx_out[r] = vo;

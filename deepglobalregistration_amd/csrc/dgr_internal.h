@@ -130,7 +130,7 @@ struct DgrMapSet {
 
 // Builds all coordinate maps and kernel maps of one sparse tensor into `arena`.
 int dgr_build_maps(DgrArena &arena, const int32_t *coords, int64_t N, int D, int conv1_ks,
-                   DgrMapSet *ms, hipStream_t stream, bool skip_conv1_map = false);
+                   DgrMapSet *ms, hipStream_t stream, bool skip_conv1_map = false, bool lean = false);
 // conv1 fused with its neighbour search (D = 3, Cin <= 8, Cout = 32): no kernel map for the ks^3 offsets
 int dgr_conv1_probe(DgrArena &arena, const DgrCoordMap &cm, int ks, const float *in, int in_ld, int cin,
                     const float *w_tiled, const float *shift, float *out, int out_ld, int32_t *pair_count,

@@ -172,14 +172,14 @@ __global__ void __launch_bounds__(KM_THREADS)
   }
 }
 
-// transposed bit matrix: colmask[g * K + k] = rows of 64-row group g that have offset k (one
-// ballot), colsub[g * K + k] = pairs of offset k in the earlier groups of the same 256-row block,
-// counts[k * RB + rb] = pairs of the (offset, block) cell
+// transposed bit matrix: cell[g * K + k] = {rows of 64-row group g that have offset k (one ballot, 2 words),
+// rule-major position of the group's first pair of that offset, 0}; counts[k * RB + rb] = pairs of the
+// (offset, 256-row block) cell.  The position is written in two steps: the pairs of the earlier groups of the
+// same block here, the cell base (exclusive scan of counts) by kmap_cellbase_kernel.
 constexpr int KM_KMAX = 736;
 __global__ void __launch_bounds__(KM_THREADS)
     kmap_colmask(const uint32_t *__restrict__ mask_out, const int32_t *n_out_dev, int K, int KW, int RB,
-                 unsigned long long *__restrict__ colmask, uint8_t *__restrict__ colsub,
-                 int32_t *__restrict__ counts) {
+                 int4 *__restrict__ cell, int32_t *__restrict__ counts) {
   __shared__ unsigned long long bal[KM_THREADS / 64][KM_KMAX];
   const int rb = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -201,22 +201,28 @@ __global__ void __launch_bounds__(KM_THREADS)
 #pragma unroll
     for (int g = 0; g < KM_THREADS / 64; ++g) {
       const unsigned long long m = bal[g][k];
-      const int64_t cell = ((int64_t)rb * (KM_THREADS / 64) + g) * K + k;
-      colmask[cell] = m;
-      colsub[cell] = (uint8_t)run;
+      cell[((int64_t)rb * (KM_THREADS / 64) + g) * K + k] = make_int4((int)(m & 0xffffffffull), (int)(m >> 32), run, 0);
       run += __popcll(m);
     }
     counts[(int64_t)k * RB + rb] = run;
   }
 }
 
-// one thread per (row, mask word): places the pairs of the set offsets
+__global__ void kmap_cellbase_kernel(int4 *__restrict__ cell, const int32_t *__restrict__ base, int K, int RB, int64_t n_cells) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_cells) return;
+  const int64_t g = c / K;
+  const int k = (int)(c - g * K);
+  cell[c].z += base[(int64_t)k * RB + (g >> 2)];
+}
+
+// one thread per (row, mask word): places the pairs of the set offsets.  pair_out / pair_k may be NULL (maps
+// whose consumers never read them): two random stores less per pair.
 __global__ void __launch_bounds__(KM_THREADS)
     kmap_place6(const int32_t *__restrict__ out_coords, const int32_t *n_out_dev,
                 const int32_t *__restrict__ in_coords, const int32_t *__restrict__ in_table, uint32_t in_mask,
-                int ts_in, int K, int KW, int RB, const uint32_t *__restrict__ mask_out,
-                const int32_t *__restrict__ out_ptr, const unsigned long long *__restrict__ colmask,
-                const uint8_t *__restrict__ colsub, const int32_t *__restrict__ base,
+                int ts_in, int K, int KW, const uint32_t *__restrict__ mask_out,
+                const int32_t *__restrict__ out_ptr, const int4 *__restrict__ cell,
                 int32_t *__restrict__ pair_in, int32_t *__restrict__ pair_out, uint16_t *__restrict__ pair_k,
                 int32_t *__restrict__ out_pos, int64_t pair_cap, int32_t *overflow,
                 const uint32_t *__restrict__ mask_in, const int32_t *__restrict__ in_ptr,
@@ -234,7 +240,6 @@ __global__ void __launch_bounds__(KM_THREADS)
 #pragma unroll
   for (int d = 0; d < 7; ++d) co[d] = out_coords[o * 7 + d];
   const int64_t g = o >> 6;
-  const int rb = (int)(o >> 8);
   const unsigned long long below = (1ull << (o & 63)) - 1ull;
   while (m) {
     const int b = __ffs(m) - 1;
@@ -249,12 +254,13 @@ __global__ void __launch_bounds__(KM_THREADS)
       kk /= 3;
     }
     const int in = dgr_lookup<7>(in_table, in_mask, in_coords, q);
-    const int64_t cell = g * K + k;
-    const int64_t pos = (int64_t)base[(int64_t)k * RB + rb] + colsub[cell] + __popcll(colmask[cell] & below);
+    const int4 c = cell[g * K + k];   // ONE 16-byte read: column ballot + position of the group's first pair
+    const unsigned long long cm = ((unsigned long long)(uint32_t)c.y << 32) | (uint32_t)c.x;
+    const int64_t pos = (int64_t)c.z + __popcll(cm & below);
     if (pos < pair_cap && slot < pair_cap && in >= 0) {
       pair_in[pos] = in;
-      pair_out[pos] = (int32_t)o;
-      pair_k[pos] = (uint16_t)k;
+      if (pair_out) pair_out[pos] = (int32_t)o;
+      if (pair_k) pair_k[pos] = (uint16_t)k;
       out_pos[slot] = (int32_t)pos;
       if (mask_in) in_pos[in_ptr[in] + mask_rank(mask_in + (int64_t)in * KW, k)] = (int32_t)pos;
     } else {
@@ -300,8 +306,8 @@ __global__ void __launch_bounds__(KM_THREADS)
       const int64_t pos = base + __popcll(m & ((1ull << lane) - 1ull));
       if (pos < pair_cap) {
         pair_in[pos] = hit;
-        pair_out[pos] = (int32_t)o;
-        pair_k[pos] = (uint16_t)k;
+        if (pair_out) pair_out[pos] = (int32_t)o;
+        if (pair_k) pair_k[pos] = (uint16_t)k;
         // CSR slot = row start + number of this row's offsets below k (ascending-k order per row)
         out_pos[out_ptr[o] + mask_rank(mask_out + o * KW, k)] = (int32_t)pos;
         if (mask_in) in_pos[in_ptr[hit] + mask_rank(mask_in + (int64_t)hit * KW, k)] = (int32_t)pos;
@@ -358,7 +364,8 @@ __global__ void tile_desc_kernel(const int32_t *__restrict__ tile_ptr, const int
 template <int D>
 static int build_kernel_map_t(DgrArena &arena, const DgrCoordMap &in, const DgrCoordMap &out,
                               const DgrHalfBuckets *in_buckets, int ks, int max_pairs_per_row,
-                              bool need_in_csr, DgrKernelMap *km, int32_t *overflow, hipStream_t stream) {
+                              bool need_in_csr, bool want_pair_out, bool want_pair_k, DgrKernelMap *km,
+                              int32_t *overflow, hipStream_t stream) {
   int K = 1;
   for (int d = 0; d < D; ++d) K *= ks;
   DGR_REQUIRE(K <= 1024, "kernel volume %d > 1024 not supported", K);
@@ -371,12 +378,14 @@ static int build_kernel_map_t(DgrArena &arena, const DgrCoordMap &in, const DgrC
   DGR_ALLOC(km->rule_ptr, arena, int32_t, K + 1);
   DGR_ALLOC(km->tile_ptr, arena, int32_t, K + 1);
   DGR_ALLOC(km->pair_in, arena, int32_t, km->pair_cap);
-  DGR_ALLOC(km->pair_out, arena, int32_t, km->pair_cap);
+  km->pair_out = nullptr;
+  if (want_pair_out) DGR_ALLOC(km->pair_out, arena, int32_t, km->pair_cap);
   km->tile_cap = km->pair_cap / DGR_TILE_M + K;
   DGR_ALLOC(km->tile_desc, arena, int4, km->tile_cap);
   DGR_ALLOC(km->out_ptr, arena, int32_t, n_cap + 1);
   DGR_ALLOC(km->out_pos, arena, int32_t, km->pair_cap);
-  DGR_ALLOC(km->pair_k, arena, uint16_t, km->pair_cap);
+  km->pair_k = nullptr;
+  if (want_pair_k) DGR_ALLOC(km->pair_k, arena, uint16_t, km->pair_cap);
   const int64_t n_in_cap = in.n_cap;
   if (need_in_csr) {
     DGR_ALLOC(km->in_ptr, arena, int32_t, n_in_cap + 1);
@@ -401,13 +410,12 @@ static int build_kernel_map_t(DgrArena &arena, const DgrCoordMap &in, const DgrC
     DGR_HIP_CHECK(hipMemsetAsync(mask_in, 0, (size_t)(n_in_cap + 1) * KW * sizeof(uint32_t), stream));
   }
   int32_t *hits = nullptr;
-  unsigned long long *colmask = nullptr;
-  uint8_t *colsub = nullptr;
+  int4 *cell = nullptr;
+  int64_t n_cells = 0;
   if constexpr (D == 6) {
     DGR_REQUIRE(ks == 3, "6-D kernel maps support kernel size 3 only (got %d)", ks);
-    const int64_t cells = (int64_t)RB * (KM_THREADS / 64) * K;
-    DGR_ALLOC(colmask, arena, unsigned long long, cells);
-    DGR_ALLOC(colsub, arena, uint8_t, cells);
+    n_cells = (int64_t)RB * (KM_THREADS / 64) * K;
+    DGR_ALLOC(cell, arena, int4, n_cells);
     // same-stride maps (in and out are the SAME coordinate set) are symmetric: search half the offsets
     const int symmetric = (in.coords == out.coords && !need_in_csr) ? 1 : 0;
     if (in_buckets && in_buckets->built && ks == 3) {
@@ -420,7 +428,7 @@ static int build_kernel_map_t(DgrArena &arena, const DgrCoordMap &in, const DgrC
                                                     in.ts, K, KW, symmetric, mask_out, mask_in);
     }
     DGR_LAUNCH_CHECK();
-    kmap_colmask<<<RB, KM_THREADS, 0, stream>>>(mask_out, out.n_dev, K, KW, RB, colmask, colsub, counts);
+    kmap_colmask<<<RB, KM_THREADS, 0, stream>>>(mask_out, out.n_dev, K, KW, RB, cell, counts);
   } else {
     DGR_ALLOC(hits, arena, int32_t, (int64_t)K * n_cap);
     dim3 grid(RB, K);
@@ -442,11 +450,11 @@ static int build_kernel_map_t(DgrArena &arena, const DgrCoordMap &in, const DgrC
   tile_desc_kernel<<<(int)dgr_ceil_div(km->tile_cap, 256), 256, 0, stream>>>(km->tile_ptr, km->rule_ptr, K,
                                                                             km->tile_desc, km->tile_cap);
   if constexpr (D == 6) {
+    kmap_cellbase_kernel<<<(int)dgr_ceil_div(n_cells, 256), 256, 0, stream>>>(cell, base, K, RB, n_cells);
     const int64_t threads = n_cap * KW;
     kmap_place6<<<(int)dgr_ceil_div(threads, KM_THREADS), KM_THREADS, 0, stream>>>(
-        out.coords, out.n_dev, in.coords, in.table, in.table_mask, in.ts, K, KW, RB, mask_out, km->out_ptr, colmask,
-        colsub, base, km->pair_in, km->pair_out, km->pair_k, km->out_pos, km->pair_cap, overflow, mask_in,
-        km->in_ptr, km->in_pos);
+        out.coords, out.n_dev, in.coords, in.table, in.table_mask, in.ts, K, KW, mask_out, km->out_ptr, cell,
+        km->pair_in, km->pair_out, km->pair_k, km->out_pos, km->pair_cap, overflow, mask_in, km->in_ptr, km->in_pos);
   } else {
     dim3 fill_grid(RB, (K + KM_KGROUP - 1) / KM_KGROUP);
     kmap_fill<<<fill_grid, KM_THREADS, 0, stream>>>(out.n_dev, RB, K, n_cap, hits, counts, base, km->pair_in,
@@ -464,7 +472,7 @@ int dgr_build_coord_maps(DgrArena &arena, const int32_t *coords, int64_t N, DgrM
 int dgr_build_half_buckets(DgrArena &arena, const DgrCoordMap &cm, DgrHalfBuckets *hb, hipStream_t stream);
 
 int dgr_build_maps(DgrArena &arena, const int32_t *coords, int64_t N, int D, int conv1_ks,
-                   DgrMapSet *ms, hipStream_t stream, bool skip_conv1_map) {
+                   DgrMapSet *ms, hipStream_t stream, bool skip_conv1_map, bool lean) {
   DGR_REQUIRE(D == 3 || D == 6, "D=%d not supported (the DGR path uses D=3 and D=6)", D);
   DGR_REQUIRE(conv1_ks % 2 == 1 && conv1_ks >= 1, "conv1 kernel size must be odd");
   DGR_REQUIRE(N > 0 && N < (1ll << 30), "N=%lld out of range", (long long)N);
@@ -484,18 +492,22 @@ int dgr_build_maps(DgrArena &arena, const int32_t *coords, int64_t N, int D, int
     // share only a few hundred first halves and the generic 729-probe search is as cheap
     for (int l = 0; l < 3; ++l) DGR_CHECK(dgr_build_half_buckets(arena, ms->cm[l], &ms->hb[l], stream));
   }
+  // `lean` (the network forward): pair_out is only read by the transposed convs (strided maps used swapped),
+  // pair_k only by the small-Cin conv1 (same[0] / the conv1 map); the stand-alone maps object keeps everything
   auto build = [&](const DgrCoordMap &in, const DgrCoordMap &out, const DgrHalfBuckets *hb, int ks, bool rev,
-                   DgrKernelMap *km) -> int {
-    if (D == 3) return build_kernel_map_t<3>(arena, in, out, nullptr, ks, cap_row, rev, km, ms->overflow, stream);
-    return build_kernel_map_t<6>(arena, in, out, hb, ks, cap_row, rev, km, ms->overflow, stream);
+                   bool want_k, DgrKernelMap *km) -> int {
+    const bool want_out = !lean || rev, want_pk = !lean || want_k;
+    if (D == 3)
+      return build_kernel_map_t<3>(arena, in, out, nullptr, ks, cap_row, rev, want_out, want_pk, km, ms->overflow, stream);
+    return build_kernel_map_t<6>(arena, in, out, hb, ks, cap_row, rev, want_out, want_pk, km, ms->overflow, stream);
   };
-  for (int l = 0; l < 4; ++l) DGR_CHECK(build(ms->cm[l], ms->cm[l], &ms->hb[l], 3, false, &ms->same[l]));
+  for (int l = 0; l < 4; ++l) DGR_CHECK(build(ms->cm[l], ms->cm[l], &ms->hb[l], 3, false, l == 0, &ms->same[l]));
   if (conv1_ks == 3)
     ms->conv1 = ms->same[0];
   else if (!skip_conv1_map)
-    DGR_CHECK(build(ms->cm[0], ms->cm[0], nullptr, conv1_ks, false, &ms->conv1));
+    DGR_CHECK(build(ms->cm[0], ms->cm[0], nullptr, conv1_ks, false, true, &ms->conv1));
   // strided maps are also used swapped by the transposed convs: build the in-major CSR too
-  for (int l = 0; l < 3; ++l) DGR_CHECK(build(ms->cm[l], ms->cm[l + 1], &ms->hb[l], 3, true, &ms->down[l]));
+  for (int l = 0; l < 3; ++l) DGR_CHECK(build(ms->cm[l], ms->cm[l + 1], &ms->hb[l], 3, true, false, &ms->down[l]));
   return DGR_OK;
 }
 

@@ -280,7 +280,7 @@ int dgr_resunet_forward_impl(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, 
   f.ms.overflow = ctx->flag_dev;
   // FCGF conv1 (ks^3 offsets, <= 8 input channels) is fused with its neighbour search: no map for it
   const bool conv1_fused = net->D == 3 && net->conv1_ks != 3 && net->cin <= 8;
-  DGR_CHECK(dgr_build_maps(A, coords, N, net->D, net->conv1_ks, &f.ms, stream, conv1_fused));
+  DGR_CHECK(dgr_build_maps(A, coords, N, net->D, net->conv1_ks, &f.ms, stream, conv1_fused, /*lean=*/true));
   if (f.prof) {
     DGR_HIP_CHECK(hipEventRecord(m1, stream));
     (net->D == 3 ? ctx->map3_spans : ctx->map6_spans).push_back({m0, m1});
