@@ -17,16 +17,23 @@ constexpr int KNN_TB = 64;  // F1 rows per LDS tile
 template <int C, int QPT>
 __global__ void __launch_bounds__(KNN_THREADS)
     knn1_kernel(const float *__restrict__ F0, int64_t N0, const float *__restrict__ F1, int64_t N1,
-                int rows_per_split, unsigned long long *__restrict__ best, const int32_t *run_flag) {
+                int rows_per_split, unsigned long long *__restrict__ best, const int32_t *run_flag,
+                const int32_t *__restrict__ qlist, const int32_t *qcount) {
   __shared__ __attribute__((aligned(16))) float tile[KNN_TB * C];
-  if (run_flag && *run_flag == 0) return;  // fallback launch of the prefiltered path: nothing overflowed
+  if (run_flag && *run_flag == 0) return;  // fallback launch of the prefiltered path: nothing to redo
+  // optional indirection: only the queries listed in qlist[0 .. *qcount) (prefilter slot overflow)
+  const int64_t n_q = qlist ? (int64_t)*qcount : N0;
+  if ((int64_t)blockIdx.x * KNN_THREADS * QPT >= n_q) return;
   const int64_t q0 = ((int64_t)blockIdx.x * KNN_THREADS + threadIdx.x) * QPT;
   const int64_t j_begin = (int64_t)blockIdx.y * rows_per_split;
   const int64_t j_end = min(N1, j_begin + rows_per_split);
   float q[QPT][C];
+  int64_t qrow[QPT];
 #pragma unroll
   for (int u = 0; u < QPT; ++u) {
-    const int64_t r = min(q0 + u, N0 - 1);
+    const int64_t li = min(q0 + u, n_q - 1);
+    const int64_t r = qlist ? (int64_t)qlist[li] : li;
+    qrow[u] = r;
 #pragma unroll
     for (int c = 0; c < C; c += 4) {
       const float4 v = *reinterpret_cast<const float4 *>(F0 + r * C + c);
@@ -74,10 +81,10 @@ __global__ void __launch_bounds__(KNN_THREADS)
   }
 #pragma unroll
   for (int u = 0; u < QPT; ++u) {
-    if (q0 + u < N0 && bi[u] != 0x7fffffff) {
+    if (q0 + u < n_q && bi[u] != 0x7fffffff) {
       const unsigned long long key =
           ((unsigned long long)__float_as_uint(bd[u]) << 32) | (unsigned int)bi[u];
-      atomicMin(best + q0 + u, key);
+      atomicMin(best + qrow[u], key);
     }
   }
 }
@@ -96,7 +103,8 @@ __global__ void knn1_finish(const unsigned long long *__restrict__ best, int64_t
 
 template <int C>
 static int knn_launch(dgr_ctx *ctx, const float *F0, int64_t N0, const float *F1, int64_t N1,
-                      unsigned long long *best, const int32_t *run_flag, hipStream_t stream) {
+                      unsigned long long *best, const int32_t *run_flag, hipStream_t stream,
+                      const int32_t *qlist = nullptr, const int32_t *qcount = nullptr) {
   constexpr int QPT = (C <= 32) ? 4 : 2;
   const int qblocks = (int)dgr_ceil_div(N0, (int64_t)KNN_THREADS * QPT);
   // enough (query block, F1 split) workgroups to cover every CU a few times over
@@ -107,7 +115,7 @@ static int knn_launch(dgr_ctx *ctx, const float *F0, int64_t N0, const float *F1
   int rows_per_split = (int)dgr_ceil_div(dgr_ceil_div(N1, splits), KNN_TB) * KNN_TB;
   splits = (int)dgr_ceil_div(N1, rows_per_split);
   dim3 grid(qblocks, splits);
-  knn1_kernel<C, QPT><<<grid, KNN_THREADS, 0, stream>>>(F0, N0, F1, N1, rows_per_split, best, run_flag);
+  knn1_kernel<C, QPT><<<grid, KNN_THREADS, 0, stream>>>(F0, N0, F1, N1, rows_per_split, best, run_flag, qlist, qcount);
   DGR_LAUNCH_CHECK();
   return DGR_OK;
 }
@@ -129,8 +137,9 @@ static int knn_launch(dgr_ctx *ctx, const float *F0, int64_t N0, const float *F1
 //            in the list.
 //   exact    one thread per candidate evaluates sum (a - b)^2 exactly like knn1_kernel and merges with
 //            the same 64-bit atomicMin key.
-// If a query collects more than KNN_SLOTS candidates (degenerate inputs: many near-ties) or any feature is
-// non-finite / huge, a flag makes the brute-force kernel, launched behind it, do the work instead.
+// A query that collects more than KNN_SLOTS candidates (many near-ties, e.g. repeated structure) is redone by the
+// brute-force kernel through a device-side query list; a non-finite / huge feature makes the brute-force kernel,
+// launched behind, redo the whole search.  No host round trip either way.
 // ------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
@@ -259,8 +268,7 @@ __global__ void __launch_bounds__(256, 2)
             const int64_t i = (int64_t)t * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
             if (!(acc[e] > thr[u]) && q < N0 && i < N1 && qb0 + u < n_qblocks) {
               const int slot = atomicAdd(cand_cnt + q, 1);   // per-query counters: no hot address
-              if (slot < KNN_SLOTS) cand[q * KNN_SLOTS + slot] = (int32_t)i;
-              else *overflow = 1;
+              if (slot < KNN_SLOTS) cand[q * KNN_SLOTS + slot] = (int32_t)i;   // beyond: knn_overflow_list
             }
           }
         }
@@ -284,7 +292,7 @@ __global__ void __launch_bounds__(256)
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t q = t / KNN_SLOTS;
   const int slot = (int)(t % KNN_SLOTS);
-  if (q >= N0 || slot >= cand_cnt[q]) return;
+  if (q >= N0 || slot >= min(cand_cnt[q], KNN_SLOTS)) return;
   const int i = cand[t];
   const float *a = F0 + q * 32, *b = F1 + (int64_t)i * 32;
   float d0 = 0.f, d1 = 0.f;  // the very chain of knn1_kernel
@@ -304,6 +312,13 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// queries that collected more candidates than slots (many near-ties): redone exactly by the brute-force kernel
+__global__ void knn_overflow_list(const int32_t *__restrict__ cand_cnt, int64_t N0, int32_t *__restrict__ qlist,
+                                  int32_t *qcount) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < N0 && cand_cnt[q] > KNN_SLOTS) qlist[atomicAdd(qcount, 1)] = (int32_t)q;
+}
+
 static int knn_prefiltered(dgr_ctx *ctx, const float *F0, int64_t N0, const float *F1, int64_t N1,
                            unsigned long long *best, hipStream_t stream) {
   DgrArena &arena = ctx->arena;
@@ -317,7 +332,9 @@ static int knn_prefiltered(dgr_ctx *ctx, const float *F0, int64_t N0, const floa
   DGR_ALLOC(na, arena, float, (int64_t)n_qblocks * 32);
   DGR_ALLOC(nb, arena, float, (int64_t)n_rtiles * 32);
   DGR_ALLOC(mt, arena, uint32_t, N0);
-  DGR_ALLOC(cand_cnt, arena, int32_t, N0 + 4);   // + [N0]: max nb bits, [N0 + 1]: fallback flag
+  int32_t *qlist;
+  DGR_ALLOC(qlist, arena, int32_t, N0);
+  DGR_ALLOC(cand_cnt, arena, int32_t, N0 + 4);   // + [N0]: max nb bits, [N0 + 1]: fallback flag, [N0 + 2]: overflow count
   DGR_ALLOC(cand, arena, int32_t, N0 * KNN_SLOTS);
   nb_max = reinterpret_cast<uint32_t *>(cand_cnt + N0);
   int32_t *fallback = cand_cnt + N0 + 1;
@@ -343,8 +360,11 @@ static int knn_prefiltered(dgr_ctx *ctx, const float *F0, int64_t N0, const floa
   DGR_LAUNCH_CHECK();
   knn_exact_kernel<<<(int)dgr_ceil_div(N0 * KNN_SLOTS, 256), 256, 0, stream>>>(F0, F1, cand, cand_cnt, N0, best);
   DGR_LAUNCH_CHECK();
-  // too many near-ties for the slots, or non-finite input: the brute-force kernel redoes the search
-  // (it exits at once otherwise)
+  // queries with more near-ties than slots are redone one by one by the brute-force kernel (its blocks beyond
+  // the list length exit at once); non-finite / huge input: the brute-force kernel redoes the whole search
+  int32_t *qcount = cand_cnt + N0 + 2;
+  knn_overflow_list<<<(int)dgr_ceil_div(N0, 256), 256, 0, stream>>>(cand_cnt, N0, qlist, qcount);
+  DGR_CHECK(knn_launch<32>(ctx, F0, N0, F1, N1, best, nullptr, stream, qlist, qcount));
   return knn_launch<32>(ctx, F0, N0, F1, N1, best, fallback, stream);
 }
 

@@ -85,6 +85,11 @@ cases['concentrated'] = (unit(base + 0.02 * rng.standard_normal((3000, 32))),
 # (c) exact duplicates in F1 (first index must win) and F0 rows copied from F1 (distance 0)
 F1 = unit(rng.standard_normal((4096, 32))); F1[2048:] = F1[:2048]
 cases['duplicates'] = (np.concatenate([F1[100:1100], unit(rng.standard_normal((500, 32)))]), F1)
+# (c2) a cluster of 64 identical reference rows: queries next to it collect 64 tied candidates (> 8 slots) and
+# must still get the FIRST of the tied rows; the other queries take the regular path
+F1c = unit(rng.standard_normal((3000, 32))); F1c[100:164] = F1c[100]
+F0c = unit(rng.standard_normal((2000, 32))); F0c[:300] = unit(F1c[100] + 1e-4 * rng.standard_normal((300, 32)))
+cases['tied_cluster'] = (F0c, F1c)
 # (d) un-normalised features with a wide range of magnitudes
 cases['scaled'] = ((rng.standard_normal((2500, 32)) * 10.0 ** rng.uniform(-3, 3, (2500, 1))).astype(np.float32),
                    (rng.standard_normal((3500, 32)) * 10.0 ** rng.uniform(-3, 3, (3500, 1))).astype(np.float32))
