@@ -567,7 +567,18 @@ __global__ void __launch_bounds__(256)
     }
     int j = ptr[row];
     const int end = ptr[row + 1];
-    // four independent loads in flight; the additions stay in ascending-k order
+    // eight independent product-row loads in flight (their eight slot indices are fetched together first);
+    // the additions stay in ascending-k order
+    for (; j + 8 <= end; j += 8) {
+      int p[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) p[u] = pos[j + u];
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4 *>(y + (int64_t)p[u] * y_ld + c);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
     for (; j + 4 <= end; j += 4) {
       const int p0 = pos[j], p1 = pos[j + 1], p2 = pos[j + 2], p3 = pos[j + 3];
       const f32x4 v0 = *reinterpret_cast<const f32x4 *>(y + (int64_t)p0 * y_ld + c);
