@@ -41,6 +41,15 @@ struct ConvKArgs {
   int cin, cin_pad, cout, K;
 };
 
+// Product rows are written once and read once.  Measured on the 256-wide layers (3.7 GB of product rows per
+// launch): reading them with non-temporal loads in the reduce pass is 19 % faster (no L2 allocation for data
+// that is never touched again); non-temporal STORES in the MFMA kernel cost it 10 % (the 16-byte pieces of a
+// row no longer merge in L2) and narrow layers, whose product rows fit the L2 / MALL, prefer plain loads.
+template <bool STREAM>
+__device__ __forceinline__ f32x4 dgr_y_load(const float *p) {
+  if (STREAM) return __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
+  return *reinterpret_cast<const f32x4 *>(p);
+}
 template <int WM, int WN, int MB, int NB>
 __global__ void __launch_bounds__(64 * WM * WN) sparse_conv_mfma(ConvKArgs a) {
   constexpr int THREADS = 64 * WM * WN;
@@ -575,19 +584,19 @@ __global__ void __launch_bounds__(256)
       for (int u = 0; u < 8; ++u) p[u] = pos[j + u];
       f32x4 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4 *>(y + (int64_t)p[u] * y_ld + c);
+      for (int u = 0; u < 8; ++u) v[u] = dgr_y_load<LPR == 64>(y + (int64_t)p[u] * y_ld + c);
 #pragma unroll
       for (int u = 0; u < 8; ++u) acc += v[u];
     }
     for (; j + 4 <= end; j += 4) {
       const int p0 = pos[j], p1 = pos[j + 1], p2 = pos[j + 2], p3 = pos[j + 3];
-      const f32x4 v0 = *reinterpret_cast<const f32x4 *>(y + (int64_t)p0 * y_ld + c);
-      const f32x4 v1 = *reinterpret_cast<const f32x4 *>(y + (int64_t)p1 * y_ld + c);
-      const f32x4 v2 = *reinterpret_cast<const f32x4 *>(y + (int64_t)p2 * y_ld + c);
-      const f32x4 v3 = *reinterpret_cast<const f32x4 *>(y + (int64_t)p3 * y_ld + c);
+      const f32x4 v0 = dgr_y_load<LPR == 64>(y + (int64_t)p0 * y_ld + c);
+      const f32x4 v1 = dgr_y_load<LPR == 64>(y + (int64_t)p1 * y_ld + c);
+      const f32x4 v2 = dgr_y_load<LPR == 64>(y + (int64_t)p2 * y_ld + c);
+      const f32x4 v3 = dgr_y_load<LPR == 64>(y + (int64_t)p3 * y_ld + c);
       acc += v0; acc += v1; acc += v2; acc += v3;
     }
-    for (; j < end; ++j) acc += *reinterpret_cast<const f32x4 *>(y + (int64_t)pos[j] * y_ld + c);
+    for (; j < end; ++j) acc += dgr_y_load<LPR == 64>(y + (int64_t)pos[j] * y_ld + c);
     *reinterpret_cast<f32x4 *>(out + row * out_ld + c) = acc;
   }
 }
