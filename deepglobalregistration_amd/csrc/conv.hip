@@ -946,25 +946,29 @@ __global__ void __launch_bounds__(256)
     const int my_n = vsel ? nh[1] : nh[0];
     const int trips = max(nh[0], nh[1]);
     float acc = shift ? shift[co] : 0.f;
-    for (int r0 = 0; r0 < trips; r0 += 4) {
-      float t[4];
+    // eight list entries per trip: all loads of a trip (per input channel) are issued together -- nothing
+    // between them consumes a loaded value -- and only the adds form a serial chain
+    for (int r0 = 0; r0 < trips; r0 += 8) {
+      int2 e[8];
+      float t[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const bool ok = r0 + u < my_n;
-        const int2 e = ok ? lists[wv][vsel][r0 + u] : make_int2(0, 0);
-        float tt = 0.f;
+      for (int u = 0; u < 8; ++u) {
+        e[u] = (r0 + u < my_n) ? lists[wv][vsel][r0 + u] : make_int2(0, 0);
+        t[u] = 0.f;
+      }
+      for (int ci = 0; ci < cin; ++ci) {   // wave-uniform trip count (1 for FCGF)
+        float xs[8], ws[8];
+        const int wofs = (32 * (ci >> 2) + co) * 4 + (ci & 3);
 #pragma unroll
-        for (int ci = 0; ci < 8; ++ci) {
-          if (ci < cin) {   // cin is wave-uniform
-            const float xs = in[(int64_t)e.y * in_ld + ci];
-            const float wvv = w[(int64_t)e.x * 256 + (32 * (ci >> 2) + co) * 4 + (ci & 3)];
-            tt = fmaf(xs, wvv, tt);   // same k-ordered fma chain as the MFMA path
-          }
+        for (int u = 0; u < 8; ++u) {
+          xs[u] = in[(int64_t)e[u].y * in_ld + ci];
+          ws[u] = w[(int64_t)e[u].x * 256 + wofs];
         }
-        t[u] = tt;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = fmaf(xs[u], ws[u], t[u]);   // same k-ordered fma chain as the MFMA path
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc = (r0 + u < my_n) ? acc + t[u] : acc;
+      for (int u = 0; u < 8; ++u) acc = (r0 + u < my_n) ? acc + t[u] : acc;
     }
     const int64_t o = o0 + vsel;
     if (o < n) out[o * out_ld + co] = acc;
