@@ -153,20 +153,33 @@ __global__ void __launch_bounds__(KM_THREADS)
   if (b < 0) return;
   const int c4 = co[4], c5 = co[5], c6 = co[6];
   const int beg = hb.start[b], end = hb.start[b + 1];
-  for (int p = beg; p < end; ++p) {
-    const int r = hb.rows[p];
-    const int32_t *ci = in_coords + (int64_t)r * 7;
-    const int d4 = ci[4] - c4, d5 = ci[5] - c5, d6 = ci[6] - c6;
-    // every component must be -ts, 0 or +ts (all coordinates of a level are multiples of ts)
-    if (abs(d4) <= ts_in && abs(d5) <= ts_in && abs(d6) <= ts_in) {
-      const int k = ja + 27 * ((d4 / ts_in + 1) + 3 * (d5 / ts_in + 1) + 9 * (d6 / ts_in + 1));
-      if (symmetric && ja == 13 && k > 364) continue;  // ja == 13 mirrors onto itself: upper half found from the other row
-      atomicOr(&mask_out[o * KW + (k >> 5)], 1u << (k & 31));
-      if (symmetric) {
-        const int km = 728 - k;
-        if (km != k) atomicOr(&mask_out[(int64_t)r * KW + (km >> 5)], 1u << (km & 31));
-      } else if (mask_in) {
-        atomicOr(&mask_in[(int64_t)r * KW + (k >> 5)], 1u << (k & 31));
+  // four bucket rows per trip: their indices, then their second halves, are fetched together (a
+  // one-row-at-a-time loop pays two dependent L2 latencies per candidate)
+  for (int p0 = beg; p0 < end; p0 += 4) {
+    int r[4];
+    int32_t e4[4], e5[4], e6[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) r[u] = hb.rows[min(p0 + u, end - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int32_t *ci = in_coords + (int64_t)r[u] * 7;
+      e4[u] = ci[4]; e5[u] = ci[5]; e6[u] = ci[6];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (p0 + u >= end) break;
+      const int d4 = e4[u] - c4, d5 = e5[u] - c5, d6 = e6[u] - c6;
+      // every component must be -ts, 0 or +ts (all coordinates of a level are multiples of ts)
+      if (abs(d4) <= ts_in && abs(d5) <= ts_in && abs(d6) <= ts_in) {
+        const int k = ja + 27 * ((d4 / ts_in + 1) + 3 * (d5 / ts_in + 1) + 9 * (d6 / ts_in + 1));
+        if (symmetric && ja == 13 && k > 364) continue;  // ja == 13 mirrors onto itself: upper half found from the other row
+        atomicOr(&mask_out[o * KW + (k >> 5)], 1u << (k & 31));
+        if (symmetric) {
+          const int km = 728 - k;
+          if (km != k) atomicOr(&mask_out[(int64_t)r[u] * KW + (km >> 5)], 1u << (km & 31));
+        } else if (mask_in) {
+          atomicOr(&mask_in[(int64_t)r[u] * KW + (k >> 5)], 1u << (k & 31));
+        }
       }
     }
   }
