@@ -52,3 +52,40 @@ __device__ __forceinline__ int dgr_lookup(const int32_t *__restrict__ table, uin
     slot = (slot + 1) & mask;
   }
 }
+
+// U independent look-ups at once: the U table reads are issued together, then the key rows of the occupied
+// slots, so a thread pays two memory latencies for U probes instead of 2 U (collisions fall back to the
+// sequential probe loop, continuing behind the first slot).
+template <int NC, int U>
+__device__ __forceinline__ void dgr_lookup_many(const int32_t *__restrict__ table, uint32_t mask,
+                                                const int32_t *__restrict__ coords, const int32_t (*q)[NC],
+                                                int *found) {
+  uint32_t slot[U];
+  int v[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    slot[u] = dgr_hash_row<NC>(q[u]) & mask;
+    v[u] = table[slot[u]];
+  }
+  bool eq[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) eq[u] = dgr_rows_equal<NC>(coords + (int64_t)max(v[u], 0) * NC, q[u]);
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if (v[u] == DGR_EMPTY) {
+      found[u] = -1;
+    } else if (eq[u]) {
+      found[u] = v[u];
+    } else {   // collision: keep probing
+      uint32_t s2 = (slot[u] + 1) & mask;
+      int r = -1;
+      while (true) {
+        const int w = table[s2];
+        if (w == DGR_EMPTY) break;
+        if (dgr_rows_equal<NC>(coords + (int64_t)w * NC, q[u])) { r = w; break; }
+        s2 = (s2 + 1) & mask;
+      }
+      found[u] = r;
+    }
+  }
+}

@@ -104,29 +104,47 @@ __global__ void mask_count_kernel(const uint32_t *__restrict__ mask, int KW, con
 //            inside its row (CSR slot) and inside its cell (rule-major position) with popcounts.
 // Result identical to the generic path: pairs sorted by (k, out), CSR slots in ascending k.
 
-// generic search, bits only: grid = (row blocks, offsets to probe)
+// generic search, bits only: grid = (row blocks, ceil(offsets to probe / 4)); a thread probes four consecutive
+// offsets of its row with the batched look-up (two memory latencies for the four probes)
+constexpr int KM_PROBES = 4;
 template <int D>
 __global__ void __launch_bounds__(KM_THREADS)
     kmap_bits(const int32_t *__restrict__ out_coords, const int32_t *n_out_dev,
               const int32_t *__restrict__ in_coords, const int32_t *__restrict__ in_table, uint32_t in_mask,
-              int ks, int ts_in, int K, int KW, int symmetric, uint32_t *mask_out, uint32_t *mask_in) {
-  const int k = blockIdx.y;
+              int ks, int ts_in, int K, int KW, int n_probe, int symmetric, uint32_t *mask_out, uint32_t *mask_in) {
+  constexpr int NC = D + 1;
+  const int k0 = blockIdx.y * KM_PROBES;
   const int64_t o = (int64_t)blockIdx.x * KM_THREADS + threadIdx.x;
   if (o >= *n_out_dev) return;
-  if (symmetric && k == 0) {  // the centre offset always maps a row onto itself
+  if (symmetric && k0 == 0) {  // the centre offset always maps a row onto itself
     const int c = K >> 1;
     atomicOr(&mask_out[o * KW + (c >> 5)], 1u << (c & 31));
   }
-  int32_t delta[D];
-  offset_of<D>(k, ks, ts_in, delta);
-  const int hit = probe<D>(out_coords, o, delta, in_coords, in_table, in_mask);
-  if (hit < 0) return;
-  atomicOr(&mask_out[o * KW + (k >> 5)], 1u << (k & 31));
-  if (symmetric) {
-    const int km = K - 1 - k;
-    atomicOr(&mask_out[(int64_t)hit * KW + (km >> 5)], 1u << (km & 31));
-  } else if (mask_in) {
-    atomicOr(&mask_in[(int64_t)hit * KW + (k >> 5)], 1u << (k & 31));
+  int32_t base[NC];
+#pragma unroll
+  for (int d = 0; d < NC; ++d) base[d] = out_coords[o * NC + d];
+  int32_t q[KM_PROBES][NC];
+#pragma unroll
+  for (int u = 0; u < KM_PROBES; ++u) {
+    int32_t delta[D];
+    offset_of<D>(min(k0 + u, n_probe - 1), ks, ts_in, delta);
+    q[u][0] = base[0];
+#pragma unroll
+    for (int d = 0; d < D; ++d) q[u][1 + d] = base[1 + d] + delta[d];
+  }
+  int hit[KM_PROBES];
+  dgr_lookup_many<NC, KM_PROBES>(in_table, in_mask, in_coords, q, hit);
+#pragma unroll
+  for (int u = 0; u < KM_PROBES; ++u) {
+    const int k = k0 + u;
+    if (k >= n_probe || hit[u] < 0) continue;
+    atomicOr(&mask_out[o * KW + (k >> 5)], 1u << (k & 31));
+    if (symmetric) {
+      const int km = K - 1 - k;
+      atomicOr(&mask_out[(int64_t)hit[u] * KW + (km >> 5)], 1u << (km & 31));
+    } else if (mask_in) {
+      atomicOr(&mask_in[(int64_t)hit[u] * KW + (k >> 5)], 1u << (k & 31));
+    }
   }
 }
 
@@ -436,9 +454,10 @@ static int build_kernel_map_t(DgrArena &arena, const DgrCoordMap &in, const DgrC
       kmap_bits_pruned6<<<(int)dgr_ceil_div(threads, KM_THREADS), KM_THREADS, 0, stream>>>(
           out.coords, out.n_dev, in.coords, *in_buckets, in.ts, KW, symmetric, mask_out, mask_in);
     } else {
-      dim3 grid(RB, symmetric ? K / 2 : K);
+      const int n_probe = symmetric ? K / 2 : K;
+      dim3 grid(RB, (n_probe + KM_PROBES - 1) / KM_PROBES);
       kmap_bits<D><<<grid, KM_THREADS, 0, stream>>>(out.coords, out.n_dev, in.coords, in.table, in.table_mask, ks,
-                                                    in.ts, K, KW, symmetric, mask_out, mask_in);
+                                                    in.ts, K, KW, n_probe, symmetric, mask_out, mask_in);
     }
     DGR_LAUNCH_CHECK();
     kmap_colmask<<<RB, KM_THREADS, 0, stream>>>(mask_out, out.n_dev, K, KW, RB, cell, counts);
