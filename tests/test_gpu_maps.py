@@ -78,3 +78,36 @@ def test_single_voxel_and_tiny_maps():
     k, i, o = m.kernel_map('same', 1)
     assert (k.tolist(), i.tolist(), o.tolist()) == ([13], [0], [0])
     assert m.coords(8).tolist() == [[0, 0, -8, 0]]
+
+
+def test_6d_maps_pipeline_shaped():
+    """6-D rows built like the pipeline builds them (a 3-D voxel paired with a nearby 3-D voxel, two batch
+    elements): several thousand rows so that the bit-matrix pipeline runs over many 256-row blocks, the
+    pruned search meets multi-row buckets, the symmetric half-search has to mirror across blocks and the
+    stride-8 level is dense (tens of neighbours per row)."""
+    from deepglobalregistration_amd import ops
+    rng = np.random.default_rng(99)
+    rows = []
+    for b in (0, 1):
+        c0 = random_cloud_coords(rng, 9000, 22, 3, batch=b)
+        shift = rng.integers(-3, 4, (len(c0), 3)).astype(np.int32)
+        rows.append(np.concatenate([c0, c0[:, 1:] + 5 + shift], axis=1))
+    coords = np.concatenate(rows).astype(np.int32)
+    maps = ops.Maps(coords, 6, 3)
+    ocoords = {1: coords}
+    for ts in (2, 4, 8):
+        ocoords[ts] = me.stride_coords(ocoords[ts // 2], ts)
+        np.testing.assert_array_equal(maps.coords(ts), ocoords[ts])
+    dens = {}
+    for ts in (1, 2, 4, 8):
+        k, i, o = maps.kernel_map('same', ts)
+        assert kmap_set(k, i, o) == kmap_set(*me.kernel_map(ocoords[ts], ocoords[ts], 6, 3, ts))
+        assert np.all(np.diff(k) >= 0) and np.all(np.diff(o)[np.diff(k) == 0] > 0)     # sorted by (k, out)
+        # same-stride maps are symmetric: (o, k) -> i  <=>  (i, K-1-k) -> o
+        assert kmap_set(728 - k, o, i) == kmap_set(k, i, o)
+        dens[ts] = len(k) / len(ocoords[ts])
+    assert dens[8] > 8 * dens[1] / 2 or dens[8] > 10          # the coarse level really is dense
+    for ts in (1, 2, 4):
+        k, i, o = maps.kernel_map('down', ts)
+        assert kmap_set(k, i, o) == kmap_set(*me.kernel_map(ocoords[ts], ocoords[2 * ts], 6, 3, ts))
+        assert np.all(np.diff(k) >= 0) and np.all(np.diff(o)[np.diff(k) == 0] > 0)
