@@ -119,6 +119,8 @@ def main():
     ap.add_argument('--conv1-ks', type=int, default=7)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-refine', action='store_true', help='ablation: stop after weighted Procrustes')
+    ap.add_argument('--from-host', action='store_true', help='PCIe-inclusive variant (NOT the headline): every step '
+                    'starts from the raw float64 host points (H2D copy + GPU voxelisation inside the timed region)')
     ap.add_argument('--streams', type=int, default=3, help='HIP streams per GPU, each driven by its own host '
                     'thread with its own library context and its own batch of pairs (independent units)')
     args = ap.parse_args()
@@ -204,6 +206,13 @@ def main():
                 torch.cuda.synchronize()
 
         def step(self):
+            if args.from_host and self.forced is not None:
+                x0, c0, x1, c1 = [], [], [], []
+                for p, (a, b, _) in enumerate(self.pairs):
+                    xa, ca, _ = self.dgr.preprocess(a, batch_index=p)
+                    xb, cb, _ = self.dgr.preprocess(b, batch_index=p)
+                    x0.append(xa); c0.append(ca); x1.append(xb); c1.append(cb)
+                self.C0, self.X0, self.C1, self.X1 = torch.cat(c0), torch.cat(x0), torch.cat(c1), torch.cat(x1)
             return self.dgr.register_voxelized(self.C0, self.X0, self.off0, self.C1, self.X1, self.off1,
                                                forced_logits=self.forced, skip_refinement=args.no_refine,
                                                override_idx1=self.ovr)
@@ -340,7 +349,8 @@ def main():
             'value': world * S * B * args.steps / elapsed, 'unit': 'pairs/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
-            'data': 'synthetic 3DMatch-shaped pairs, seeded synthetic weights, teacher-forced matches (20% GT) and inlier logits',
+            'data': 'synthetic 3DMatch-shaped pairs, seeded synthetic weights, teacher-forced matches (20% GT) and inlier logits'
+                    + ('; PCIe-inclusive: raw host points -> H2D -> voxelisation inside the timed region' if args.from_host else ''),
             'config': {'workload': f'{S * B} pairs/step/GPU ({S} stream(s) x {B}), {args.n_raw} raw pts/fragment, '
                                    f'{args.kind}, voxel {args.voxel}, conv1 k={args.conv1_ks} ({cfg_label(args)})',
                        'streams_per_gpu': S,
