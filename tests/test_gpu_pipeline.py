@@ -182,3 +182,36 @@ def test_collated_batch_and_batched_knn(setup):
     assert torch.equal(cat[700:], ref1 + 900) and torch.equal(per[1], ref1) and dist.shape == (2000, 1)
     with pytest.raises(ValueError):
         find_knn_batch(F0, F1, lens, search_method='tree')
+
+
+def test_ragged_and_tiny_batches(setup):
+    """Edge cases through the fused batched call: a tiny pair (tens of voxels), a one-voxel fragment, very
+    different fragment sizes inside one batch.  Nothing may crash; hopeless pairs come back as low confidence
+    with T = I, and the normal pair next to them is unaffected."""
+    from deepglobalregistration_amd import synth
+    ck, dgr, pairs = setup
+    rng = np.random.default_rng(5)
+    tiny0 = rng.uniform(0, 0.4, (60, 3)); tiny1 = rng.uniform(0, 0.4, (45, 3))
+    single = np.array([[0.01, 0.02, 0.03]])
+    big0, big1, T_gt = pairs[0]
+    batch = [(tiny0, tiny1), (big0, single), (big0, big1)]
+    x0, c0, x1, c1, off0, off1 = [], [], [], [], [0], [0]
+    for p, (a, b) in enumerate(batch):
+        xa, ca, _ = dgr.preprocess(a, batch_index=p)
+        xb, cb, _ = dgr.preprocess(b, batch_index=p)
+        x0.append(xa); c0.append(ca); x1.append(xb); c1.append(cb)
+        off0.append(off0[-1] + len(xa)); off1.append(off1[-1] + len(xb))
+    assert len(x1[1]) == 1
+    C0, X0, C1, X1 = torch.cat(c0), torch.cat(x0), torch.cat(c1), torch.cat(x1)
+    T, status, stats = dgr.register_voxelized(C0, X0, off0, C1, X1, off1)
+    assert T.shape == (3, 4, 4) and np.isfinite(T).all()
+    assert status[0] == 1                                    # 60 correspondences: wsum < 200, never enough support
+    np.testing.assert_array_equal(T[0], np.eye(4))
+    # every voxel of the big fragment matched to ONE point: a degenerate (rank-0) covariance; with untrained
+    # weights the gate may let it through -- whatever the status, the result must be a finite rigid transform
+    assert status[1] in (0, 1, 2) and abs(np.linalg.det(T[1, :3, :3]) - 1) < 1e-4
+    # the same big pair alone gives the same answer as inside the ragged batch (pairs are independent units)
+    xa, ca, _ = dgr.preprocess(big0); xb, cb, _ = dgr.preprocess(big1)
+    T1, s1, st1 = dgr.register_voxelized(ca, xa, [0, len(xa)], cb, xb, [0, len(xb)])
+    assert s1[0] == status[2]
+    np.testing.assert_allclose(T1[0], T[2], atol=1e-4)
