@@ -386,7 +386,7 @@ def main():
             'layers_3d_cloud0': [[x['pairs'], x['nonempty'], x['n_in'], x['n_out'], x['cin'], x['cout']] for x in s_a],
         }
         log('roofline accounting done')
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported on rank 0 at N = 1 only
             out['cpu_baseline'] = cpu_baseline(ck, args.n_raw, args.voxel, args.kind, (int(off0[-1] / B), int(off1[-1] / B)))
         else:
             out['cpu_baseline'] = None
