@@ -24,6 +24,7 @@
 #include <map>
 
 #include "dgr_internal.h"
+#include <algorithm>
 #include "hash.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -998,8 +999,17 @@ int dgr_conv1_probe(DgrArena &arena, const DgrCoordMap &cm, int ks, const float 
     grid_layout_kernel<<<1, 64, 0, stream>>>(meta, ks >> 1, cap);
     grid_clear_kernel<<<2048, 256, 0, stream>>>(meta, cells);
     grid_fill_kernel<<<(int)dgr_ceil_div(cm.n_cap, 256), 256, 0, stream>>>(cm.coords, cm.n_dev, meta, ks >> 1, cells);
+    // grid-stride kernel: a whole number of resident rounds (a ragged last round costs up to 10 %)
+    static int resident = 0;
+    if (resident == 0) {
+      int per_cu = 0, dev = 0, cus = 0;
+      DGR_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv1_grid_kernel, 256, 0));
+      DGR_HIP_CHECK(hipGetDevice(&dev));
+      DGR_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+      resident = (per_cu < 1 ? 1 : per_cu) * (cus < 1 ? 1 : cus);
+    }
     int64_t blocks = dgr_ceil_div(cm.n_cap, 8);
-    if (blocks > 8192) blocks = 8192;
+    if (blocks > resident) blocks = (int64_t)resident * std::min<int64_t>(4, blocks / resident);
     conv1_grid_kernel<<<(int)blocks, 256, 0, stream>>>(cm.coords, cm.n_dev, meta, cells, ks, in, in_ld, cin, w_tiled, shift,
                                                        out, out_ld, pair_count);
     DGR_LAUNCH_CHECK();
