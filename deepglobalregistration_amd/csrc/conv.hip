@@ -607,12 +607,22 @@ int dgr_reduce_rows(const float *y, int cout, const int32_t *ptr, const int32_t 
                     int res_relu, hipStream_t stream) {
   DGR_REQUIRE((out_ld & 3) == 0 && (res == nullptr || (res_ld & 3) == 0), "reduce_rows: row strides must be x4");
   const int lpr = cout / 4;
-  int64_t blocks = dgr_ceil_div(n_cap, 256 / lpr);
-  if (blocks > 8192) blocks = 8192;
-  if (blocks < 1) blocks = 1;
+  const int64_t want = std::max<int64_t>(1, dgr_ceil_div(n_cap, 256 / lpr));
+  // grid-stride kernels: at most four resident rounds, and a whole number of them
 #define DGR_RR(L)                                                                                              \
-  reduce_rows_kernel<L><<<(int)blocks, 256, 0, stream>>>(y, cout, ptr, pos, n_dev, out, out_ld, shift, res, res_ld, \
-                                                         res_relu)
+  do {                                                                                                         \
+    static int resident = 0;                                                                                   \
+    if (resident == 0) {                                                                                       \
+      int per_cu = 0, dev = 0, cus = 0;                                                                        \
+      DGR_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reduce_rows_kernel<L>, 256, 0));     \
+      DGR_HIP_CHECK(hipGetDevice(&dev));                                                                       \
+      DGR_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));                  \
+      resident = (per_cu < 1 ? 1 : per_cu) * (cus < 1 ? 1 : cus);                                              \
+    }                                                                                                          \
+    const int64_t blocks = want > resident ? (int64_t)resident * std::min<int64_t>(4, want / resident) : want; \
+    reduce_rows_kernel<L><<<(int)blocks, 256, 0, stream>>>(y, cout, ptr, pos, n_dev, out, out_ld, shift, res,  \
+                                                           res_ld, res_relu);                                  \
+  } while (0)
   switch (cout) {
     case 32: DGR_RR(8); break;
     case 64: DGR_RR(16); break;
