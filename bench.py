@@ -129,11 +129,19 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     import torch.distributed as dist
+    # test hooks (a 1-GPU box cannot run RCCL between two ranks): DGR_BENCH_BACKEND=gloo moves the two tiny
+    # collectives to the CPU, DGR_BENCH_ONE_GPU=1 puts every rank on device 0; the driver sets neither
+    backend = os.environ.get('DGR_BENCH_BACKEND', 'nccl')
+    if os.environ.get('DGR_BENCH_ONE_GPU'):
+        local_rank = 0
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
     assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback)'
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
@@ -144,7 +152,8 @@ def main():
     B = args.pairs_per_step
     S = max(1, args.streams)
     ck = synth.synth_checkpoint(seed=0, voxel_size=args.voxel, feat_conv1_kernel_size=args.conv1_ks) if rank == 0 else None
-    ck = ddist.broadcast_checkpoint(ck, src=0, device=device)
+    coll_dev = device if backend == 'nccl' else torch.device('cpu')
+    ck = ddist.broadcast_checkpoint(ck, src=0, device=coll_dev)
     log('checkpoint ready')
 
     class Worker:
@@ -247,13 +256,13 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     log(f'timed region done: {elapsed / args.steps * 1e3:.1f} ms/step ({S * B} pairs/step/GPU)')
     T = np.concatenate([w.result[0] for w in workers]); status = np.concatenate([w.result[1] for w in workers])
     stats = np.concatenate([w.result[2] for w in workers])
-    gathered = ddist.gather_results(T, status, stats, dst=0, device=device)
+    gathered = ddist.gather_results(T, status, stats, dst=0, device=coll_dev)
     w0 = workers[0]
     dgr, pairs, off0, off1, C0, X0, C1, X1, idx1 = w0.dgr, w0.pairs, w0.off0, w0.off1, w0.C0, w0.X0, w0.C1, w0.X1, w0.idx1
     t_vox = w0.t_vox
