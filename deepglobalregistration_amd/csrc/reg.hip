@@ -283,6 +283,7 @@ __global__ void __launch_bounds__(REG_THREADS) registration_kernel(RegArgs a) {
   for (int i = 0; i < 9; ++i) { am[i] = 0.f; av[i] = 0.f; }
   const float w1 = (float)S[1];  // loss_fn.w1 = weights.sum(), core/loss.py:48-49
   const float q = a.q;
+  const float inv_q = 1.f / q;
 #ifdef DGR_REG_TIMING
   long long tsum[3] = {0, 0, 0};
 #endif
@@ -311,7 +312,15 @@ __global__ void __launch_bounds__(REG_THREADS) registration_kernel(RegArgs a) {
       const float px = A.x * R00 + A.y * R01 + A.z * R02 + prm[6];
       const float py = A.x * R10 + A.y * R11 + A.z * R12 + prm[7];
       const float pz = A.x * R20 + A.y * R21 + A.z * R22 + prm[8];
+      // `(X - Y) / quantization_size` (core/loss.py:54) divides a tensor by a Python scalar: on the reference's CUDA
+      // device ATen evaluates that as a multiplication by the f32 reciprocal (div_true_kernel_cuda, "compute
+      // a * reciprocal(b)"), on the CPU as a true division.  The multiplication also saves three ~10-instruction
+      // IEEE divisions per point (-12 % per iteration); -DDGR_REG_TRUE_DIV gives the CPU behaviour.
+#ifndef DGR_REG_TRUE_DIV
+      const float rx = (px - B.x) * inv_q, ry = (py - B.y) * inv_q, rz = (pz - B.z) * inv_q;
+#else
       const float rx = (px - B.x) / q, ry = (py - B.y) / q, rz = (pz - B.z) / q;
+#endif
       const float s = rx * rx + ry * ry + rz * rz;
       float per, dps;
       if (s < 1.f) {
