@@ -331,7 +331,11 @@ __global__ void __launch_bounds__(REG_THREADS) registration_kernel(RegArgs a) {
         per = 0.5f * (rt - 0.5f);  // discontinuous at s == 1 like core/loss.py:55-56
         dps = 0.25f / rt;
       }
+#ifndef DGR_REG_TRUE_DIV
+      const float wk = A.w * dps * 2.f * inv_q;   // DivBackward by the same scalar: again a reciprocal multiply
+#else
       const float wk = A.w * dps * 2.f / q;
+#endif
       const float gx = wk * rx, gy = wk * ry, gz = wk * rz;
       g[0] += per * A.w;
       g[1] += gx; g[2] += gy; g[3] += gz;
