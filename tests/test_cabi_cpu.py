@@ -49,3 +49,27 @@ def test_product_does_not_import_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f
                 assert '/root/reference' not in src, f
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """The boundary is a C ABI: include/dgr_hip.h must compile as C99 (no C++ / torch types in the signatures)
+    and a C program must link against libdgr_hip.so and call into it (dgr_version needs no GPU)."""
+    import os
+    import shutil
+    import subprocess
+    if shutil.which('gcc') is None:
+        pytest.skip('no gcc')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, 'deepglobalregistration_amd', 'lib')
+    if not os.path.exists(os.path.join(lib_dir, 'libdgr_hip.so')):
+        pytest.skip('library not built')
+    src = tmp_path / 'c_abi.c'
+    src.write_text('#include <stdio.h>\n#include "dgr_hip.h"\n'
+                   'int main(void) { dgr_params p; p.max_iter = 1000; (void)p;\n'
+                   '  printf("%s\\n", dgr_version()); return dgr_last_error() == 0; }\n')
+    exe = tmp_path / 'c_abi'
+    subprocess.run(['gcc', '-std=c99', '-Wall', '-Wextra', '-pedantic', '-Werror', '-I', os.path.join(root, 'include'),
+                    str(src), '-o', str(exe), '-L', lib_dir, '-ldgr_hip', f'-Wl,-rpath,{lib_dir}',
+                    '-Wl,-rpath,/opt/rocm/lib'], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    assert 'dgr_hip' in out
