@@ -103,3 +103,50 @@ def test_resunet_forward_shapes_and_row_alignment():
     perm = rng.permutation(len(pts))
     Fp = resunet.resunet_forward(sd, coords[perm], np.ones((len(pts), 1), np.float32), 3, 5, True)
     np.testing.assert_allclose(Fp, F[perm], atol=2e-5)
+
+
+# ---- randomized properties of the restatement (hypothesis): internal consistency of the conventions --------
+from hypothesis import given, settings, strategies as st
+
+
+def _random_coords(seed, n, D, extent, batches):
+    rng = np.random.default_rng(seed)
+    c = np.concatenate([rng.integers(0, batches, (n, 1)), rng.integers(-extent, extent, (n, D))], axis=1).astype(np.int32)
+    _, first = np.unique(c, axis=0, return_index=True)
+    return c[np.sort(first)]
+
+
+@settings(max_examples=25, deadline=None)
+@given(seed=st.integers(0, 10 ** 6), D=st.sampled_from([3, 6]), n=st.integers(1, 300), ts=st.sampled_from([1, 2, 4]))
+def test_same_stride_maps_are_symmetric_and_contain_the_identity(seed, D, n, ts):
+    c = _random_coords(seed, n, D, 4 if D == 6 else 8, 2)
+    c[:, 1:] *= ts
+    k, i, o = me.kernel_map(c, c, D, 3, ts)
+    K = 3 ** D
+    pairs = set(zip(k.tolist(), i.tolist(), o.tolist()))
+    assert len(pairs) == len(k)                                     # no duplicates
+    assert pairs == {(K - 1 - kk, oo, ii) for kk, ii, oo in pairs}  # (o,k)->i  <=>  (i,K-1-k)->o
+    centre = [(kk, ii, oo) for kk, ii, oo in pairs if kk == K // 2]
+    assert sorted(ii for _, ii, _ in centre) == list(range(len(c))) and all(ii == oo for _, ii, oo in centre)
+    # the defining relation: in = out + delta_k * ts
+    off = me.kernel_offsets(D, 3)
+    np.testing.assert_array_equal(c[i][:, 1:], c[o][:, 1:] + off[k] * ts)
+    np.testing.assert_array_equal(c[i][:, 0], c[o][:, 0])
+
+
+@settings(max_examples=25, deadline=None)
+@given(seed=st.integers(0, 10 ** 6), D=st.sampled_from([3, 6]), n=st.integers(1, 300))
+def test_stride_maps_and_their_transpose(seed, D, n):
+    fine = _random_coords(seed, n, D, 6, 2)
+    coarse = me.stride_coords(fine, 2)
+    assert (coarse[:, 1:] % 2 == 0).all() and len(np.unique(coarse, axis=0)) == len(coarse)
+    np.testing.assert_array_equal(me.stride_coords(coarse, 2), coarse)          # idempotent
+    # every fine row lies in exactly one coarse cell, and that cell exists
+    cell = fine.copy(); cell[:, 1:] = (fine[:, 1:] // 2) * 2
+    assert {tuple(r) for r in cell.tolist()} == {tuple(r) for r in coarse.tolist()}
+    k, i, o = me.kernel_map(fine, coarse, D, 3, 1)                              # strided conv: fine -> coarse
+    kt, it, ot = me.transposed_kernel_map(coarse, fine, D, 3, 1)                # transposed conv: coarse -> fine
+    assert set(zip(k.tolist(), i.tolist(), o.tolist())) == set(zip(kt.tolist(), ot.tolist(), it.tolist()))
+    # each fine row reaches its own cell through the offset 0 or +1 per axis (floor semantics), so every fine
+    # row appears at least once as an input of the strided conv
+    assert set(i.tolist()) == set(range(len(fine)))
