@@ -5,7 +5,9 @@ reference, dataloader/threedmatch_loader.py:192-195).  Host-side Python like the
 from .formats import (load_cloud, read_kitti_bin, read_ply, read_trajectory, write_kitti_bin, write_ply,
                       write_trajectory)
 from .harness import ThreeDMatchTrajectory, analyze_stats, evaluate
+from .kitti import KITTIOdometryPairs, evaluate_kitti, relative_velodyne_pose
 from .metrics import rte_rre
 
 __all__ = ['rte_rre', 'read_trajectory', 'write_trajectory', 'read_kitti_bin', 'write_kitti_bin', 'read_ply',
-           'write_ply', 'load_cloud', 'ThreeDMatchTrajectory', 'evaluate', 'analyze_stats']
+           'write_ply', 'load_cloud', 'ThreeDMatchTrajectory', 'evaluate', 'analyze_stats', 'KITTIOdometryPairs',
+           'evaluate_kitti', 'relative_velodyne_pose']

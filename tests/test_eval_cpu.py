@@ -106,3 +106,46 @@ def test_harness_on_a_synthetic_trajectory_dataset(tmp_path):
     np.testing.assert_array_equal(stats[0, :, 4], [0, 0, 1, 1])
     assert summary['stub']['recall'] == 0.5 and summary['stub']['mean_successful'][1] < 1e-9
     assert scene_means.shape == (1, 2, 3) and scene_means[0, 0, 0] == 0.5 and lines
+
+
+def test_kitti_pairs_ground_truth_and_loop(tmp_path):
+    """A synthetic mini odometry sequence: a static world seen from a vehicle driving 2.5 m per frame."""
+    rng = np.random.default_rng(3)
+    root = tmp_path / 'dataset'
+    (root / 'sequences' / '03' / 'velodyne').mkdir(parents=True)
+    (root / 'poses').mkdir()
+    world = rng.uniform(-60, 60, (4000, 3)); world[:, 2] = rng.uniform(-2, 3, 4000)
+    V = ev.kitti.VELO2CAM
+    poses = []
+    for f in range(12):
+        # camera-0 pose: drive along the camera z axis with a slow yaw about the camera y axis
+        a = 0.02 * f
+        P = np.eye(4)
+        P[:3, :3] = [[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]]
+        P[:3, 3] = [0.1 * f, 0.0, 2.5 * f]
+        poses.append(P)
+        velo_T_world = np.linalg.inv(P @ V)            # world -> velodyne frame f (world = camera-0 frame of frame 0)
+        pts = world @ velo_T_world[:3, :3].T + velo_T_world[:3, 3]
+        ev.write_kitti_bin(root / 'sequences' / '03' / 'velodyne' / f'{f:06d}.bin', pts)
+    np.savetxt(root / 'poses' / '03.txt', np.array([P[:3].reshape(-1) for P in poses]))
+    ds = ev.KITTIOdometryPairs(str(root), [3])
+    # 10 m is first exceeded 4 frames later (10.008 m); the 3DFeatNet rule takes the frame before that one
+    assert ds.files == [(3, 0, 3), (3, 4, 7)]        # frames 8..11 never get 10 m apart
+    drive, x0, x1, T = ds[0]
+    assert drive == 3 and x0.dtype == np.float32 and x0.shape == (4000, 3)
+    np.testing.assert_allclose(x0.astype(np.float64) @ T[:3, :3].T + T[:3, 3], x1, atol=2e-4)   # x1 = T x0
+    np.testing.assert_allclose(T, ev.relative_velodyne_pose(poses[0], poses[3]), atol=1e-12)
+    # an ICP hook is applied the way the reference caches its refined poses (M @ reg)
+    nudge = np.eye(4); nudge[0, 3] = 0.01
+    ds2 = ev.KITTIOdometryPairs(str(root), [3], icp_refine=lambda s, d, init: nudge)
+    np.testing.assert_allclose(ds2[0][3], T @ nudge, atol=1e-12)
+
+    class Perfect:
+        def register(self, a, b):
+            return T_of[(len(a), float(a[0, 0]))]
+    T_of = {(len(ds[k][1]), float(ds[k][1][0, 0])): ds[k][3] for k in range(len(ds))}
+    lines = []
+    stats, summary = ev.evaluate_kitti(Perfect(), ds, out=lines.append)
+    assert stats.shape == (2, 5) and summary['recall'] == 1.0 and (stats[:, 4] == 3).all() and lines
+    with pytest.raises(FileNotFoundError):
+        ev.KITTIOdometryPairs(str(root), [7])
