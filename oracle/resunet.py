@@ -98,12 +98,13 @@ def basic_block(x, kmap, sd, prefix, n):
 
 
 def resunet_forward(sd, coords, feats, D, conv1_ks, normalize_feature, maps=None,
-                    return_intermediates=False):
+                    return_intermediates=False, dtype=torch.float32):
     """`ResUNet2.forward`, model/resunet.py:598-649.  `sd` is a state_dict
     with MinkowskiEngine key names; coords int32 [N,1+D]; feats f32 [N,Cin].
     Returns the output feature matrix [N,Cout] row-aligned with the input."""
     sd = {k: (torch.as_tensor(v) if not torch.is_tensor(v) else v) for k, v in sd.items()}
-    x = torch.as_tensor(np.asarray(feats), dtype=torch.float32)
+    sd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}   # f32 = the reference's arithmetic
+    x = torch.as_tensor(np.asarray(feats), dtype=dtype)
     if maps is None:
         maps = SparseMaps(coords, D, conv1_ks)
     n = {ts: len(c) for ts, c in maps.coords.items()}

@@ -63,3 +63,14 @@ def assert_refine_parity(X, Y, w, R, t, stats, tol=1e-4, window=40, **kw):
     band = max(max(np.abs(Ri - Ro).max(), np.abs(ti - to).max()) for Ri, ti in tail)
     assert dR <= max(tol, band) and dt <= max(tol, band), (dR, dt, band, so, stats)
     return Ro, to, so
+
+
+def oracle_pair_counts(maps, conv1_ks):
+    """Kernel-map pair count of every conv of ResUNetBN2C in forward order (23 entries), from the
+    oracle's maps (`oracle.resunet.SparseMaps`); k = 1 convs count one pair per row."""
+    n1 = len(maps.coords[1])
+    same = {ts: len(maps.same(ts)[0]) for ts in (1, 2, 4, 8)}
+    down = {ts: len(maps.down(ts)[0]) for ts in (1, 2, 4)}
+    c1 = len(maps.same(1, conv1_ks)[0])
+    return [c1, same[1], same[1], down[1], same[2], same[2], down[2], same[4], same[4], down[4], same[8], same[8],
+            down[4], same[4], same[4], down[2], same[2], same[2], down[1], same[1], same[1], n1, n1]
