@@ -1,25 +1,32 @@
 #!/usr/bin/env python
 """Benchmark of the DGR inference hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--pairs-per-step B] [--n-raw 50000]
+    python bench.py --gpus N --steps K --warmup W [--pairs-per-step B] [--streams S] [--total-pairs P]
 
 One "step" = one pass of the hot path (FCGF x2 -> 1-NN -> 6-D inputs -> 6-D inlier net -> gate ->
-weighted Procrustes -> SE(3) refinement; dgr_register_batch) over S x B synthetic 3DMatch-shaped
-pairs per GPU (BASELINE.json configs[1]: 50k raw points per fragment, 5 cm voxels, conv1 k=7)
-whose voxelised coordinates are already resident in HBM: S HIP streams, each driven by its own host
-thread with its own library context, each registering its own batch of B pairs (pairs are
-independent units, streams never exchange data; the second and third stream fill the holes the
-small map-building kernels of the first leave on the chip).  With N > 1 (launched through
-torch.distributed.run, one process per GPU) every rank registers its own S x B pairs (weak scaling,
-no collective on the data path), the weights come from rank 0 by ONE RCCL broadcast and the results
-are gathered on rank 0.
+weighted Procrustes -> SE(3) refinement; `dgr_register_batch`) over synthetic 3DMatch-shaped pairs
+(BASELINE.json configs[1]: 50k raw points per fragment, 5 cm voxels, conv1 k=7) whose voxelised
+coordinates are already resident in HBM.  Per GPU: S HIP streams, each driven by its own host thread
+with its own library context, each registering batches of B pairs (pairs are independent units,
+streams never exchange data).
+
+* default (weak scaling): every rank registers its own S x B pairs per step;
+* `--total-pairs P` (strong scaling, BASELINE configs[3] with P = 512): P pairs are dealt over the
+  ranks by cost (N0 * N1, sorted, snake round-robin: `dist.deal_by_cost`), a step = one pass over all P.
+
+With N > 1 the script runs one process per GPU under `torch.distributed.run` (it re-executes itself
+under the launcher when started plainly with `--gpus N`); the weights come from rank 0 by ONE RCCL
+broadcast, the results are gathered on rank 0, no collective on the data path.
 
 Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for the definition of every field.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -29,67 +36,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md, dense
 PEAK_HBM_GBPS = 8000.0          # spec
-
-
-def conv_work(stats):
-    """Algorithmic work of one net forward from the per-layer statistics:
-    FLOP = 2 P Cin Cout; compulsory bytes = 4 (Nin Cin + Nout Cout + Kne Cin Cout) + 8 P."""
-    flop = sum(2.0 * s['pairs'] * s['cin'] * s['cout'] for s in stats)
-    byts = sum(4.0 * (s['n_in'] * s['cin'] + s['n_out'] * s['cout'] + s['nonempty'] * s['cin'] * s['cout'])
-               + 8.0 * s['pairs'] for s in stats)
-    flop_c64 = sum(2.0 * s['pairs'] * s['cin'] * s['cout'] for s in stats if max(s['cin'], s['cout']) <= 64)
-    byts_c64 = sum(4.0 * (s['n_in'] * s['cin'] + s['n_out'] * s['cout'] + s['nonempty'] * s['cin'] * s['cout'])
-                   + 8.0 * s['pairs'] for s in stats if max(s['cin'], s['cout']) <= 64)
-    return flop, byts, flop_c64, byts_c64
-
-
-def cpu_baseline(ck, n_raw, voxel, kind, full_sizes):
-    """The CPU oracle (restated reference CPU path, kind "port") timed on this host's cores on a
-    BOUNDED sample of the same workload: one pair generated like the benchmark pairs but with a
-    quarter of the raw points; every stage runs completely on that pair and its time is scaled to
-    the full-size pair (conv stacks and registration linearly in the voxel count, the brute-force
-    1-NN by N0*N1).  Reported baseline, not a target."""
-    from deepglobalregistration_amd import synth
-    from oracle import knn as oknn, pipeline as opipe, registration as oreg, resunet as oresunet
-    threads = max(1, min(16, os.cpu_count() or 1))
-    torch.set_num_threads(threads)
-    xyz0, xyz1, T_gt = synth.synth_pair(0, n_raw=max(2000, n_raw // 4), kind=kind)
-    t = {}
-    t0 = time.time()
-    p0, c0, f0 = opipe.preprocess(xyz0, voxel)
-    p1, c1, f1 = opipe.preprocess(xyz1, voxel)
-    t['voxelize'] = time.time() - t0
-    n0, n1 = len(p0), len(p1)
-    s_lin = (full_sizes[0] + full_sizes[1]) / float(n0 + n1)
-    s0 = full_sizes[0] / float(n0)
-    s_knn = (full_sizes[0] * full_sizes[1]) / float(n0 * n1)
-    ks = ck['config']['feat_conv1_kernel_size']
-    t0 = time.time()
-    F0 = oresunet.resunet_forward(ck['state_dict'], c0, f0, 3, ks, True)
-    F1 = oresunet.resunet_forward(ck['state_dict'], c1, f1, 3, ks, True)
-    t['fcgf'] = (time.time() - t0) * s_lin
-    t0 = time.time()
-    idx1 = oknn.find_knn(F0, F1, nn_max_n=250).reshape(-1)
-    t['knn'] = (time.time() - t0) * s_knn
-    gt = synth.gt_correspondences(p0, p1, T_gt, voxel)
-    idx1 = np.where(gt >= 0, gt, idx1)          # same harness override as the GPU run
-    t0 = time.time()
-    coords6, feats6 = opipe.inlier_inputs(p0, p1, c0, c1, np.arange(n0), idx1)
-    oresunet.resunet_forward(ck['state_dict_inlier'], coords6, feats6, 6, 3, False)
-    t['inlier_net'] = (time.time() - t0) * s0
-    t0 = time.time()
-    w, wsum, thr = opipe.confidence_gate(synth.gt_forced_logits(p0, p1[idx1], T_gt, voxel))
-    if wsum >= thr:
-        oreg.global_registration(p0, p1[idx1], w, break_threshold_ratio=1e-4, quantization_size=2 * voxel)
-    t['registration'] = (time.time() - t0) * s0
-    total = t['fcgf'] + t['knn'] + t['inlier_net'] + t['registration']
-    return {'value': 1.0 / total, 'unit': 'pairs/s', 'cores': threads, 'kind': 'port',
-            'sample': f'1 pair with {max(2000, n_raw // 4)} raw pts/fragment ({n0}/{n1} voxels), all stages, '
-                      f'times scaled to {full_sizes[0]}/{full_sizes[1]} voxels (conv/registration linear, 1-NN by N0*N1); '
-                      'voxelisation excluded',
-            'scaled_stage_s': {k: round(v, 3) for k, v in t.items()}}
-
 
 _T0 = time.time()
 
@@ -102,49 +50,202 @@ def log(msg):
 def cfg_label(args):
     """Which BASELINE.json config the chosen flags correspond to (only the default is the headline)."""
     key = (args.kind, args.n_raw, args.voxel, args.conv1_ks)
-    return {('indoor', 50000, 0.05, 7): 'BASELINE configs[1]',
+    base = {('indoor', 50000, 0.05, 7): 'BASELINE configs[1]',
             ('outdoor', 120000, 0.3, 5): 'BASELINE configs[2]',
             ('indoor', 200000, 0.025, 7): 'BASELINE configs[4]'}.get(key, 'non-BASELINE configuration')
+    if args.total_pairs and base == 'BASELINE configs[1]':
+        return f'BASELINE configs[3] shape: {args.total_pairs} pairs sharded over the ranks'
+    return base
+
+
+# ----------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without a torch.distributed environment re-executes itself
+# ----------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def relaunch_under_torchrun(n):
+    one_gpu = bool(os.environ.get('DGR_BENCH_ONE_GPU')) or '--launch-check' in sys.argv
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if ndev < n and not one_gpu:
+        print(f'bench.py: --gpus {n} requested but this node exposes {ndev} GPU(s); no extrapolation '
+              '(SURVEY.md 8e).  Run on a node with enough GPUs.', file=sys.stderr)
+        return 2
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}',
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+# ----------------------------------------------------------------------------------------------
+# roofline accounting
+# ----------------------------------------------------------------------------------------------
+def layer_bytes(s):
+    """Compulsory bytes of one conv layer: every input row once, every output row once,
+    every used weight slice once, one (in, out) int32 pair per map entry."""
+    return 4.0 * (s['n_in'] * s['cin'] + s['n_out'] * s['cout'] + s['nonempty'] * s['cin'] * s['cout']) + 8.0 * s['pairs']
+
+
+def layer_flop(s):
+    return 2.0 * s['pairs'] * s['cin'] * s['cout']
+
+
+def roofline_time_s(s):
+    return max(layer_bytes(s) / (PEAK_HBM_GBPS * 1e9), layer_flop(s) / (PEAK_FP32_MFMA_TFLOPS * 1e12))
+
+
+# ----------------------------------------------------------------------------------------------
+# CPU legs (rank 0, N = 1 only): parity of the timed batch's pair 0 against the oracle, and the
+# oracle timed as the reported CPU baseline.  The oracle is the checker, never the measured product.
+# ----------------------------------------------------------------------------------------------
+def oracle_parity_and_baseline(ck, args, pair0, do_baseline):
+    """pair0 = dict(xyz0, coords0, xyz1, coords1 [numpy, batch column 0], idx1 [local], F0, F1, logit, forced).
+    Returns (parity dict, cpu_baseline dict | None)."""
+    from oracle import knn as oknn, pipeline as opipe, registration as oreg, resunet as oresunet
+    threads = max(1, min(16, os.cpu_count() or 1))
+    torch.set_num_threads(threads)
+    ks = ck['config']['feat_conv1_kernel_size']
+    p0, c0, p1, c1 = pair0['xyz0'], pair0['coords0'], pair0['xyz1'], pair0['coords1']
+    n0, n1 = len(p0), len(p1)
+    t = {}
+    t0 = time.time()
+    oF0 = oresunet.resunet_forward(ck['state_dict'], c0, np.ones((n0, 1), np.float32), 3, ks, True)
+    oF1 = oresunet.resunet_forward(ck['state_dict'], c1, np.ones((n1, 1), np.float32), 3, ks, True)
+    t['fcgf'] = time.time() - t0
+    t0 = time.time()
+    c6, f6 = opipe.inlier_inputs(p0, p1, c0, c1, np.arange(n0), pair0['idx1'])
+    ologit = oresunet.resunet_forward(ck['state_dict_inlier'], c6, f6, 6, 3, False).reshape(-1)
+    t['inlier_net'] = time.time() - t0
+    parity = {'pair': 0, 'voxels': [n0, n1],
+              'dF': float(max(np.abs(pair0['F0'] - oF0).max(), np.abs(pair0['F1'] - oF1).max())),
+              'dlogit_rel': float(np.abs(pair0['logit'] - ologit).max() / max(1e-12, np.abs(ologit).max())),
+              'tolerance': 1e-4,
+              'what': 'F0/F1 and the 6-D logits of pair 0 of the timed batch (HIP, dgr_register_batch) vs '
+                      'oracle.resunet.resunet_forward on identical voxels / correspondences; computed outside '
+                      'the timed region'}
+    parity['ok'] = bool(parity['dF'] < 1e-4 and parity['dlogit_rel'] < 1e-4)
+    if not do_baseline:
+        return parity, None
+    # 1-NN: a bounded sample -- the first `nq` query rows against ALL reference rows, chunked like the
+    # reference (nn_max_n = 250); the search is row-independent, so the full time is the sample x N0 / nq
+    nq = min(n0, 1500)
+    runs = []
+    for _ in range(3):
+        t0 = time.time()
+        oknn.find_knn(oF0[:nq], oF1, nn_max_n=250)
+        runs.append(time.time() - t0)
+    t['knn'] = float(np.median(runs)) * n0 / nq
+    w, wsum, thr = opipe.confidence_gate(pair0['forced'])
+    runs = []
+    for _ in range(3):
+        t0 = time.time()
+        if wsum >= thr:
+            oreg.global_registration(p0, p1[pair0['idx1']], w, break_threshold_ratio=1e-4, quantization_size=2 * args.voxel)
+        runs.append(time.time() - t0)
+    t['registration'] = float(np.median(runs))
+    total = sum(t.values())
+    base = {'value': 1.0 / total, 'unit': 'pairs/s', 'cores': threads, 'kind': 'port',
+            'sample': f'pair 0 of the timed batch at FULL size ({n0}/{n1} voxels): FCGF x2 and 6-D net one run each, '
+                      f'registration median of 3, 1-NN on the first {nq} of {n0} query rows vs all {n1} reference rows '
+                      f'(median of 3, scaled by N0/{nq}); voxelisation excluded',
+            'stage_s': {k: round(v, 3) for k, v in t.items()},
+            'reference_modules_in_container': {
+                'note': 'the reference\'s own core/knn.py / core/registration.py timed on CPU tensors in the build '
+                        'container (8 cores, torch 2.10; BASELINE.md section 2) -- /root/reference is absent on the GPU box',
+                'find_knn_gpu_26422x24182x32_s': 25.96, 'weighted_procrustes_N26422_ms': 0.88,
+                'GlobalRegistration_N26422_s': 1.19}}
+    return parity, base
+
+
+# ----------------------------------------------------------------------------------------------
+def launch_check(args, rank, world, backend):
+    """CPU-only check of the multi-rank plumbing (tests/test_bench_launcher_cpu.py): rendezvous, weight
+    broadcast, cost-balanced dealing, max-over-ranks timing, result gather -- no GPU work."""
+    import torch.distributed as dist
+    from deepglobalregistration_amd import dist as ddist, synth
+    ck = synth.synth_checkpoint(seed=0, feat_conv1_kernel_size=3, with_inlier=False) if rank == 0 else None
+    ck = ddist.broadcast_checkpoint(ck, src=0, device=torch.device('cpu'))
+    P = args.total_pairs or world * args.streams * args.pairs_per_step
+    lo, hi = ddist.shard_range(P, rank, world)
+    rng = np.random.default_rng(1234)
+    all_cost = rng.uniform(1.0, 2.0, P)                     # stand-in for N0 * N1 of the provisional block
+    cost = ddist.all_gather_vector(all_cost[lo:hi], P, lo, device=torch.device('cpu'))
+    mine = ddist.deal_by_cost(cost, world)[rank]
+    T = np.tile(np.eye(4), (len(mine), 1, 1))
+    T[:, 0, 3] = mine
+    out = ddist.gather_results(T, np.zeros(len(mine), np.int32), np.zeros((len(mine), 4), np.float32), dst=0,
+                               device=torch.device('cpu'))
+    tt = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        ids = sorted(int(v) for v in out[0][:, 0, 3])
+        print(json.dumps({'launch_check': True, 'n_gpus': world, 'requested_gpus': args.gpus, 'backend': backend,
+                          'pairs': P, 'all_pairs_covered_once': ids == list(range(P)), 'max_over_ranks': float(tt.item()),
+                          'weights_broadcast_keys': len(ck['state_dict'])}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--pairs-per-step', type=int, default=4, help='pairs per stream per step')
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--pairs-per-step', type=int, default=4, help='pairs per batch (one dgr_register_batch)')
+    ap.add_argument('--total-pairs', type=int, default=0, help='strong-scaling mode: this many pairs in total, dealt '
+                    'over the ranks by cost; a step = one pass over all of them (BASELINE configs[3]: 512)')
     ap.add_argument('--n-raw', type=int, default=50000, help='raw points per fragment')
     ap.add_argument('--voxel', type=float, default=0.05)
     ap.add_argument('--kind', default='indoor', choices=['indoor', 'outdoor'])
     ap.add_argument('--conv1-ks', type=int, default=7)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-parity', action='store_true', help='skip the oracle comparison of pair 0 (about 30 s of CPU)')
     ap.add_argument('--no-refine', action='store_true', help='ablation: stop after weighted Procrustes')
     ap.add_argument('--from-host', action='store_true', help='PCIe-inclusive variant (NOT the headline): every step '
                     'starts from the raw float64 host points (H2D copy + GPU voxelisation inside the timed region)')
     ap.add_argument('--streams', type=int, default=3, help='HIP streams per GPU, each driven by its own host '
-                    'thread with its own library context and its own batch of pairs (independent units)')
+                    'thread with its own library context and its own batches of pairs (independent units)')
+    ap.add_argument('--launch-check', action='store_true', help='CPU-only check of the multi-rank plumbing')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(relaunch_under_torchrun(args.gpus))
 
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     import torch.distributed as dist
-    # test hooks (a 1-GPU box cannot run RCCL between two ranks): DGR_BENCH_BACKEND=gloo moves the two tiny
+    # test hooks (a 1-GPU box cannot run RCCL between two ranks): DGR_BENCH_BACKEND=gloo moves the tiny
     # collectives to the CPU, DGR_BENCH_ONE_GPU=1 puts every rank on device 0; the driver sets neither
-    backend = os.environ.get('DGR_BENCH_BACKEND', 'nccl')
+    backend = os.environ.get('DGR_BENCH_BACKEND', 'gloo' if args.launch_check else 'nccl')
     if os.environ.get('DGR_BENCH_ONE_GPU'):
         local_rank = 0
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local_rank)
         if backend == 'nccl':
+            torch.cuda.set_device(local_rank)
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         else:
             dist.init_process_group(backend)
+        assert dist.get_world_size() == world
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)')
+    if args.launch_check:
+        return launch_check(args, rank, world, backend)
     assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback)'
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
+    if world > 1:
+        log(f'{dist.get_backend()} process group up: {dist.get_world_size()} ranks (backend "nccl" = RCCL on ROCm)')
 
     from deepglobalregistration_amd import _lib, dist as ddist, ops, synth
     from deepglobalregistration_amd.core.deep_global_registration import DeepGlobalRegistration
@@ -156,15 +257,40 @@ def main():
     ck = ddist.broadcast_checkpoint(ck, src=0, device=coll_dev)
     log('checkpoint ready')
 
-    class Worker:
-        """One HIP stream + one library context + one resident batch of B pairs, driven by one host
-        thread.  Pairs are independent units, so streams never exchange data."""
+    # ---- which pairs does this rank register? --------------------------------------------------
+    vox_cache = {}
 
-        def __init__(self, wid):
-            self.wid = wid
+    def voxelised(seed):
+        """Pair `seed`: raw points, voxelised tensors on the device, ground-truth pose (cached)."""
+        if seed not in vox_cache:
+            a, b, Tg = synth.synth_pair(seed, n_raw=args.n_raw, kind=args.kind)
+            xa, ca, _ = ops.voxelize(a, args.voxel, 0, device)
+            xb, cb, _ = ops.voxelize(b, args.voxel, 0, device)
+            vox_cache[seed] = (a, b, Tg, xa, ca, xb, cb)
+        return vox_cache[seed]
+
+    if args.total_pairs:
+        P = args.total_pairs
+        lo, hi = ddist.shard_range(P, rank, world)          # provisional contiguous block: measure its costs
+        costs = [float(len(voxelised(s)[3])) * float(len(voxelised(s)[5])) for s in range(lo, hi)]
+        cost = ddist.all_gather_vector(costs, P, lo, device=coll_dev)
+        my_pairs = ddist.deal_by_cost(cost, world)[rank]    # sorted by N0 * N1, dealt snake round-robin
+        log(f'strong scaling: {P} pairs dealt by cost, this rank {len(my_pairs)} (cost share '
+            f'{cost[my_pairs].sum() / cost.sum():.4f})')
+    else:
+        my_pairs = [rank * S * B + i for i in range(S * B)]  # weak scaling: S x B own pairs per rank
+    # batches of B pairs, dealt over the S streams
+    batches = [my_pairs[i:i + B] for i in range(0, len(my_pairs), B)]
+    per_stream = [batches[w::S] for w in range(S)]
+
+    class Worker:
+        """One HIP stream + one library context + its resident batches, driven by one host thread."""
+
+        def __init__(self, wid, batch_ids):
+            self.wid, self.batch_ids = wid, batch_ids
             self.ctx = _lib.new_ctx(device) if S > 1 else None
             self.stream = torch.cuda.Stream(device) if S > 1 else torch.cuda.current_stream(device)
-            self.result = None
+            self.results = []
 
         def __enter__(self):
             _lib.use_ctx(self.ctx)
@@ -181,71 +307,74 @@ def main():
                 self.dgr = DeepGlobalRegistration({'weights': ck, 'clip_weight_thresh': 0.05}, device)
                 dgr = self.dgr
                 dgr.fcgf_model._handle(); dgr.inlier_model._handle()
-                base = (rank * S + self.wid) * B          # this worker's pairs: seeds base .. base+B-1
-                self.pairs = [synth.synth_pair(base + i, n_raw=args.n_raw, kind=args.kind) for i in range(B)]
-                x0, c0, x1, c1, self.off0, self.off1 = [], [], [], [], [0], [0]
-                t0 = time.time()
-                for p, (a, b, _) in enumerate(self.pairs):
-                    xa, ca, _ = dgr.preprocess(a, batch_index=p)
-                    xb, cb, _ = dgr.preprocess(b, batch_index=p)
-                    x0.append(xa); c0.append(ca); x1.append(xb); c1.append(cb)
-                    self.off0.append(self.off0[-1] + len(xa)); self.off1.append(self.off1[-1] + len(xb))
-                torch.cuda.synchronize()
-                self.t_vox = (time.time() - t0) / B
-                self.C0, self.X0, self.C1, self.X1 = torch.cat(c0), torch.cat(x0), torch.cat(c1), torch.cat(x1)
-                off0, off1 = self.off0, self.off1
-                # harness-only overrides (DESIGN.md "Synthetic workload"): untrained weights give ~0 %
-                # correct matches and a meaningless confidence, so a share of the 1-NN results is replaced
-                # by ground-truth matches AFTER the search ran and the logits by GT-derived ones AFTER the
-                # inlier net ran.
-                X0h, X1h = self.X0.cpu().numpy(), self.X1.cpu().numpy()
-                self.ovr = torch.from_numpy(np.concatenate([
-                    (lambda g, o: np.where(g >= 0, g + o, -1))(
-                        synth.gt_correspondences(X0h[off0[p]:off0[p + 1]], X1h[off1[p]:off1[p + 1]], self.pairs[p][2],
-                                                 args.voxel, seed=p), off1[p]) for p in range(B)])).to(device)
-                self.forced = None
-                self.step()                                # untimed: final correspondences for the forced logits
-                torch.cuda.synchronize()
-                self.idx1 = ops.batch_output(device, 'idx1').cpu().numpy()
-                self.forced = torch.from_numpy(np.concatenate([
-                    synth.gt_forced_logits(X0h[off0[p]:off0[p + 1]], X1h[self.idx1[off0[p]:off0[p + 1]]],
-                                           self.pairs[p][2], args.voxel) for p in range(B)])).to(device)
+                self.batches = []
+                for ids in self.batch_ids:
+                    x0, c0, x1, c1, off0, off1, ovr = [], [], [], [], [0], [0], []
+                    for q, seed in enumerate(ids):
+                        a, b, Tg, xa, ca, xb, cb = voxelised(seed)
+                        ca, cb = ca.clone(), cb.clone()
+                        ca[:, 0] = q; cb[:, 0] = q
+                        # harness-only override (DESIGN.md "Synthetic workload"): untrained weights give ~0 %
+                        # correct matches, so a share of the 1-NN results is replaced by ground-truth matches
+                        # AFTER the search ran
+                        g = synth.gt_correspondences(xa.cpu().numpy(), xb.cpu().numpy(), Tg, args.voxel, seed=seed)
+                        ovr.append(np.where(g >= 0, g + off1[-1], -1))
+                        x0.append(xa); c0.append(ca); x1.append(xb); c1.append(cb)
+                        off0.append(off0[-1] + len(xa)); off1.append(off1[-1] + len(xb))
+                    bt = {'ids': ids, 'C0': torch.cat(c0), 'X0': torch.cat(x0), 'C1': torch.cat(c1), 'X1': torch.cat(x1),
+                          'off0': off0, 'off1': off1, 'ovr': torch.from_numpy(np.concatenate(ovr)).to(device),
+                          'forced': None, 'raw': [(vox_cache[s][0], vox_cache[s][1]) for s in ids]}
+                    # ... and the inlier logits by GT-derived ones AFTER the inlier net ran: one untimed call
+                    # yields the final correspondences the forced logits are derived from
+                    self.run_batch(bt)
+                    torch.cuda.synchronize()
+                    idx1 = ops.batch_output(device, 'idx1').cpu().numpy()
+                    X0h, X1h = bt['X0'].cpu().numpy(), bt['X1'].cpu().numpy()
+                    bt['idx1'] = idx1
+                    bt['forced'] = torch.from_numpy(np.concatenate([
+                        synth.gt_forced_logits(X0h[off0[q]:off0[q + 1]], X1h[idx1[off0[q]:off0[q + 1]]],
+                                               vox_cache[s][2], args.voxel) for q, s in enumerate(ids)])).to(device)
+                    self.batches.append(bt)
                 for _ in range(args.warmup):
                     self.step()
                 torch.cuda.synchronize()
 
-        def step(self):
-            if args.from_host and self.forced is not None:
+        def run_batch(self, bt):
+            if args.from_host and bt['forced'] is not None:
                 x0, c0, x1, c1 = [], [], [], []
-                for p, (a, b, _) in enumerate(self.pairs):
-                    xa, ca, _ = self.dgr.preprocess(a, batch_index=p)
-                    xb, cb, _ = self.dgr.preprocess(b, batch_index=p)
+                for q, (a, b) in enumerate(bt['raw']):
+                    xa, ca, _ = self.dgr.preprocess(a, batch_index=q)
+                    xb, cb, _ = self.dgr.preprocess(b, batch_index=q)
                     x0.append(xa); c0.append(ca); x1.append(xb); c1.append(cb)
-                self.C0, self.X0, self.C1, self.X1 = torch.cat(c0), torch.cat(x0), torch.cat(c1), torch.cat(x1)
-            return self.dgr.register_voxelized(self.C0, self.X0, self.off0, self.C1, self.X1, self.off1,
-                                               forced_logits=self.forced, skip_refinement=args.no_refine,
-                                               override_idx1=self.ovr)
+                bt['C0'], bt['X0'], bt['C1'], bt['X1'] = torch.cat(c0), torch.cat(x0), torch.cat(c1), torch.cat(x1)
+            return self.dgr.register_voxelized(bt['C0'], bt['X0'], bt['off0'], bt['C1'], bt['X1'], bt['off1'],
+                                               forced_logits=bt['forced'], skip_refinement=args.no_refine,
+                                               override_idx1=bt['ovr'])
+
+        def step(self):
+            self.results = [self.run_batch(bt) for bt in self.batches]
 
         def run(self, n):
             with self:
                 for _ in range(n):
-                    self.result = self.step()
+                    self.step()
 
-    workers = [Worker(w) for w in range(S)]
+    workers = [Worker(w, ids) for w, ids in enumerate(per_stream) if ids]
     for w in workers:
         w.prepare()
-    log(f'{S} stream(s) ready: weights resident, inputs voxelised (N0={workers[0].off0[-1]} N1={workers[0].off1[-1]} '
-        f'per batch of {B}), warm-up done')
+    n_local = sum(len(ids) for w in workers for ids in w.batch_ids)
+    b0 = workers[0].batches[0]
+    log(f'{len(workers)} stream(s) ready: weights resident, {n_local} pairs voxelised (first batch N0={b0["off0"][-1]} '
+        f'N1={b0["off1"][-1]}), warm-up done')
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    import threading
     barrier()
     t0 = time.perf_counter()
-    if S == 1:
+    if len(workers) == 1:
         workers[0].run(args.steps)
     else:
         threads = [threading.Thread(target=w.run, args=(args.steps,)) for w in workers]
@@ -259,146 +388,171 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    log(f'timed region done: {elapsed / args.steps * 1e3:.1f} ms/step ({S * B} pairs/step/GPU)')
-    T = np.concatenate([w.result[0] for w in workers]); status = np.concatenate([w.result[1] for w in workers])
-    stats = np.concatenate([w.result[2] for w in workers])
-    gathered = ddist.gather_results(T, status, stats, dst=0, device=coll_dev)
+    log(f'timed region done: {elapsed / args.steps * 1e3:.1f} ms/step ({n_local} pairs/step on this rank)')
+
     w0 = workers[0]
-    dgr, pairs, off0, off1, C0, X0, C1, X1, idx1 = w0.dgr, w0.pairs, w0.off0, w0.off1, w0.C0, w0.X0, w0.C1, w0.X1, w0.idx1
-    t_vox = w0.t_vox
-    all_pairs = [p for w in workers for p in w.pairs]
-
-    def step(forced=None):
-        return w0.step()
-    forced = w0.forced
     _lib.use_ctx(w0.ctx)
+    # outputs of the LAST call of stream 0 (the last batch of the last timed step), before anything else runs there
+    last_bt = w0.batches[-1]
+    with torch.cuda.stream(w0.stream):
+        hip_out = {k: ops.batch_output(device, k).cpu().numpy() for k in ('idx1', 'logit', 'F0', 'F1')}
+    T = np.concatenate([r[0] for w in workers for r in w.results])
+    status = np.concatenate([r[1] for w in workers for r in w.results])
+    stats = np.concatenate([r[2] for w in workers for r in w.results])
+    ids_local = [s for w in workers for ids in w.batch_ids for s in ids]
+    gathered = ddist.gather_results(T, status, stats, dst=0, device=coll_dev)
+    gathered_ids = ddist.gather_results(np.tile(np.eye(4), (len(ids_local), 1, 1)) * np.asarray(ids_local)[:, None, None],
+                                        np.zeros(len(ids_local), np.int32), np.zeros((len(ids_local), 4), np.float32),
+                                        dst=0, device=coll_dev)
 
-    # ---- profiled re-run of the same K steps: HIP events around every sparse-conv launch --------
-    ops.set_profiling(device, True)
-    prof = {}
-    for _ in range(args.steps):
-        step(forced)
-        st = ops.stage_times(device)
-        for k, v in st.items():
-            prof[k] = prof.get(k, 0.0) + v
-    launch_ms, gemm_ms = ops.conv_launch_times(device)   # last profiled step: FCGF layers, then the inlier net's
-    ops.set_profiling(device, False)
-    prof = {k: v / args.steps for k, v in prof.items()}
+    # ---- profiled re-run of stream 0's first batch: HIP events around every sparse-conv launch ----
+    bt = w0.batches[0]
+    with torch.cuda.stream(w0.stream):
+        ops.set_profiling(device, True)
+        prof = {}
+        n_prof = min(args.steps, 10)
+        for _ in range(n_prof):
+            w0.run_batch(bt)
+            st = ops.stage_times(device)
+            for k, v in st.items():
+                prof[k] = prof.get(k, 0.0) + v
+        launch_ms, gemm_ms = ops.conv_launch_times(device)   # last profiled call: FCGF layers, then the inlier net's
+        kinds = ops.conv_launch_kinds(device)
+        ops.set_profiling(device, False)
+    prof = {k: v / n_prof for k, v in prof.items()}
     log(f'profiled region done: {prof}')
 
     if rank == 0:
-        # algorithmic work of the conv kernel per step, from the kernel maps of this very input
-        fc = dgr.fcgf_model._handle()
-        ones0 = torch.ones(len(C0), 1, device=device)
-        fc.forward(C0, ones0); s_a = fc.layer_stats()
-        fc.forward(C1, torch.ones(len(C1), 1, device=device)); s_b = fc.layer_stats()
-        coords6, feats6 = ops.inlier_inputs(C0, X0, C1, X1, torch.from_numpy(idx1).to(device),
-                                            dgr.inlier_feature_type)
-        inl = dgr.inlier_model._handle()
-        inl.forward(coords6, feats6); s_c = inl.layer_stats()
-        work = [conv_work(s) for s in (s_a, s_b, s_c)]
-        flop = sum(w[0] for w in work); byts = sum(w[1] for w in work)
-        flop64 = sum(w[2] for w in work); byts64 = sum(w[3] for w in work)
+        dgr = w0.dgr
+        off0, off1, C0, X0, C1, X1, idx1 = bt['off0'], bt['off1'], bt['C0'], bt['X0'], bt['C1'], bt['X1'], bt['idx1']
+        nb = len(bt['ids'])
+        # algorithmic work of the conv kernels per batch, from the kernel maps of this very input
+        with torch.cuda.stream(w0.stream):
+            fc = dgr.fcgf_model._handle()
+            C01 = torch.cat([C0 * torch.tensor([2, 1, 1, 1], device=device, dtype=torch.int32),
+                             C1 * torch.tensor([2, 1, 1, 1], device=device, dtype=torch.int32)
+                             + torch.tensor([1, 0, 0, 0], device=device, dtype=torch.int32)])
+            fc.forward(C01, torch.ones(len(C01), 1, device=device)); s_a = fc.layer_stats()
+            coords6, feats6 = ops.inlier_inputs(C0, X0, C1, X1, torch.from_numpy(idx1).to(device), dgr.inlier_feature_type)
+            inl = dgr.inlier_model._handle()
+            inl.forward(coords6, feats6); s_c = inl.layer_stats()
+        per_layer = list(s_a) + list(s_c)
+        flop = sum(layer_flop(s) for s in per_layer)
+        byts = sum(layer_bytes(s) for s in per_layer)
         n_launch = max(1, int(prof['conv_launches']))
-        # the layers SURVEY.md 8d calls HBM-bound (C <= 64): compulsory bytes and gather-scatter traffic
-        # (4 P (Cin + 2 Cout) + 8 P + 4 Kne Cin Cout) over their measured launch durations
-        c64 = dominant = None
-        if len(launch_ms) == len(s_a) + len(s_c):
-            per_layer = [dict(a, pairs=a['pairs'] + b['pairs'], n_in=a['n_in'] + b['n_in'], n_out=a['n_out'] + b['n_out'],
-                              nonempty=max(a['nonempty'], b['nonempty'])) for a, b in zip(s_a, s_b)] + list(s_c)
-            ms64 = comp64 = gath64 = 0.0
-            for st, ms in zip(per_layer, launch_ms):
-                if max(st['cin'], st['cout']) <= 64:
-                    ms64 += ms
-                    comp64 += 4.0 * (st['n_in'] * st['cin'] + st['n_out'] * st['cout'] + st['nonempty'] * st['cin'] * st['cout']) + 8.0 * st['pairs']
-                    gath64 += 4.0 * st['pairs'] * (st['cin'] + 2 * st['cout']) + 8.0 * st['pairs'] + 4.0 * st['nonempty'] * st['cin'] * st['cout']
-            # the dominant kernel instance: sparse_conv_mfma_v2<256, 1, 4, 2, 2, true> = every 256 -> 256 layer
-            # (block4 of both nets); its average launch duration is what `rocprofv3 --kernel-trace --stats` of
-            # the single-stream command reports for that kernel name (profiles/)
-            dom = [(2.0 * st['pairs'] * st['cin'] * st['cout'], g) for st, g in zip(per_layer, gemm_ms)
-                   if st['cin'] == 256 and st['cout'] == 256]
-            if dom:
-                dominant = {'name': 'sparse_conv_mfma_v2<256, 1, 4, 2, 2, true>', 'launches_per_step': len(dom),
-                            'avg_launch_us': 1e3 * sum(g for _, g in dom) / len(dom),
-                            'gflop_per_step': sum(f for f, _ in dom) / 1e9,
-                            'achieved_tflops': sum(f for f, _ in dom) / (sum(g for _, g in dom) * 1e-3) / 1e12,
-                            'share_of_conv_flop': sum(f for f, _ in dom) / flop,
-                            'algorithmic_bytes_per_launch': sum(
-                                4.0 * (st['n_in'] * st['cin'] + st['n_out'] * st['cout'] + st['nonempty'] * st['cin'] * st['cout'])
-                                + 8.0 * st['pairs'] for st in per_layer if st['cin'] == 256 and st['cout'] == 256) / len(dom)}
-            if ms64 > 0:
-                c64 = {'layers': sum(1 for st in per_layer if max(st['cin'], st['cout']) <= 64), 'ms_per_step': ms64,
-                       'compulsory_gbps': comp64 / ms64 / 1e6, 'gather_scatter_gbps': gath64 / ms64 / 1e6,
-                       'frac_of_hbm_peak_gather_scatter': gath64 / ms64 / 1e6 / PEAK_HBM_GBPS}
+        groups, c64, dominant = {}, None, None
+        if len(launch_ms) == len(per_layer) == len(kinds):
+            # per kernel variant (name reported by the library): launches, time, algorithmic work
+            for st, ms, gms, kind in zip(per_layer, launch_ms, gemm_ms, kinds):
+                g = groups.setdefault(kind, {'launches': 0, 'ms': 0.0, 'main_kernel_ms': 0.0, 'gflop': 0.0, 'gbytes': 0.0,
+                                             'roofline_ms': 0.0})
+                g['launches'] += 1; g['ms'] += ms; g['main_kernel_ms'] += gms
+                g['gflop'] += layer_flop(st) / 1e9; g['gbytes'] += layer_bytes(st) / 1e9
+                g['roofline_ms'] += roofline_time_s(st) * 1e3
+            for g in groups.values():
+                g['tflops'] = g['gflop'] / max(g['ms'], 1e-9)
+                g['frac_of_roofline'] = g['roofline_ms'] / max(g['ms'], 1e-9)
+            # the layers SURVEY.md 8d calls HBM-bound (C <= 64): COMPULSORY bytes over their measured durations
+            sel = [(st, ms) for st, ms in zip(per_layer, launch_ms) if max(st['cin'], st['cout']) <= 64]
+            if sel:
+                ms64 = sum(ms for _, ms in sel)
+                comp64 = sum(layer_bytes(st) for st, _ in sel)
+                c64 = {'layers': len(sel), 'ms_per_batch': ms64, 'gflop': sum(layer_flop(st) for st, _ in sel) / 1e9,
+                       'compulsory_gbytes': comp64 / 1e9, 'compulsory_gbps': comp64 / ms64 / 1e6,
+                       'frac_of_hbm_peak_compulsory': comp64 / ms64 / 1e6 / PEAK_HBM_GBPS,
+                       'roofline_ms': sum(roofline_time_s(st) for st, _ in sel) * 1e3,
+                       'frac_of_roofline': sum(roofline_time_s(st) for st, _ in sel) * 1e3 / ms64}
+            # the dominant kernel = the variant with the largest share of the conv time
+            dk = max(groups, key=lambda k: groups[k]['main_kernel_ms'])
+            sel = [(st, gms) for st, gms, kind in zip(per_layer, gemm_ms, kinds) if kind == dk]
+            f = sum(layer_flop(st) for st, _ in sel)
+            tms = sum(g for _, g in sel)
+            dominant = {'name': dk, 'launches_per_batch': len(sel), 'avg_launch_us': 1e3 * tms / len(sel),
+                        'gflop_per_launch': f / 1e9 / len(sel), 'achieved_tflops': f / (tms * 1e-3) / 1e12,
+                        'share_of_conv_flop': f / flop, 'share_of_conv_time': tms / max(1e-9, sum(gemm_ms)),
+                        'algorithmic_bytes_per_launch': sum(layer_bytes(st) for st, _ in sel) / len(sel)}
         conv_ms = prof['conv_kernels']
         achieved = flop / (conv_ms * 1e-3) / 1e12
         T_all, status_all, stats_all = gathered
+        ids_all = [int(round(v)) for v in gathered_ids[0][:, 0, 0]]
         te, re = [], []
-        for p in range(S * B):
+        for p, seed in enumerate(ids_all):
             if status_all[p] == 0:
-                Tg = all_pairs[p][2]
+                Tg = vox_cache[seed][2] if seed in vox_cache else synth.synth_pair(seed, n_raw=args.n_raw, kind=args.kind)[2]
                 te.append(float(np.linalg.norm(T_all[p][:3, 3] - Tg[:3, 3])))
                 c = (np.trace(T_all[p][:3, :3].T @ Tg[:3, :3]) - 1) / 2
                 re.append(float(np.degrees(np.arccos(np.clip(c, -1, 1)))))
-        # HBM traffic of the conv kernels from PMC counters (FETCH_SIZE x 2 + WRITE_SIZE, see
-        # profiles/r01_conv_hbm_traffic.json): collected in separate rocprofv3 --pmc passes on the same
-        # per-stream workload (4 pairs per batch); not measurable from inside this process
-        # (a) the dominant kernel instance (roofline headline) and (b) all conv launches of the batch
-        traffic = traffic_all = None
-        tpath = os.path.join(ROOT, 'profiles', 'r01_conv_hbm_traffic.json')
-        if os.path.exists(tpath) and B == 4 and args.n_raw == 50000 and args.conv1_ks == 7:
-            tj = json.load(open(tpath))
-            traffic_all = tj['per_conv_launch_bytes']['total']
-            for kname, kv in tj['kernels'].items():
-                if dominant and dominant['name'] in kname and kv['dispatches']:
-                    traffic = (2.0 * kv['FETCH_SIZE_KB'] + kv['WRITE_SIZE_KB']) * 1024.0 / kv['dispatches']
+        # HBM traffic / MFMA-busy of the dominant kernel from PMC counters: separate rocprofv3 --pmc passes on
+        # the same per-stream workload (tools/evidence.sh), committed under profiles/ -- not measurable from inside
+        # this process, hence the field name
+        pmc = None
+        ppath = os.path.join(ROOT, 'profiles', 'r02_dominant_pmc.json')
+        if os.path.exists(ppath):
+            pj = json.load(open(ppath))
+            if dominant and pj.get('kernel') and pj['kernel'] in dominant['name'] and pj.get('workload') == cfg_label(args):
+                pmc = pj
+        peak = PEAK_FP32_MFMA_TFLOPS
+        pairs_per_step = (args.total_pairs or world * n_local)
         ms_per_step = elapsed / args.steps * 1e3
         out = {
             'metric': 'pair registrations/sec (FCGF x2 + 1-NN + 6-D inlier net + gate + weighted Procrustes + SE(3) refinement)',
-            'value': world * S * B * args.steps / elapsed, 'unit': 'pairs/s', 'n_gpus': world,
+            'value': pairs_per_step * args.steps / elapsed, 'unit': 'pairs/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'higher_is_better': True, 'scaling': 'strong' if args.total_pairs else 'weak', 'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic 3DMatch-shaped pairs, seeded synthetic weights, teacher-forced matches (20% GT) and inlier logits'
                     + ('; PCIe-inclusive: raw host points -> H2D -> voxelisation inside the timed region' if args.from_host else ''),
-            'config': {'workload': f'{S * B} pairs/step/GPU ({S} stream(s) x {B}), {args.n_raw} raw pts/fragment, '
-                                   f'{args.kind}, voxel {args.voxel}, conv1 k={args.conv1_ks} ({cfg_label(args)})',
-                       'streams_per_gpu': S,
-                       'voxels_per_pair': [int(off0[-1] / B), int(off1[-1] / B)],
-                       'pairs_per_step_per_gpu': S * B, 'refinement': not args.no_refine,
+            'config': {'workload': f'{pairs_per_step} pairs/step ({world} GPU(s) x {len(workers)} stream(s) x batches of {B}), '
+                                   f'{args.n_raw} raw pts/fragment, {args.kind}, voxel {args.voxel}, conv1 k={args.conv1_ks} '
+                                   f'({cfg_label(args)})',
+                       'streams_per_gpu': len(workers),
+                       'voxels_per_pair': [int(off0[-1] / nb), int(off1[-1] / nb)],
+                       'pairs_per_step': pairs_per_step, 'refinement': not args.no_refine,
                        'parallelism': f'pair-sharded x{world}, no data-path collective'},
-            # roofline of the DOMINANT kernel (76 % of the conv FLOPs): algorithmic FLOP per launch / its average
-            # launch duration (HIP events on the launch stream); `all_conv_layers` is the same over all 46 launches
+            # roofline of the DOMINANT conv kernel variant: algorithmic FLOP per launch / its average launch
+            # duration (HIP events on the launch stream); `all_conv_layers` is the same over every layer launch
             'roofline': {'bound': 'mfma', 'achieved': dominant['achieved_tflops'] if dominant else achieved,
-                         'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': (dominant['achieved_tflops'] if dominant else achieved) / PEAK_FP32_MFMA_TFLOPS,
-                         'traffic': traffic,
-                         'traffic_unit': 'HBM bytes per launch of the kernel (PMC: 2 x FETCH_SIZE + WRITE_SIZE)',
-                         'kernel': dominant['name'] if dominant else 'sparse_conv_mfma (all instances)',
-                         'launches_per_step': dominant['launches_per_step'] if dominant else n_launch,
+                         'peak': peak, 'unit': 'TFLOP/s',
+                         'frac': (dominant['achieved_tflops'] if dominant else achieved) / peak,
+                         'traffic': None,
+                         'traffic_from_profiles': pmc.get('hbm_bytes_per_launch') if pmc else None,
+                         'mfma_busy_from_profiles': pmc.get('mfma_busy') if pmc else None,
+                         'pmc_source': 'profiles/r02_dominant_pmc.json (separate rocprofv3 --pmc passes, 2 x FETCH_SIZE + WRITE_SIZE)' if pmc else None,
+                         'kernel': dominant['name'] if dominant else 'sparse conv (all variants)',
+                         'launches_per_batch': dominant['launches_per_batch'] if dominant else n_launch,
                          'avg_launch_us': dominant['avg_launch_us'] if dominant else conv_ms * 1e3 / n_launch,
-                         'gflop_per_launch': (dominant['gflop_per_step'] / dominant['launches_per_step']) if dominant else flop / 1e9 / n_launch,
+                         'gflop_per_launch': dominant['gflop_per_launch'] if dominant else flop / 1e9 / n_launch,
                          'share_of_conv_flop': dominant['share_of_conv_flop'] if dominant else 1.0,
+                         'share_of_conv_time': dominant['share_of_conv_time'] if dominant else 1.0,
                          'algorithmic_bytes_per_launch': dominant['algorithmic_bytes_per_launch'] if dominant else byts / n_launch,
-                         'all_conv_layers': {'achieved': achieved, 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
-                                             'kernel': 'sparse_conv_mfma_v2<*> + reduce_rows (every layer launch)',
-                                             'launches_per_step': n_launch, 'avg_launch_us': conv_ms * 1e3 / n_launch,
-                                             'gflop_per_step': flop / 1e9, 'compulsory_gbytes_per_step': byts / 1e9,
-                                             'traffic': traffic_all, 'algorithmic_bytes_per_launch': byts / n_launch,
-                                             'hbm_gbps_compulsory': byts / (conv_ms * 1e-3) / 1e9},
-                         'c_le_64_layers': dict({'gflop': flop64 / 1e9, 'gbytes': byts64 / 1e9}, **(c64 or {}))},
-            'stage_ms_per_step': {k: round(v, 3) for k, v in prof.items() if k != 'conv_launches'},
+                         'all_conv_layers': {'achieved': achieved, 'frac': achieved / peak,
+                                             'launches_per_batch': n_launch, 'avg_launch_us': conv_ms * 1e3 / n_launch,
+                                             'gflop_per_batch': flop / 1e9, 'compulsory_gbytes_per_batch': byts / 1e9,
+                                             'hbm_gbps_compulsory': byts / (conv_ms * 1e-3) / 1e9,
+                                             'roofline_ms': sum(roofline_time_s(s) for s in per_layer) * 1e3,
+                                             'frac_of_roofline': sum(roofline_time_s(s) for s in per_layer) * 1e3 / conv_ms},
+                         'c_le_64_layers': c64,
+                         'by_kernel': {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in g.items()}
+                                       for k, g in groups.items()}},
+            'stage_ms_per_batch': {k: round(v, 3) for k, v in prof.items() if k != 'conv_launches'},
             'te_m_mean': float(np.mean(te)) if te else None, 're_deg_mean': float(np.mean(re)) if re else None,
-            'status': [int(s) for s in status_all.tolist()],
-            'iterations': [int(v) for v in stats_all[:, 0].tolist()],
-            'voxelize_ms_per_pair': t_vox * 1e3,
+            'status_counts': {str(k): int((status_all == k).sum()) for k in np.unique(status_all)},
+            'iterations_mean': float(stats_all[:, 0].mean()),
             'layers_6d': [[x['pairs'], x['nonempty'], x['n_in'], x['n_out'], x['cin'], x['cout']] for x in s_c],
-            'layers_3d_cloud0': [[x['pairs'], x['nonempty'], x['n_in'], x['n_out'], x['cin'], x['cout']] for x in s_a],
+            'layers_3d_batch': [[x['pairs'], x['nonempty'], x['n_in'], x['n_out'], x['cin'], x['cout']] for x in s_a],
         }
         log('roofline accounting done')
-        if not args.no_cpu_baseline and world == 1:   # reported on rank 0 at N = 1 only
-            out['cpu_baseline'] = cpu_baseline(ck, args.n_raw, args.voxel, args.kind, (int(off0[-1] / B), int(off1[-1] / B)))
-        else:
-            out['cpu_baseline'] = None
+        out['parity'] = out['cpu_baseline'] = None
+        if not args.no_parity and world == 1:
+            lb = last_bt
+            s0, e0, s1, e1 = lb['off0'][0], lb['off0'][1], lb['off1'][0], lb['off1'][1]
+            c0 = lb['C0'][s0:e0].cpu().numpy().copy(); c0[:, 0] = 0
+            c1 = lb['C1'][s1:e1].cpu().numpy().copy(); c1[:, 0] = 0
+            pair0 = {'xyz0': lb['X0'][s0:e0].cpu().numpy(), 'coords0': c0, 'xyz1': lb['X1'][s1:e1].cpu().numpy(), 'coords1': c1,
+                     'idx1': hip_out['idx1'][s0:e0] - s1, 'F0': hip_out['F0'].reshape(-1, 32)[s0:e0],
+                     'F1': hip_out['F1'].reshape(-1, 32)[s1:e1], 'logit': hip_out['logit'][s0:e0],
+                     'forced': lb['forced'].cpu().numpy()[s0:e0]}
+            out['parity'], out['cpu_baseline'] = oracle_parity_and_baseline(ck, args, pair0, not args.no_cpu_baseline)
+            log(f'parity: {out["parity"]}')
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

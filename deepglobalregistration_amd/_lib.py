@@ -72,6 +72,7 @@ SIGNATURES = {
     'dgr_ctx_stage_times': (C.c_int, [vp, c_f32p]),
     'dgr_ctx_conv_launches': (C.c_int64, [vp]),
     'dgr_ctx_conv_launch_times': (C.c_int, [vp, c_f32p, c_f32p, C.c_int64, C.POINTER(C.c_int64)]),
+    'dgr_ctx_conv_launch_kinds': (C.c_int, [vp, C.c_char_p, C.c_int64, C.POINTER(C.c_int64)]),
 }
 
 _lib = None

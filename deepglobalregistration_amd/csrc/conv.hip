@@ -51,186 +51,6 @@ __device__ __forceinline__ f32x4 dgr_y_load(const float *p) {
   if (STREAM) return __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
   return *reinterpret_cast<const f32x4 *>(p);
 }
-template <int WM, int WN, int MB, int NB>
-__global__ void __launch_bounds__(64 * WM * WN) sparse_conv_mfma(ConvKArgs a) {
-  constexpr int THREADS = 64 * WM * WN;
-  constexpr int TM = 32 * MB * WM;
-  static_assert(TM == DGR_TILE_M, "tile height must match the kernel-map tiling");
-  constexpr int NBLK = NB * WN;  // 32-column blocks of the padded output
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int CP = a.cin_pad;
-  const int LDA = CP + 4;  // +4 floats: keeps 16-B alignment, spreads rows over LDS banks
-  float *As = lds;
-  int *idx_in = reinterpret_cast<int *>(lds + TM * LDA);
-  int *idx_out = idx_in + TM;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-  const int S = CP >> 3;
-  const bool identity = (a.pair_in == nullptr);
-
-  int T;  // total tiles
-  if (identity)
-    T = (*a.n_rows_dev + TM - 1) / TM;
-  else
-    T = a.tile_ptr[a.K];
-  // XCD-aware persistent schedule: block b runs on XCD (b % 8); give each XCD a contiguous range
-  const int per = (T + 7) >> 3;
-  const int xcd = blockIdx.x & 7;
-  const int t_end = min(T, (xcd + 1) * per);
-  const int nj = gridDim.x >> 3;
-
-  for (int t = xcd * per + (blockIdx.x >> 3); t < t_end; t += nj) {
-    // ---- locate the rule and the pair range of this tile
-    int k = 0, pstart, count;
-    if (identity) {
-      pstart = t * TM;
-      count = min(TM, *a.n_rows_dev - pstart);
-    } else {
-      int lo = 0, hi = a.K;  // largest k with tile_ptr[k] <= t
-      while (hi - lo > 1) {
-        int mid = (lo + hi) >> 1;
-        if (a.tile_ptr[mid] <= t) lo = mid; else hi = mid;
-      }
-      k = lo;
-      pstart = a.rule_ptr[k] + (t - a.tile_ptr[k]) * TM;
-      count = min(TM, a.rule_ptr[k + 1] - pstart);
-    }
-    if (tid < TM) {
-      int r = tid;
-      int vi = -1, vo = -1;
-      if (r < count) {
-        vi = identity ? pstart + r : a.pair_in[pstart + r];
-      }
-      idx_in[r] = vi;
-      idx_out[r] = vo;
-    }
-    __syncthreads();
-    // ---- gather the input rows into LDS (coalesced 16-B pieces along each row)
-    if (((a.cin | a.in_ld) & 3) == 0) {
-      const int c4n = CP >> 2;
-      for (int ch = tid; ch < TM * c4n; ch += THREADS) {
-        const int r = ch / c4n, c4 = ch - r * c4n;
-        const int row = idx_in[r];
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (row >= 0 && c4 * 4 < a.cin) {
-          v = *reinterpret_cast<const f32x4 *>(a.in + (int64_t)row * a.in_ld + c4 * 4);
-          if (a.in_relu) {
-            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-          }
-        }
-        *reinterpret_cast<f32x4 *>(As + r * LDA + c4 * 4) = v;
-      }
-    } else {
-      for (int e = tid; e < TM * CP; e += THREADS) {
-        const int r = e / CP, c = e - r * CP;
-        const int row = idx_in[r];
-        float v = 0.f;
-        if (row >= 0 && c < a.cin) {
-          v = a.in[(int64_t)row * a.in_ld + c];
-          if (a.in_relu) v = fmaxf(v, 0.f);
-        }
-        As[r * LDA + c] = v;
-      }
-    }
-    __syncthreads();
-    // ---- MFMA main loop over Cin in steps of 8
-    f32x16 acc[MB][NB];
-#pragma unroll
-    for (int i = 0; i < MB; ++i)
-#pragma unroll
-      for (int j = 0; j < NB; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    const f32x4 *wk = reinterpret_cast<const f32x4 *>(a.w) + ((int64_t)k * S * NBLK + wn * NB) * 64 + lane;
-    const float *arow = As + (32 * wm * MB + (lane & 31)) * LDA + 4 * (lane >> 5);
-    f32x4 bcur[NB], bnext[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) bcur[j] = wk[j * 64];
-    for (int s = 0; s < S; ++s) {
-      if (s + 1 < S) {
-#pragma unroll
-        for (int j = 0; j < NB; ++j) bnext[j] = wk[((int64_t)(s + 1) * NBLK + j) * 64];
-      }
-      f32x4 av[MB];
-#pragma unroll
-      for (int i = 0; i < MB; ++i) av[i] = *reinterpret_cast<const f32x4 *>(arow + i * 32 * LDA + s * 8);
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int i = 0; i < MB; ++i)
-#pragma unroll
-          for (int j = 0; j < NB; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][c], bcur[j][c], acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int j = 0; j < NB; ++j) bcur[j] = bnext[j];
-    }
-    // ---- write the product rows: C layout col = lane & 31, row = (e&3) + 8 (e>>2) + 4 (lane>>5)
-#pragma unroll
-    for (int i = 0; i < MB; ++i) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int r = 32 * (wm * MB + i) + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-        if (r < count) {
-          if (identity) {
-            float *dst = a.out + (int64_t)(pstart + r) * a.out_ld;
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-              const int col = 32 * (wn * NB + j) + (lane & 31);
-              if (col < a.cout) dst[col] = acc[i][j][e] + (a.shift ? a.shift[col] : 0.f);
-            }
-          } else {
-            float *dst = a.y + (int64_t)(pstart + r) * a.y_ld;
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-              const int col = 32 * (wn * NB + j) + (lane & 31);
-              if (col < a.cout) dst[col] = acc[i][j][e];
-            }
-          }
-        }
-      }
-    }
-    __syncthreads();
-  }
-}
-
-template <int WM, int WN, int MB, int NB>
-static int launch_cfg(const ConvKArgs &ka, int64_t tile_bound, int num_cus, hipStream_t stream) {
-  constexpr int THREADS = 64 * WM * WN;
-  const size_t lds_bytes = (size_t)DGR_TILE_M * (ka.cin_pad + 4) * sizeof(float) + 2 * DGR_TILE_M * sizeof(int);
-  static size_t configured = 0;
-  if (lds_bytes > configured) {
-    DGR_HIP_CHECK(hipFuncSetAttribute((const void *)sparse_conv_mfma<WM, WN, MB, NB>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    configured = 160 * 1024;
-  }
-  // persistent grid: exactly as many blocks as can be co-resident (more would queue behind the
-  // resident ones and unbalance the tile ranges)
-  static std::map<size_t, int> occ_cache;
-  int per_cu;
-  auto it = occ_cache.find(lds_bytes);
-  if (it != occ_cache.end()) {
-    per_cu = it->second;
-  } else {
-    int n = 0;
-    DGR_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sparse_conv_mfma<WM, WN, MB, NB>, THREADS,
-                                                               lds_bytes));
-    per_cu = n < 1 ? 1 : n;
-    if (per_cu > 2048 / THREADS) per_cu = 2048 / THREADS;
-    occ_cache[lds_bytes] = per_cu;
-  }
-  int64_t grid = (int64_t)num_cus * per_cu;
-  if (tile_bound < grid) grid = tile_bound;
-  grid = (grid + 7) / 8 * 8;
-  if (grid < 8) grid = 8;
-  sparse_conv_mfma<WM, WN, MB, NB><<<(int)grid, THREADS, lds_bytes, stream>>>(ka);
-  DGR_LAUNCH_CHECK();
-  return DGR_OK;
-}
-
 // ------------------------------------------------------------------------------------------
 // v2: compile-time Cin, software-pipelined in PHASES of <= 128 input channels.
 //   * LDS holds two A buffers [64 rows x CK channels]; phase q multiplies out of buffer q&1 while
@@ -517,7 +337,7 @@ static int launch_v2(const ConvKArgs &ka, int64_t tile_bound, int num_cus, hipSt
   return DGR_OK;
 }
 
-int dgr_conv_launch(const DgrConvLaunch &a, int num_cus, hipStream_t stream) {
+int dgr_conv_launch(const DgrConvLaunch &a, int num_cus, hipStream_t stream, const char **kernel_name) {
   ConvKArgs ka;
   ka.in = a.in; ka.out = a.out; ka.w = a.w; ka.y = a.y; ka.shift = a.shift; ka.y_ld = a.cout;
   ka.pair_in = a.pair_in; ka.pair_out = a.pair_out; ka.tile_ptr = a.tile_ptr; ka.rule_ptr = a.rule_ptr;
@@ -528,32 +348,25 @@ int dgr_conv_launch(const DgrConvLaunch &a, int num_cus, hipStream_t stream) {
   const int64_t tile_bound = a.tile_bound > 0 ? a.tile_bound : (int64_t)num_cus * 4;
   // specialised (compile-time Cin, pipelined) instantiations for every layer shape of ResUNetBN2C
   const bool vec = ((a.cin | a.in_ld) & 3) == 0;
-  static const bool use_v2 = getenv("DGR_CONV_V1") == nullptr;
-#define DGR_V2(CPV, WMV, WNV, MBV, NBV)                                                             \
-  if (a.cin_pad == CPV) {                                                                            \
-    return vec ? launch_v2<CPV, WMV, WNV, MBV, NBV, true>(ka, tile_bound, num_cus, stream)          \
-               : launch_v2<CPV, WMV, WNV, MBV, NBV, false>(ka, tile_bound, num_cus, stream);        \
+#define DGR_V2(CPV, WMV, WNV, MBV, NBV)                                                                        \
+  if (a.cin_pad == CPV) {                                                                                       \
+    if (kernel_name)                                                                                            \
+      *kernel_name = vec ? "sparse_conv_mfma_v2<" #CPV ", " #WMV ", " #WNV ", " #MBV ", " #NBV ", true>"        \
+                         : "sparse_conv_mfma_v2<" #CPV ", " #WMV ", " #WNV ", " #MBV ", " #NBV ", false>";      \
+    return vec ? launch_v2<CPV, WMV, WNV, MBV, NBV, true>(ka, tile_bound, num_cus, stream)                     \
+               : launch_v2<CPV, WMV, WNV, MBV, NBV, false>(ka, tile_bound, num_cus, stream);                   \
   }
-  if (use_v2) {
-    switch (a.cout_pad) {
-      case 32: DGR_V2(8, 2, 1, 1, 1) DGR_V2(32, 2, 1, 1, 1) DGR_V2(64, 2, 1, 1, 1) break;
-      case 64: DGR_V2(32, 2, 2, 1, 1) DGR_V2(64, 2, 2, 1, 1) DGR_V2(96, 2, 2, 1, 1) DGR_V2(128, 2, 2, 1, 1)
-               DGR_V2(256, 2, 2, 1, 1) break;
-      case 128: DGR_V2(64, 1, 4, 2, 1) DGR_V2(128, 1, 4, 2, 1) DGR_V2(256, 1, 4, 2, 1) break;
-      case 256: DGR_V2(128, 1, 4, 2, 2) DGR_V2(256, 1, 4, 2, 2) break;
-      default: break;
-    }
+  switch (a.cout_pad) {
+    case 32: DGR_V2(8, 2, 1, 1, 1) DGR_V2(32, 2, 1, 1, 1) DGR_V2(64, 2, 1, 1, 1) break;
+    case 64: DGR_V2(32, 2, 2, 1, 1) DGR_V2(64, 2, 2, 1, 1) DGR_V2(96, 2, 2, 1, 1) DGR_V2(128, 2, 2, 1, 1)
+             DGR_V2(256, 2, 2, 1, 1) break;
+    case 128: DGR_V2(64, 1, 4, 2, 1) DGR_V2(128, 1, 4, 2, 1) DGR_V2(256, 1, 4, 2, 1) break;
+    case 256: DGR_V2(128, 1, 4, 2, 2) DGR_V2(256, 1, 4, 2, 2) break;
+    default: break;
   }
 #undef DGR_V2
-  switch (a.cout_pad) {
-    case 32: return launch_cfg<2, 1, 1, 1>(ka, tile_bound, num_cus, stream);
-    case 64: return launch_cfg<2, 2, 1, 1>(ka, tile_bound, num_cus, stream);
-    case 128: return launch_cfg<1, 4, 2, 1>(ka, tile_bound, num_cus, stream);
-    case 256: return launch_cfg<1, 4, 2, 2>(ka, tile_bound, num_cus, stream);
-    default:
-      dgr_set_error("unsupported padded output width %d", a.cout_pad);
-      return DGR_EINVAL;
-  }
+  dgr_set_error("sparse conv: no kernel instantiation for Cin (padded) %d -> Cout (padded) %d", a.cin_pad, a.cout_pad);
+  return DGR_EINVAL;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -716,25 +529,16 @@ int dgr_conv_small_cin(const float *in, int in_ld, int in_relu, int cin, const f
 // replayed in ascending-k order (ballot + readlane) with lane = output channel accumulating
 // x[hit] * W[k][ci][co] -- the same k-ordered sum as the map-based path, bit for bit.
 // ------------------------------------------------------------------------------------------
-template <bool W_IN_LDS>
 __global__ void __launch_bounds__(256)
     conv1_probe_kernel(const int32_t *__restrict__ coords, const int32_t *n_dev, const int32_t *__restrict__ table,
                        uint32_t mask, int ks, const float *__restrict__ in, int in_ld, int cin,
                        const float *__restrict__ w, const float *__restrict__ shift, float *__restrict__ out,
                        int out_ld, int32_t *pair_count, const int32_t *skip_flag) {
-  extern __shared__ __attribute__((aligned(16))) float wl[];   // [K][cin][32] compact copy of the weights
   if (skip_flag && *skip_flag) return;   // the dense-grid kernel did the layer
   const int n = *n_dev;
   const int lane = threadIdx.x & 63;
   const int co = lane & 31;
   const int K = ks * ks * ks, half = ks >> 1;
-  if (W_IN_LDS) {
-    for (int e = threadIdx.x; e < K * cin * 32; e += blockDim.x) {
-      const int c = e & 31, ci = (e >> 5) % cin, k = e / (32 * cin);
-      wl[e] = w[(int64_t)k * 256 + (32 * (ci >> 2) + c) * 4 + (ci & 3)];
-    }
-    __syncthreads();
-  }
   const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   int pairs = 0;
@@ -769,8 +573,7 @@ __global__ void __launch_bounds__(256)
         for (int ci = 0; ci < 8; ++ci) {
           if (ci < cin) {
             const float xs = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xv[ci]), src));
-            const float wv = W_IN_LDS ? wl[((k0 + src) * cin + ci) * 32 + co]
-                                      : w[(int64_t)(k0 + src) * 256 + (32 * (ci >> 2) + co) * 4 + (ci & 3)];
+            const float wv = w[(int64_t)(k0 + src) * 256 + (32 * (ci >> 2) + co) * 4 + (ci & 3)];
             t = fmaf(xs, wv, t);   // same k-ordered fma chain as the MFMA path
           }
         }
@@ -1026,18 +829,11 @@ int dgr_conv1_probe(DgrArena &arena, const DgrCoordMap &cm, int ks, const float 
     grid_done = &meta->ok;
     arena.rewind(mk);   // stream order keeps the grid alive until the kernels above are done
   }
-  const size_t wbytes = (size_t)ks * ks * ks * cin * 32 * sizeof(float);
-  static const bool lds_w = getenv("DGR_CONV1_LDS") != nullptr;  // measured slower than L1-cached global reads
-  if (lds_w && wbytes <= 64 * 1024) {
-    int64_t blocks = 768;      // 3 per CU (44 KB of LDS each): copy the weights once, then walk many voxels
-    conv1_probe_kernel<true><<<(int)blocks, 256, wbytes, stream>>>(cm.coords, cm.n_dev, cm.table, cm.table_mask, ks, in,
-                                                                   in_ld, cin, w_tiled, shift, out, out_ld, pair_count,
-                                                                   grid_done);
-  } else {
+  {
     int64_t blocks = dgr_ceil_div(cm.n_cap, 4);
     if (blocks > 16384) blocks = 16384;
-    conv1_probe_kernel<false><<<(int)blocks, 256, 0, stream>>>(cm.coords, cm.n_dev, cm.table, cm.table_mask, ks, in, in_ld,
-                                                               cin, w_tiled, shift, out, out_ld, pair_count, grid_done);
+    conv1_probe_kernel<<<(int)blocks, 256, 0, stream>>>(cm.coords, cm.n_dev, cm.table, cm.table_mask, ks, in, in_ld, cin,
+                                                        w_tiled, shift, out, out_ld, pair_count, grid_done);
   }
   DGR_LAUNCH_CHECK();
   return DGR_OK;

@@ -161,3 +161,18 @@ extern "C" int dgr_ctx_conv_launch_times(dgr_ctx *ctx, float *times_ms, float *g
   *n = m;
   return DGR_OK;
 }
+
+extern "C" int dgr_ctx_conv_launch_kinds(dgr_ctx *ctx, char *buf, int64_t capacity, int64_t *n) {
+  DGR_REQUIRE(ctx != nullptr && buf != nullptr && n != nullptr && capacity > 0, "bad argument");
+  std::string all;
+  int64_t m = 0;
+  for (const char *k : ctx->conv_kinds) {
+    if ((int64_t)(all.size() + strlen(k) + 2) > capacity) break;
+    all += k;
+    all += '\n';
+    ++m;
+  }
+  memcpy(buf, all.c_str(), all.size() + 1);
+  *n = m;
+  return DGR_OK;
+}

@@ -160,7 +160,7 @@ struct DgrConvLaunch {
   const int32_t *n_rows_dev;                                 // identity map: number of rows
   int64_t tile_bound;                                        // host upper bound on the tile count (0 = unknown)
 };
-int dgr_conv_launch(const DgrConvLaunch &a, int num_cus, hipStream_t stream);
+int dgr_conv_launch(const DgrConvLaunch &a, int num_cus, hipStream_t stream, const char **kernel_name = nullptr);
 // out[o,:] = shift (+res[o,:]) + sum_{j in [ptr[o], ptr[o+1])} y[pos[j],:]   (ascending-k order)
 int dgr_reduce_rows(const float *y, int cout, const int32_t *ptr, const int32_t *pos, const int32_t *n_dev,
                     int64_t n_cap, float *out, int out_ld, const float *shift, const float *res, int res_ld,
@@ -199,6 +199,7 @@ struct dgr_ctx {
   // event spans recorded while profiling; resolved by dgr_ctx_collect_profile after a sync
   std::vector<std::pair<hipEvent_t, hipEvent_t>> conv_spans, gemm_spans, map3_spans, map6_spans;
   std::vector<float> conv_span_ms, gemm_span_ms;  // per-launch durations of the last collected profile
+  std::vector<const char *> conv_kinds;            // kernel variant of every span (static strings)
   int32_t *flag_dev = nullptr;  // error flag word of the current top-level call (arena)
 };
 

@@ -235,11 +235,12 @@ struct Fwd {
       DGR_HIP_CHECK(hipEventRecord(e0, stream));
     }
     const bool small_cin = km && !swapped && !res && L.cin <= 8 && L.cout == 32 && L.cin_pad == 8;
+    const char *kname = "conv_small_cin_kernel";
     if (small_cin)
       DGR_CHECK(dgr_conv_small_cin(in.ptr, in.ld, in.relu, L.cin, L.w, L.shift, *km, cout_map.n_dev, cout_map.n_cap,
                                    out.ptr, out.ld, stream));
     else
-      DGR_CHECK(dgr_conv_launch(a, ctx->num_cus, stream));
+      DGR_CHECK(dgr_conv_launch(a, ctx->num_cus, stream, &kname));
     if (prof) DGR_HIP_CHECK(hipEventRecord(em, stream));   // end of the MFMA phase
     if (km && !small_cin)
       DGR_CHECK(dgr_reduce_rows(ybuf, L.cout, swapped ? km->in_ptr : km->out_ptr, swapped ? km->in_pos : km->out_pos,
@@ -249,6 +250,7 @@ struct Fwd {
       DGR_HIP_CHECK(hipEventRecord(e1, stream));
       ctx->conv_spans.push_back({e0, e1});
       ctx->gemm_spans.push_back({e0, em});
+      ctx->conv_kinds.push_back(kname);
     }
     LayerRun &r = net->runs[li];
     r.launch = a;
@@ -337,6 +339,7 @@ int dgr_resunet_forward_impl(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, 
       DGR_HIP_CHECK(hipEventRecord(e1, stream));
       ctx->conv_spans.push_back({e0, e1});
       ctx->gemm_spans.push_back({e0, e1});
+      ctx->conv_kinds.push_back("conv1_grid_kernel");
     }
     LayerRun &r0 = net->runs[0];
     r0 = LayerRun();
@@ -393,6 +396,7 @@ void dgr_ctx_begin_profile(dgr_ctx *ctx) {
   ctx->events.used = 0;
   ctx->conv_spans.clear();
   ctx->gemm_spans.clear();
+  ctx->conv_kinds.clear();
   ctx->map3_spans.clear();
   ctx->map6_spans.clear();
   ctx->conv_launches = 0;

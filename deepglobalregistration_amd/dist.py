@@ -97,3 +97,32 @@ def gather_results(T, status, stats, dst=0, device=None):
         return None
     rows = torch.cat([b[:int(c)] for b, c in zip(bufs, counts.tolist())]).cpu().numpy()
     return rows[:, :16].reshape(-1, 4, 4), rows[:, 16].astype(np.int32), rows[:, 17:].astype(np.float32)
+
+
+def deal_by_cost(costs, world_size):
+    """Static load balancing of independent units: sort the units by decreasing cost and deal them
+    round-robin in snake order (rank 0..W-1, then W-1..0, ...), so that every rank gets the same
+    number of units (+-1) and nearly the same total cost.  `costs[i]` is the cost proxy of unit i
+    (N0 * N1 of a pair: the brute-force 1-NN and the 6-D maps scale with it).  Returns a list of
+    `world_size` lists of unit indices, each in decreasing-cost order; identical on every rank."""
+    costs = np.asarray(costs, np.float64).reshape(-1)
+    order = np.lexsort((np.arange(len(costs)), -costs))       # ties: smaller index first (deterministic)
+    shares = [[] for _ in range(world_size)]
+    for j, u in enumerate(order.tolist()):
+        r = j % (2 * world_size)
+        shares[r if r < world_size else 2 * world_size - 1 - r].append(u)
+    return shares
+
+
+def all_gather_vector(values, total, lo, device=None):
+    """Every rank contributes `values` for the contiguous unit block starting at `lo`; returns the
+    full [total] float64 vector on every rank (one small all-reduce of a zero-padded vector)."""
+    full = np.zeros(total, np.float64)
+    full[lo:lo + len(values)] = np.asarray(values, np.float64)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return full
+    if device is None:
+        device = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else torch.device('cpu')
+    t = torch.from_numpy(full).to(device)
+    dist.all_reduce(t)
+    return t.cpu().numpy()

@@ -393,3 +393,13 @@ def conv_launch_times(device):
     n = C.c_int64(0)
     check(_lib.load().dgr_ctx_conv_launch_times(get_ctx(device), t, g, cap, C.byref(n)))
     return [float(t[i]) for i in range(n.value)], [float(g[i]) for i in range(n.value)]
+
+
+def conv_launch_kinds(device):
+    """Kernel variant (rocprof kernel name) of every launch reported by `conv_launch_times`."""
+    cap = 1 << 16
+    buf = C.create_string_buffer(cap)
+    n = C.c_int64(0)
+    check(_lib.load().dgr_ctx_conv_launch_kinds(get_ctx(device), buf, cap, C.byref(n)))
+    names = buf.value.decode().split('\n')
+    return names[:n.value]

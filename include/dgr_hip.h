@@ -225,6 +225,9 @@ int64_t dgr_ctx_conv_launches(dgr_ctx *ctx);
  * 0..22, then the inlier net's): times_ms = MFMA phase + reduce phase, gemm_ms (nullable) = MFMA phase alone
  * (the sparse_conv_mfma kernel); *n = number written (<= capacity) */
 int dgr_ctx_conv_launch_times(dgr_ctx *ctx, float *times_ms, float *gemm_ms, int64_t capacity, int64_t *n);
+/* kernel variant that ran each of those launches (the kernel's name as rocprofv3 --kernel-trace prints it),
+ * newline-separated and NUL-terminated in buf; *n = number of names written */
+int dgr_ctx_conv_launch_kinds(dgr_ctx *ctx, char *buf, int64_t capacity, int64_t *n);
 
 #ifdef __cplusplus
 }
