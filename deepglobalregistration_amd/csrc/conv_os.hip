@@ -1,0 +1,325 @@
+// Output-stationary fused sparse convolution for the 3-D (FCGF) net on gfx950.
+// Replaces, for D = 3, the ME.MinkowskiConvolution / MinkowskiConvolutionTranspose forward of every
+// K = 27 conv of ResUNetBN2C (model/resunet.py:598-649, model/residual_block.py:15-80) -- same
+// arithmetic as the rule-major path in conv.hip (per pair an exact-f32 MFMA product row, summed per
+// output row in ascending offset order on top of the folded batch-norm shift and the residual), but
+// with NO product rows in HBM and NO reduction pass:
+//
+//   * a workgroup owns DGR_OS_ROWS = 64 consecutive output rows and a slice of CS output channels; the
+//     rows' accumulators [64 x CS] live in LDS for the whole layer and are written once at the end;
+//   * the only kernel-map structure is the dense neighbour table nbr[27][n_pad] (kmap.hip): per offset k
+//     the 64 entries of the block are ballot-compacted into a list of (input row, local output row);
+//   * per offset one tile: the <= 64 gathered input rows go through a double-buffered LDS tile
+//     (requested one phase ahead, landed one phase later: one barrier per phase) and are multiplied
+//     with W[k] by v_mfma_f32_16x16x4_f32 (exact f32).  A wave owns 16 output channels and walks the
+//     tile's 16-row groups, so a tile costs ceil(count / 16) row groups instead of a full 64-row MFMA
+//     tile -- the map's fill (47 % of a 64-row block per offset on 3DMatch-shaped clouds) does not turn
+//     into idle matrix cycles; operands are swapped (D = W^T In^T) so that a lane ends up with one pair
+//     and 4 consecutive channels and the accumulation into the LDS row is one 16-byte read-modify-write;
+//   * channel ranges are exclusive per wave, so the LDS accumulation needs no atomics and no extra
+//     barrier, and the sum order is ascending k: results do not depend on scheduling (bit-reproducible).
+//
+// Weight layout (net.hip, per layer): W16[k][g][jb][lane][c] = W_folded[k][16 g + 4 (lane >> 4) + c][16 jb + (lane & 15)]
+// (g = Cin_pad/16 groups, jb = Cout/16 channel blocks): one coalesced 16-byte load per lane = the A
+// operands of 4 consecutive MFMAs.
+#include <type_traits>
+
+#include "dgr_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvOsArgs {
+  const float *in;
+  float *out;
+  const float *w16, *shift, *res;
+  const int32_t *nbr, *n_out_dev;
+  int64_t n_pad;
+  int in_ld, in_relu, out_ld, out_relu, res_ld, res_relu;
+  int cin, cout, nb16;   // nb16 = cout / 16
+};
+
+// CP = input channels (multiple of 32), CS = output-channel slice of a workgroup (32 | 64), MB = output rows
+// per workgroup (16 | 32 | 64), CK = input channels per pipeline phase (32 | 64), TM = pair slots per tile (32 | 64)
+template <int CP, int CS, int MB, int CK, int TM>
+__global__ void __launch_bounds__(CS * 4) sparse_conv_os(ConvOsArgs a) {
+  constexpr int NW = CS / 16;            // waves: one 16-channel block each
+  constexpr int THREADS = 64 * NW;
+  constexpr int GP = TM / 16;            // 16-row groups per tile
+  constexpr int KV = 27;
+  constexpr int PPT = CP / CK;           // phases per tile
+  constexpr int LDA = CK + 4, LDC = CS + 4;
+  constexpr int C4K = CK / 4;
+  constexpr int NCH = TM * C4K / THREADS;   // 16-byte gather pieces per thread per phase
+  constexpr int G = CK / 16;                // MFMA groups (4 MFMAs, 16 input channels) per phase
+  constexpr int GT = CP / 16;               // groups per tile
+  constexpr int KPW = (KV + NW - 1) / NW;   // offsets compacted per wave
+  constexpr int NGMAX = KV * (MB / 16);
+  static_assert(TM * C4K % THREADS == 0 && CP % CK == 0, "shape");
+  __shared__ __attribute__((aligned(16))) float As[2][TM][LDA];
+  __shared__ __attribute__((aligned(16))) float acc_s[MB][LDC];
+  __shared__ int in_idx[KV][MB];
+  __shared__ unsigned char out_loc[KV][MB];
+  __shared__ int cnt[KV];
+  __shared__ int grp[NGMAX + GP];   // k | first list entry << 8 | entries << 16, ascending k
+  __shared__ int n_grp;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n_out = *a.n_out_dev;
+  const int nblocks = (n_out + MB - 1) / MB;
+  // XCD-aware block order: workgroup b runs on XCD b % 8; give every XCD a contiguous range of row blocks
+  const int per = (nblocks + 7) >> 3;
+  const int j = blockIdx.x >> 3;
+  const int blk = (blockIdx.x & 7) * per + j;
+  if (j >= per || blk >= nblocks) return;
+  const int slice = blockIdx.y;
+  const int64_t row0 = (int64_t)blk * MB;
+
+  // ---- 1. per offset: compact the block's neighbour-table column into (input row, local output row)
+  {
+    int v[KPW];
+#pragma unroll
+    for (int u = 0; u < KPW; ++u) {
+      const int k = wave + u * NW;
+      v[u] = (k < KV && lane < MB) ? a.nbr[(int64_t)k * a.n_pad + row0 + lane] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < KPW; ++u) {
+      const int k = wave + u * NW;
+      if (k < KV) {
+        const unsigned long long m = __ballot(v[u] >= 0);
+        if (v[u] >= 0) {
+          const int pos = __popcll(m & ((1ull << lane) - 1ull));
+          in_idx[k][pos] = v[u];
+          out_loc[k][pos] = (unsigned char)lane;
+        }
+        if (lane == 0) cnt[k] = __popcll(m);
+      }
+    }
+  }
+  // ---- 2. accumulators start from the folded batch-norm shift (+ residual)
+  for (int e = tid; e < MB * (CS / 4); e += THREADS) {
+    const int r = e / (CS / 4), c = (e % (CS / 4)) * 4;
+    f32x4 v = a.shift ? *reinterpret_cast<const f32x4 *>(a.shift + slice * CS + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.res && row0 + r < n_out) {
+      f32x4 x = *reinterpret_cast<const f32x4 *>(a.res + (row0 + r) * a.res_ld + slice * CS + c);
+      if (a.res_relu) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
+      v += x;
+    }
+    *reinterpret_cast<f32x4 *>(&acc_s[r][c]) = v;
+  }
+  __syncthreads();
+  // ---- 3. 16-row groups in ascending offset order: an offset with c pairs yields ceil(c / 16) groups; four
+  //         groups (of possibly different offsets) make one 64-slot tile
+  if (wave == 0) {
+    const int c = lane < KV ? cnt[lane] : 0;
+    const int ng = (c + 15) >> 4;
+    int x = ng;
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+      const int y = __shfl_up(x, d, 64);
+      if (lane >= d) x += y;
+    }
+    const int first = x - ng;
+    for (int u = 0; u < ng; ++u) grp[first + u] = lane | ((16 * u) << 8) | (min(16, c - 16 * u) << 16);
+    if (lane == KV - 1) {
+      n_grp = x;
+      for (int u = 0; u < GP; ++u) grp[x + u] = 0;   // padding groups: offset 0, no entries
+    }
+  }
+  __syncthreads();
+  const int NG = n_grp;
+  const int NT = (NG + GP - 1) / GP;
+  const int NQ = NT * PPT;
+
+  f32x4 Gr[NCH];
+  // Requests only -- nothing here consumes a loaded value (see conv.hip).  A slot beyond its group's entries
+  // reads row 0: its product is never accumulated (MFMA rows are independent), so nothing is zeroed.
+  auto gather = [&](int q) {
+    const int t = q / PPT, cbase = (q % PPT) * CK;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int ch = tid + i * THREADS;
+      const int r = ch / C4K, c = cbase + (ch % C4K) * 4;
+      const int info = grp[GP * t + (r >> 4)];
+      const int row = in_idx[info & 255][((info >> 8) & 255) + (r & 15)];
+      const uint32_t off = (uint32_t)(((r & 15) < (info >> 16)) ? row : 0) * (uint32_t)a.in_ld + (uint32_t)c;
+#ifdef DGR_OS_ABL_NOGATHER   // timing ablations (outputs are garbage): tools/ab_fcgf.py with DGR_HIP_LIB
+      Gr[i] = f32x4{(float)off, 0.f, 0.f, 0.f};
+#else
+      Gr[i] = *reinterpret_cast<const f32x4 *>(a.in + off);
+#endif
+    }
+  };
+  // pending ReLU of the producer as ONE integer max per value (negative floats are negative integers; no
+  // canonicalising second instruction as with fmaxf on freshly loaded data)
+  const int relu_lo = a.in_relu ? 0 : (int)0x80000000;
+  auto land = [&](int q) {
+    float *dst = &As[q & 1][0][0];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int ch = tid + i * THREADS;
+      i32x4 v = __builtin_bit_cast(i32x4, Gr[i]);
+      v.x = max(v.x, relu_lo); v.y = max(v.y, relu_lo); v.z = max(v.z, relu_lo); v.w = max(v.w, relu_lo);
+      *reinterpret_cast<i32x4 *>(dst + (ch / C4K) * LDA + (ch % C4K) * 4) = v;
+    }
+  };
+  // A operands (weights) of step s = GP q + rb (group rb of phase q): G coalesced 16-byte loads per lane,
+  // straight from L2 (a layer's 27 slices are at most 7 MB and shared by every workgroup)
+  const int jb = slice * NW + wave;
+  const f32x4 *wbase = reinterpret_cast<const f32x4 *>(a.w16) + (int64_t)jb * 64 + lane;
+  auto wstep = [&](int s, f32x4 *w) {
+    const int q = min(s / GP, NQ - 1);
+    const int k = __builtin_amdgcn_readfirstlane(grp[GP * (q / PPT) + (s % GP)]) & 255;
+    const f32x4 *p = wbase + (int64_t)(k * GT + (q % PPT) * G) * a.nb16 * 64;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+#ifdef DGR_OS_ABL_NOW
+      w[g] = f32x4{(float)k, 1.f, 2.f, 3.f};
+#else
+      w[g] = p[(int64_t)g * a.nb16 * 64];
+#endif
+    }
+  };
+
+  f32x4 acc[GP];
+  f32x4 w[GP][G];   // weights of the tile's four groups; each set is re-requested for the NEXT phase right after its use
+  // one 16-row group: 4 G MFMAs on its accumulator
+  auto mfma_group = [&](int rb, const float *arow) {
+#ifndef DGR_OS_ABL_NOMFMA
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const f32x4 av = *reinterpret_cast<const f32x4 *>(arow + rb * 16 * LDA + g * 16);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[rb][g][c], av[c], acc[rb], 0, 0, 0);
+    }
+#else
+    acc[rb] += *reinterpret_cast<const f32x4 *>(arow + rb * 16 * LDA) + w[rb][0];
+#endif
+  };
+  if (NQ > 0) {
+    gather(0);
+#pragma unroll
+    for (int rb = 0; rb < GP; ++rb) wstep(rb, w[rb]);
+    land(0);
+    gather(NQ > 1 ? 1 : 0);
+  }
+  __syncthreads();
+
+  for (int q = 0; q < NQ; ++q) {
+    const int t = q / PPT, h = q % PPT;
+    // unconditional (clamped) requests keep the loop body free of branches around the memory operations: the
+    // last iterations re-request the last phase and land it in the buffer nobody reads any more
+    land(q + 1);                         // requested one phase ago
+    gather(min(q + 2, NQ - 1));          // a whole phase to arrive
+    if (PPT == 1 || h == 0) {
+#pragma unroll
+      for (int rb = 0; rb < GP; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int live = min(GP, NG - GP * t);   // groups of this tile (wave-uniform)
+    const float *arow = &As[q & 1][lane & 15][4 * (lane >> 4)];
+    // a group's weights were requested a whole phase ago (right after their previous use): the other groups'
+    // MFMAs, the barrier and the next landing cover the L2 latency
+#pragma unroll
+    for (int rb = 0; rb < GP; ++rb) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (rb == 0 || live > rb) mfma_group(rb, arow);
+      wstep(GP * (q + 1) + rb, w[rb]);
+    }
+    if (PPT == 1 || h == PPT - 1) {
+      // tile done: lane = pair (lane & 15) of group rb, channels 16 wave + 4 (lane >> 4) .. +3 of the slice
+#pragma unroll
+      for (int rb = 0; rb < GP; ++rb) {
+        const int info = grp[GP * t + rb];
+#ifdef DGR_OS_ABL_NORMW
+        if ((lane & 15) < (info >> 16) && acc[rb].x == 123.456f) {
+#else
+        if ((lane & 15) < (info >> 16)) {
+#endif
+          float *p = &acc_s[out_loc[info & 255][((info >> 8) & 255) + (lane & 15)]][16 * wave + 4 * (lane >> 4)];
+          f32x4 v = *reinterpret_cast<f32x4 *>(p);
+          v += acc[rb];
+          *reinterpret_cast<f32x4 *>(p) = v;
+        }
+      }
+    }
+    __syncthreads();   // tile buffer q & 1 is free again; buffer (q + 1) & 1 is complete
+  }
+  // ---- 5. write the block's rows once (ReLU applied here when the tensor carries one: consumers that
+  //         re-apply it see an idempotent max)
+  const float out_lo = a.out_relu ? 0.f : -__builtin_inff();
+  for (int e = tid; e < MB * (CS / 4); e += THREADS) {
+    const int r = e / (CS / 4), c = (e % (CS / 4)) * 4;
+    if (row0 + r < n_out) {
+      f32x4 v = *reinterpret_cast<const f32x4 *>(&acc_s[r][c]);
+      v.x = fmaxf(v.x, out_lo); v.y = fmaxf(v.y, out_lo); v.z = fmaxf(v.z, out_lo); v.w = fmaxf(v.w, out_lo);
+      *reinterpret_cast<f32x4 *>(a.out + (row0 + r) * a.out_ld + slice * CS + c) = v;
+    }
+  }
+}
+
+template <int CP, int CS, int MB, int CK, int TM>
+static int launch_os(const ConvOsArgs &ka, int64_t n_out_cap, hipStream_t stream) {
+  int64_t blocks = dgr_ceil_div(n_out_cap, MB);
+  blocks = (blocks + 7) / 8 * 8;
+  dim3 grid((unsigned)blocks, (unsigned)(ka.cout / CS));
+  sparse_conv_os<CP, CS, MB, CK, TM><<<grid, CS * 4, 0, stream>>>(ka);
+  DGR_LAUNCH_CHECK();
+  return DGR_OK;
+}
+
+int dgr_conv_os_launch(const DgrConvOsLaunch &a, hipStream_t stream, const char **kernel_name) {
+  DGR_REQUIRE(a.nbr && a.nbr->built && a.nbr->K == 27, "output-stationary conv: no neighbour table");
+  DGR_REQUIRE((a.cin & 3) == 0 && (a.in_ld & 3) == 0 && (a.out_ld & 3) == 0 && (a.res == nullptr || (a.res_ld & 3) == 0),
+              "output-stationary conv: channel counts and row strides must be multiples of 4");
+  DGR_REQUIRE(a.cout % 32 == 0 && a.cin == a.cin_pad, "output-stationary conv: Cin = %d, Cout = %d must be multiples of 32",
+              a.cin, a.cout);
+  DGR_REQUIRE(a.n_out_cap * (int64_t)a.in_ld < (1ll << 32) / 4 * 4, "output-stationary conv: input tensor beyond 32-bit element offsets");
+  ConvOsArgs ka;
+  ka.in = a.in; ka.out = a.out; ka.w16 = a.w16; ka.shift = a.shift; ka.res = a.res;
+  ka.nbr = a.nbr->nbr; ka.n_out_dev = a.n_out_dev; ka.n_pad = a.nbr->n_pad;
+  ka.in_ld = a.in_ld; ka.in_relu = a.in_relu; ka.out_ld = a.out_ld; ka.out_relu = a.out_relu;
+  ka.res_ld = a.res_ld; ka.res_relu = a.res_relu;
+  ka.cin = a.cin; ka.cout = a.cout; ka.nb16 = a.cout / 16;
+#ifndef DGR_OS_TM
+#define DGR_OS_TM 64
+#endif
+#ifndef DGR_OS_MBBIG
+#define DGR_OS_MBBIG 64
+#endif
+#define DGR_STR2(x) #x
+#define DGR_STR(x) DGR_STR2(x)
+#define DGR_OS(CPV, CSV, MBV, CKV)                                                                      \
+  do {                                                                                                  \
+    constexpr int tm = (MBV) < DGR_OS_TM ? ((MBV) < 32 ? 32 : (MBV)) : DGR_OS_TM;                       \
+    if (kernel_name) *kernel_name = "sparse_conv_os<" #CPV ", " #CSV ", " DGR_STR(MBV) ", " DGR_STR(CKV) ">"; \
+    return launch_os<CPV, CSV, MBV, CKV, tm>(ka, a.n_out_cap, stream);                                  \
+  } while (0)
+  // rows per workgroup by level: the coarse levels have few rows (1/3, 1/12, 1/60 of the input on
+  // 3DMatch-shaped clouds) and need smaller blocks to fill 256 CUs
+  const int mb = a.rows_per_block;
+  const bool narrow = a.cout == 32;   // one 32-channel slice; wider layers: 64-channel slices over grid.y
+#define DGR_OS_MB(CPV, CKV)                                                 \
+  do {                                                                      \
+    if (narrow) { DGR_OS(CPV, 32, DGR_OS_MBBIG, CKV); }                     \
+    else if (mb == 64) { DGR_OS(CPV, 64, DGR_OS_MBBIG, CKV); }              \
+    else if (mb == 32) { DGR_OS(CPV, 64, 32, CKV); }                        \
+    else { DGR_OS(CPV, 64, 16, CKV); }                                      \
+  } while (0)
+#ifndef DGR_OS_CK
+#define DGR_OS_CK 64
+#endif
+  switch (a.cin_pad) {
+    case 32: DGR_OS_MB(32, 32);
+    case 64: DGR_OS_MB(64, DGR_OS_CK);
+    case 128: DGR_OS_MB(128, DGR_OS_CK);
+    case 256: DGR_OS_MB(256, DGR_OS_CK);
+    default: break;
+  }
+#undef DGR_OS_MB
+#undef DGR_OS
+  dgr_set_error("output-stationary conv: no instantiation for Cin (padded) %d", a.cin_pad);
+  return DGR_EINVAL;
+}

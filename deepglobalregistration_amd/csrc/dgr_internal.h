@@ -118,8 +118,23 @@ struct DgrKernelMap {
   bool built = false;
 };
 
+// D = 3: dense neighbour table of one (input map, output map, 3^3 offsets) triple -- the only kernel-map
+// structure the output-stationary conv (conv_os.hip) needs: nbr[k * n_pad + o] = input row of output
+// row o under offset k, or -1.  n_pad = output-row capacity rounded up to DGR_OS_ROWS.
+constexpr int DGR_OS_ROWS = 64;   // output rows per workgroup of the output-stationary conv
+struct DgrNbrTable {
+  int32_t *nbr = nullptr;
+  int64_t n_pad = 0;
+  int K = 27;
+  bool built = false;
+};
+
 struct DgrMapSet {
   int D = 3, nc = 4, conv1_ks = 3;
+  bool use_nbr = false;      // D = 3 network forward: neighbour tables instead of rule-major maps
+  DgrNbrTable nsame[4];      // 3^3 at ts 1,2,4,8
+  DgrNbrTable ndown[3];      // ts -> 2 ts        (out rows = coarse map)
+  DgrNbrTable nup[3];        // 2 ts -> ts, transposed convs (out rows = fine map)
   DgrCoordMap cm[4];     // ts = 1,2,4,8
   DgrHalfBuckets hb[4];  // D = 6: half-key buckets of cm[l] (built for l < 3)
   DgrKernelMap same[4];  // 3^D at ts 1,2,4,8
@@ -130,7 +145,10 @@ struct DgrMapSet {
 
 // Builds all coordinate maps and kernel maps of one sparse tensor into `arena`.
 int dgr_build_maps(DgrArena &arena, const int32_t *coords, int64_t N, int D, int conv1_ks,
-                   DgrMapSet *ms, hipStream_t stream, bool skip_conv1_map = false, bool lean = false);
+                   DgrMapSet *ms, hipStream_t stream, bool skip_conv1_map = false, bool lean = false,
+                   bool nbr_tables = false);
+// per-offset pair counts of a neighbour table (statistics / tests; synchronises)
+int dgr_nbr_counts(const DgrNbrTable &t, const int32_t *n_out_dev, int64_t counts[27]);
 // conv1 fused with its neighbour search (D = 3, Cin <= 8, Cout = 32): no kernel map for the ks^3 offsets
 int dgr_conv1_probe(DgrArena &arena, const DgrCoordMap &cm, int ks, const float *in, int in_ld, int cin,
                     const float *w_tiled, const float *shift, float *out, int out_ld, int32_t *pair_count,
@@ -169,6 +187,20 @@ int dgr_reduce_rows(const float *y, int cout, const int32_t *ptr, const int32_t 
 int dgr_conv_small_cin(const float *in, int in_ld, int in_relu, int cin, const float *w_tiled, const float *shift,
                        const DgrKernelMap &km, const int32_t *n_out_dev, int64_t n_out_cap, float *out, int out_ld,
                        hipStream_t stream);
+// output-stationary fused conv (conv_os.hip): out[o] = shift (+ res[o]) + sum_k in[nbr[k][o]] W[k], ascending k,
+// accumulated in LDS -- no product rows, no reduction pass.  w16 = the layer's weights in 16x16x4 fragment order.
+struct DgrConvOsLaunch {
+  const float *in; int in_ld, in_relu;
+  float *out; int out_ld, out_relu;
+  const float *w16, *shift;
+  const float *res; int res_ld, res_relu;
+  int rows_per_block;   // 64 | 32 | 16 output rows per workgroup
+  const DgrNbrTable *nbr;
+  const int32_t *n_out_dev;
+  int64_t n_out_cap;
+  int cin, cin_pad, cout;
+};
+int dgr_conv_os_launch(const DgrConvOsLaunch &a, hipStream_t stream, const char **kernel_name = nullptr);
 int dgr_l2_normalize_rows(const float *in, int in_ld, float *out, int out_ld, int c, int relu,
                           const int32_t *n_dev, int64_t n_cap, hipStream_t stream);
 

@@ -499,12 +499,84 @@ static int build_kernel_map_t(DgrArena &arena, const DgrCoordMap &in, const DgrC
   return DGR_OK;
 }
 
+// =========================== D = 3: dense neighbour tables =====================================
+// One launch per (input map, output map) pair: a thread owns an output row and one z-slab of the 3^3
+// offsets (9 probes issued together).  SIGN = +1: q = o + delta_k * ts (same-stride and strided convs,
+// out = the output map's rows); SIGN = -1: q = f - delta_k * ts (transposed convs: fine output row f,
+// coarse input c with f = c + delta_k * ts_fine).  Rows beyond the device-side count get -1.
+template <int SIGN>
+__global__ void __launch_bounds__(KM_THREADS)
+    nbr_search3(const int32_t *__restrict__ out_coords, const int32_t *n_out_dev,
+                const int32_t *__restrict__ in_coords, const int32_t *__restrict__ in_table, uint32_t in_mask,
+                int ts, int64_t n_pad, int32_t *__restrict__ nbr) {
+  const int64_t o = (int64_t)blockIdx.x * KM_THREADS + threadIdx.x;
+  if (o >= n_pad) return;
+  const int kz = blockIdx.y;
+  if (o >= *n_out_dev) {
+#pragma unroll
+    for (int u = 0; u < 9; ++u) nbr[(int64_t)(9 * kz + u) * n_pad + o] = -1;
+    return;
+  }
+  const int4 c = *reinterpret_cast<const int4 *>(out_coords + o * 4);
+  int32_t q[9][4];
+#pragma unroll
+  for (int u = 0; u < 9; ++u) {   // offset index k = x + 3 y + 9 z (first spatial dimension fastest: offset_of)
+    q[u][0] = c.x;
+    q[u][1] = c.y + SIGN * ((u % 3) - 1) * ts;
+    q[u][2] = c.z + SIGN * ((u / 3) - 1) * ts;
+    q[u][3] = c.w + SIGN * (kz - 1) * ts;
+  }
+  int hit[9];
+  dgr_lookup_many<4, 9>(in_table, in_mask, in_coords, q, hit);
+#pragma unroll
+  for (int u = 0; u < 9; ++u) nbr[(int64_t)(9 * kz + u) * n_pad + o] = hit[u];
+}
+
+static int build_nbr_table(DgrArena &arena, const DgrCoordMap &in, const DgrCoordMap &out, int ts, int sign,
+                           DgrNbrTable *t, hipStream_t stream) {
+  t->K = 27;
+  t->n_pad = dgr_ceil_div(out.n_cap, DGR_OS_ROWS) * DGR_OS_ROWS;
+  DGR_ALLOC(t->nbr, arena, int32_t, t->n_pad * 27);
+  dim3 grid((unsigned)dgr_ceil_div(t->n_pad, KM_THREADS), 3);
+  if (sign > 0)
+    nbr_search3<1><<<grid, KM_THREADS, 0, stream>>>(out.coords, out.n_dev, in.coords, in.table, in.table_mask, ts, t->n_pad, t->nbr);
+  else
+    nbr_search3<-1><<<grid, KM_THREADS, 0, stream>>>(out.coords, out.n_dev, in.coords, in.table, in.table_mask, ts, t->n_pad, t->nbr);
+  DGR_LAUNCH_CHECK();
+  t->built = true;
+  return DGR_OK;
+}
+
+__global__ void nbr_count_kernel(const int32_t *__restrict__ nbr, int64_t n_pad, const int32_t *n_out_dev,
+                                 unsigned long long *__restrict__ counts) {
+  const int k = blockIdx.y;
+  const int n = *n_out_dev;
+  int c = 0;
+  for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < n; o += (int64_t)gridDim.x * blockDim.x)
+    c += nbr[(int64_t)k * n_pad + o] >= 0;
+  for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(&counts[k], (unsigned long long)c);
+}
+
+int dgr_nbr_counts(const DgrNbrTable &t, const int32_t *n_out_dev, int64_t counts[27]) {
+  unsigned long long *dev;
+  DGR_HIP_CHECK(hipMalloc((void **)&dev, 27 * sizeof(unsigned long long)));
+  DGR_HIP_CHECK(hipMemset(dev, 0, 27 * sizeof(unsigned long long)));
+  nbr_count_kernel<<<dim3(64, 27), 256>>>(t.nbr, t.n_pad, n_out_dev, dev);
+  unsigned long long host[27];
+  hipError_t e = hipMemcpy(host, dev, sizeof(host), hipMemcpyDeviceToHost);
+  (void)hipFree(dev);
+  DGR_HIP_CHECK(e);
+  for (int k = 0; k < 27; ++k) counts[k] = (int64_t)host[k];
+  return DGR_OK;
+}
+
 int dgr_build_coord_maps(DgrArena &arena, const int32_t *coords, int64_t N, DgrMapSet *ms,
                          hipStream_t stream);
 int dgr_build_half_buckets(DgrArena &arena, const DgrCoordMap &cm, DgrHalfBuckets *hb, hipStream_t stream);
 
 int dgr_build_maps(DgrArena &arena, const int32_t *coords, int64_t N, int D, int conv1_ks,
-                   DgrMapSet *ms, hipStream_t stream, bool skip_conv1_map, bool lean) {
+                   DgrMapSet *ms, hipStream_t stream, bool skip_conv1_map, bool lean, bool nbr_tables) {
   DGR_REQUIRE(D == 3 || D == 6, "D=%d not supported (the DGR path uses D=3 and D=6)", D);
   DGR_REQUIRE(conv1_ks % 2 == 1 && conv1_ks >= 1, "conv1 kernel size must be odd");
   DGR_REQUIRE(N > 0 && N < (1ll << 30), "N=%lld out of range", (long long)N);
@@ -516,6 +588,22 @@ int dgr_build_maps(DgrArena &arena, const int32_t *coords, int64_t N, int D, int
     DGR_HIP_CHECK(hipMemsetAsync(ms->overflow, 0, sizeof(int32_t), stream));
   }
   DGR_CHECK(dgr_build_coord_maps(arena, coords, N, ms, stream));
+  if (nbr_tables) {
+    // D = 3 network forward: ten dense neighbour tables, one launch each -- no pair lists, no CSR, no scans
+    DGR_REQUIRE(D == 3, "neighbour tables are a D = 3 structure");
+    ms->use_nbr = true;
+    for (int l = 0; l < 4; ++l) DGR_CHECK(build_nbr_table(arena, ms->cm[l], ms->cm[l], ms->cm[l].ts, +1, &ms->nsame[l], stream));
+    for (int l = 0; l < 3; ++l) {
+      DGR_CHECK(build_nbr_table(arena, ms->cm[l], ms->cm[l + 1], ms->cm[l].ts, +1, &ms->ndown[l], stream));
+      DGR_CHECK(build_nbr_table(arena, ms->cm[l + 1], ms->cm[l], ms->cm[l].ts, -1, &ms->nup[l], stream));
+    }
+    if (lean) {   // the network forward needs nothing else (conv1 runs fused with its neighbour search)
+      if (conv1_ks != 3 && !skip_conv1_map)
+        DGR_CHECK(build_kernel_map_t<3>(arena, ms->cm[0], ms->cm[0], nullptr, conv1_ks, 1024, false, false, true, &ms->conv1,
+                                        ms->overflow, stream));
+      return DGR_OK;
+    }
+  }
   // capacity per output row: exact (K) in 3-D; in 6-D 3^6 = 729 offsets but measured mean
   // occupancy is 2..40 neighbours -- reserve 160 per row and raise the overflow flag beyond.
   const int cap_row = (D == 3) ? 1024 : 160;
@@ -568,7 +656,7 @@ extern "C" int dgr_maps_create(dgr_ctx *ctx, const int32_t *coords, int64_t N, i
     if (!m->coords_copy) { rc = DGR_ENOMEM; break; }
     if (hipMemcpyAsync(m->coords_copy, coords, (size_t)N * (D + 1) * sizeof(int32_t),
                        hipMemcpyDeviceToDevice, stream) != hipSuccess) { rc = DGR_EHIP; break; }
-    rc = dgr_build_maps(m->arena, m->coords_copy, N, D, conv1_kernel_size, &m->ms, stream);
+    rc = dgr_build_maps(m->arena, m->coords_copy, N, D, conv1_kernel_size, &m->ms, stream, false, false, D == 3);
     if (rc != DGR_OK) break;
     int32_t flag = 0;
     if (hipMemcpyAsync(&flag, m->ms.overflow, sizeof(int32_t), hipMemcpyDeviceToHost, stream) != hipSuccess ||
@@ -616,6 +704,40 @@ extern "C" int dgr_maps_get_kernel_map(dgr_maps *m, int kind, int ts, int32_t *r
   DGR_REQUIRE(m && K && P, "NULL argument");
   int l = level_of(ts);
   DGR_REQUIRE(l >= 0, "tensor stride %d not in {1,2,4,8}", ts);
+  if (kind >= 3 && kind <= 5) {
+    // D = 3 neighbour tables (kind 3: same stride, 4: ts -> 2 ts, 5: transposed 2 ts -> ts) as (k, in, out)
+    // triplets sorted by (k, out) -- the layout the rule-major getter returns
+    const DgrNbrTable *t = kind == 3 ? &m->ms.nsame[l] : (l < 3 ? (kind == 4 ? &m->ms.ndown[l] : &m->ms.nup[l]) : nullptr);
+    DGR_REQUIRE(t && t->built, "no such neighbour table (kind %d, ts %d)", kind, ts);
+    const DgrCoordMap &om = kind == 4 ? m->ms.cm[l + 1] : m->ms.cm[l];
+    int32_t n_out = 0;
+    DGR_HIP_CHECK(hipMemcpy(&n_out, om.n_dev, sizeof(int32_t), hipMemcpyDeviceToHost));
+    std::vector<int32_t> tab((size_t)t->n_pad * 27);
+    DGR_HIP_CHECK(hipMemcpy(tab.data(), t->nbr, tab.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    *K = 27;
+    int64_t total = 0;
+    for (int k = 0; k < 27; ++k) {
+      if (rule_ptr && k < rule_cap) rule_ptr[k] = (int32_t)total;
+      for (int o = 0; o < n_out; ++o) {
+        const int32_t v = tab[(size_t)k * t->n_pad + o];
+        if (v < 0) continue;
+        if (pair_in && pair_out) {
+          DGR_REQUIRE(total < pair_cap, "pair buffers too small");
+          pair_in[total] = v;
+          pair_out[total] = o;
+        }
+        ++total;
+      }
+    }
+    if (rule_ptr) {
+      DGR_REQUIRE(rule_cap >= 28, "rule_ptr buffer too small");
+      rule_ptr[27] = (int32_t)total;
+    }
+    for (int64_t o = n_out; o < t->n_pad; ++o)
+      for (int k = 0; k < 27; ++k) DGR_REQUIRE(tab[(size_t)k * t->n_pad + o] == -1, "neighbour table padding is not -1");
+    *P = total;
+    return DGR_OK;
+  }
   const DgrKernelMap *km = nullptr;
   if (kind == 0) km = &m->ms.same[l];
   else if (kind == 1) km = &m->ms.conv1;

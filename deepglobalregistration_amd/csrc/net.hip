@@ -10,6 +10,7 @@
 // consumer applies max(x,0) while gathering.  ME.cat is free: producers write into column ranges
 // of a pre-concatenated buffer (row stride = total channels).
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -26,6 +27,7 @@ struct DgrLayer {
   std::string name;
   int K, cin, cout, cin_pad, cout_pad;
   float *w = nullptr;      // device, tiled
+  float *w16 = nullptr;    // device, 16x16x4 fragment order (3-D K = 27 layers: output-stationary conv, conv_os.hip)
   float *shift = nullptr;  // device [cout] or nullptr
 };
 
@@ -36,6 +38,9 @@ struct LayerRun {  // bookkeeping of the last forward, for dgr_net_layer_stats /
   DgrConvLaunch launch;   // the exact launch of phase 1
   bool small_cin = false;  // conv1 ran through the output-stationary kernel instead
   const int32_t *fused_pairs = nullptr;  // conv1 fused with its neighbour search: device pair counter
+  bool os = false;                       // ran through the output-stationary kernel
+  DgrConvOsLaunch os_launch;
+  DgrNbrTable nbr;
   DgrKernelMap km;  // copy (the map set itself lives on the forward's stack)
   bool has_reduce = false;  // phase 2 parameters
   const int32_t *red_ptr = nullptr, *red_pos = nullptr;
@@ -123,6 +128,27 @@ static int make_layer(dgr_net *net, const dgr_weight_desc *descs, int nd, const 
   DGR_HIP_CHECK(hipMalloc((void **)&L.w, tiled.size() * sizeof(float)));
   DGR_HIP_CHECK(hipMemcpy(L.w, tiled.data(), tiled.size() * sizeof(float), hipMemcpyHostToDevice));
   net->param_bytes += tiled.size() * sizeof(float);
+  if (net->D == 3 && K == 27 && L.cin_pad % 16 == 0 && cout % 32 == 0) {
+    // second copy in v_mfma_f32_16x16x4_f32 operand order (conv_os.hip): W16[k][g][jb][lane][c]
+    const int GT = L.cin_pad / 16, NB = cout / 16;
+    std::vector<float> t16((size_t)K * GT * NB * 256);
+    for (int k = 0; k < K; ++k) {
+      const float *src = kd->data + (size_t)k * cin * cout;
+      for (int g = 0; g < GT; ++g)
+        for (int jb = 0; jb < NB; ++jb)
+          for (int lane = 0; lane < 64; ++lane) {
+            float *d = t16.data() + ((((size_t)k * GT + g) * NB + jb) * 64 + lane) * 4;
+            const int col = 16 * jb + (lane & 15);
+            for (int c = 0; c < 4; ++c) {
+              const int row = 16 * g + 4 * (lane >> 4) + c;
+              d[c] = row < cin ? src[(size_t)row * cout + col] * scale[col] : 0.f;
+            }
+          }
+    }
+    DGR_HIP_CHECK(hipMalloc((void **)&L.w16, t16.size() * sizeof(float)));
+    DGR_HIP_CHECK(hipMemcpy(L.w16, t16.data(), t16.size() * sizeof(float), hipMemcpyHostToDevice));
+    net->param_bytes += t16.size() * sizeof(float);
+  }
   if (has_shift) {
     DGR_HIP_CHECK(hipMalloc((void **)&L.shift, cout * sizeof(float)));
     DGR_HIP_CHECK(hipMemcpy(L.shift, shift.data(), cout * sizeof(float), hipMemcpyHostToDevice));
@@ -176,6 +202,7 @@ extern "C" void dgr_net_destroy(dgr_net *net) {
   (void)hipDeviceSynchronize();
   for (auto &l : net->layers) {
     if (l.w) (void)hipFree(l.w);
+    if (l.w16) (void)hipFree(l.w16);
     if (l.shift) (void)hipFree(l.shift);
   }
   delete net;
@@ -213,7 +240,10 @@ struct Fwd {
     a.y = ybuf; a.shift = L.shift;
     a.w = L.w;
     a.cin = L.cin; a.cin_pad = L.cin_pad; a.cout = L.cout; a.cout_pad = L.cout_pad; a.K = L.K;
-    if (km) {
+    if (km && ms.use_nbr) {
+      a.pair_in = a.pair_out = a.tile_ptr = a.rule_ptr = nullptr;   // output-stationary path below
+      a.tile_desc = nullptr; a.n_rows_dev = nullptr; a.tile_bound = 0;
+    } else if (km) {
       a.pair_in = swapped ? km->pair_out : km->pair_in;
       a.pair_out = swapped ? km->pair_in : km->pair_out;
       a.tile_ptr = km->tile_ptr; a.rule_ptr = km->rule_ptr; a.tile_desc = km->tile_desc;
@@ -233,6 +263,40 @@ struct Fwd {
       e0 = ctx->events.next(); em = ctx->events.next(); e1 = ctx->events.next();
       if (!e0 || !em || !e1) return DGR_EHIP;
       DGR_HIP_CHECK(hipEventRecord(e0, stream));
+    }
+    if (km && ms.use_nbr) {
+      // D = 3: output-stationary fused conv over the dense neighbour table of this (in map, out map) pair
+      const DgrNbrTable *t = nullptr;
+      for (int l = 0; l < 4; ++l)
+        if (km == &ms.same[l]) t = &ms.nsame[l];
+      for (int l = 0; l < 3; ++l)
+        if (km == &ms.down[l]) t = swapped ? &ms.nup[l] : &ms.ndown[l];
+      DGR_REQUIRE(t && t->built && L.w16, "layer %s: no neighbour table / 16x16 weights", L.name.c_str());
+      DgrConvOsLaunch o;
+      o.in = in.ptr; o.in_ld = in.ld; o.in_relu = in.relu;
+      o.out = out.ptr; o.out_ld = out.ld; o.out_relu = out.relu;
+      o.rows_per_block = lvl_out <= 1 ? 64 : lvl_out == 2 ? 32 : 16;
+      o.w16 = L.w16; o.shift = L.shift;
+      o.res = res ? res->ptr : nullptr; o.res_ld = res ? res->ld : 0; o.res_relu = res ? res->relu : 0;
+      o.nbr = t; o.n_out_dev = cout_map.n_dev; o.n_out_cap = cout_map.n_cap;
+      o.cin = L.cin; o.cin_pad = L.cin_pad; o.cout = L.cout;
+      const char *kname = "sparse_conv_os";
+      DGR_CHECK(dgr_conv_os_launch(o, stream, &kname));
+      if (prof) {
+        DGR_HIP_CHECK(hipEventRecord(e1, stream));
+        ctx->conv_spans.push_back({e0, e1});
+        ctx->gemm_spans.push_back({e0, e1});
+        ctx->conv_kinds.push_back(kname);
+      }
+      LayerRun &r = net->runs[li];
+      r = LayerRun();
+      r.os = true;
+      r.os_launch = o;
+      r.nbr = *t;
+      r.os_launch.nbr = &r.nbr;
+      r.n_in = cin_map.n_dev; r.n_out = cout_map.n_dev; r.K = L.K;
+      r.n_out_cap = cout_map.n_cap;
+      return DGR_OK;
     }
     const bool small_cin = km && !swapped && !res && L.cin <= 8 && L.cout == 32 && L.cin_pad == 8;
     const char *kname = "conv_small_cin_kernel";
@@ -281,8 +345,13 @@ int dgr_resunet_forward_impl(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, 
   }
   f.ms.overflow = ctx->flag_dev;
   // FCGF conv1 (ks^3 offsets, <= 8 input channels) is fused with its neighbour search: no map for it
-  const bool conv1_fused = net->D == 3 && net->conv1_ks != 3 && net->cin <= 8;
-  DGR_CHECK(dgr_build_maps(A, coords, N, net->D, net->conv1_ks, &f.ms, stream, conv1_fused, /*lean=*/true));
+  // (any odd kernel size <= 7, also 3); such a 3-D net then needs no rule-major map at all: the K = 27 layers
+  // run output-stationary over dense neighbour tables.  DGR_CONV3D_RULEMAJOR=1 keeps the rule-major two-phase
+  // path of conv.hip for A/B measurements.
+  static const bool rule_major_3d = getenv("DGR_CONV3D_RULEMAJOR") != nullptr;
+  const bool use_nbr = net->D == 3 && net->cin <= 8 && net->conv1_ks <= 7 && !rule_major_3d;
+  const bool conv1_fused = net->D == 3 && net->cin <= 8 && net->conv1_ks <= 7 && (net->conv1_ks != 3 || use_nbr);
+  DGR_CHECK(dgr_build_maps(A, coords, N, net->D, net->conv1_ks, &f.ms, stream, conv1_fused, /*lean=*/true, use_nbr));
   if (f.prof) {
     DGR_HIP_CHECK(hipEventRecord(m1, stream));
     (net->D == 3 ? ctx->map3_spans : ctx->map6_spans).push_back({m0, m1});
@@ -290,7 +359,7 @@ int dgr_resunet_forward_impl(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, 
   {
     // Y capacity: the largest (pair capacity x Cout) over the layers of this net
     const DgrMapSet &m = f.ms;
-    int64_t need = m.conv1.pair_cap * 32;
+    int64_t need = m.use_nbr ? 64 : m.conv1.pair_cap * 32;
     const int64_t same_c[4] = {64, 64, 128, 256}, down_c[3] = {64, 128, 256};  // widest Cout per map
     for (int l = 0; l < 4; ++l) need = std::max(need, m.same[l].pair_cap * same_c[l]);
     for (int l = 0; l < 3; ++l) need = std::max(need, m.down[l].pair_cap * down_c[l]);
@@ -510,7 +579,13 @@ extern "C" int dgr_net_layer_stats(dgr_ctx *ctx, dgr_net *net, int layer, int64_
   DGR_HIP_CHECK(hipMemcpy(&n_in, r.n_in, sizeof(int32_t), hipMemcpyDeviceToHost));
   DGR_HIP_CHECK(hipMemcpy(&n_out, r.n_out, sizeof(int32_t), hipMemcpyDeviceToHost));
   int64_t P = n_out, kne = 1;
-  if (r.fused_pairs) {
+  if (r.os) {
+    int64_t counts[27];
+    DGR_CHECK(dgr_nbr_counts(r.nbr, r.n_out, counts));
+    P = 0;
+    kne = 0;
+    for (int k = 0; k < 27; ++k) { P += counts[k]; kne += counts[k] > 0; }
+  } else if (r.fused_pairs) {
     int32_t pc = 0;
     DGR_HIP_CHECK(hipMemcpy(&pc, r.fused_pairs, sizeof(int32_t), hipMemcpyDeviceToHost));
     P = pc;
@@ -542,13 +617,15 @@ extern "C" int dgr_net_rerun_layer(dgr_ctx *ctx, dgr_net *net, int layer, int re
   float tg = 0.f, tr = 0.f;
   for (int i = 0; i < reps + 1; ++i) {  // first iteration = warm-up
     DGR_HIP_CHECK(hipEventRecord(e0, nullptr));
-    if (r.small_cin)
+    if (r.os)
+      DGR_CHECK(dgr_conv_os_launch(r.os_launch, nullptr));
+    else if (r.small_cin)
       DGR_CHECK(dgr_conv_small_cin(r.launch.in, r.launch.in_ld, r.launch.in_relu, L.cin, L.w, L.shift, r.km, r.n_out,
                                    r.n_out_cap, r.launch.out, r.launch.out_ld, nullptr));
     else
       DGR_CHECK(dgr_conv_launch(r.launch, ctx->num_cus, nullptr));
     DGR_HIP_CHECK(hipEventRecord(e1, nullptr));
-    if (r.has_reduce && !r.small_cin)
+    if (r.has_reduce && !r.small_cin && !r.os)
       DGR_CHECK(dgr_reduce_rows(r.launch.y, L.cout, r.red_ptr, r.red_pos, r.n_out, r.n_out_cap, r.launch.out,
                                 r.launch.out_ld, L.shift, r.res, r.res_ld, r.res_relu, nullptr));
     DGR_HIP_CHECK(hipEventRecord(e2, nullptr));

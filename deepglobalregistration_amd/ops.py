@@ -165,9 +165,11 @@ class Maps:
         return out
 
     def kernel_map(self, kind, ts):
-        """kind: 'same' | 'conv1' | 'down'.  Returns (k, in, out) int64 arrays sorted by (k, out)."""
+        """kind: 'same' | 'conv1' | 'down' (rule-major maps) or, D = 3 only, 'nbr_same' | 'nbr_down' | 'nbr_up'
+        (the dense neighbour tables of the output-stationary conv; 'nbr_up' = transposed conv 2 ts -> ts).
+        Returns (k, in, out) int64 arrays sorted by (k, out)."""
         lib = _lib.load()
-        kid = {'same': 0, 'conv1': 1, 'down': 2}[kind]
+        kid = {'same': 0, 'conv1': 1, 'down': 2, 'nbr_same': 3, 'nbr_down': 4, 'nbr_up': 5}[kind]
         K, P = C.c_int64(0), C.c_int64(0)
         check(lib.dgr_maps_get_kernel_map(self.handle, kid, ts, None, 0, None, None, 0, C.byref(K), C.byref(P)))
         rule = np.empty(K.value + 1, np.int32)

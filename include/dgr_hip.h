@@ -110,7 +110,9 @@ int dgr_maps_create(dgr_ctx *ctx, const int32_t *coords, int64_t N, int D, int c
 void dgr_maps_destroy(dgr_maps *maps);
 /* coordinates of the map at tensor stride ts (1,2,4,8): host int32 [n,1+D]; returns n in *n */
 int dgr_maps_get_coords(dgr_maps *maps, int ts, int32_t *host_out, int64_t capacity, int64_t *n);
-/* kernel map: kind 0 = same-stride 3^D at ts, 1 = conv1 (ks^D at ts=1), 2 = strided ts -> 2ts.
+/* kernel map: kind 0 = same-stride 3^D at ts, 1 = conv1 (ks^D at ts=1), 2 = strided ts -> 2ts; D = 3 only:
+ * 3 / 4 / 5 = the dense neighbour tables of the output-stationary conv (same stride / ts -> 2ts / transposed
+ * 2ts -> ts with out = the fine map), returned in the same (k, in, out) form.
  * host outputs: rule_ptr int32 [K+1], pair_in/pair_out int32 [P]; *K, *P returned. */
 int dgr_maps_get_kernel_map(dgr_maps *maps, int kind, int ts, int32_t *rule_ptr, int64_t rule_cap,
                             int32_t *pair_in, int32_t *pair_out, int64_t pair_cap, int64_t *K,

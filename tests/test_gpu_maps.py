@@ -63,6 +63,16 @@ def test_maps_match_oracle(D, ks, n):
     for ts in (1, 2, 4):
         k, i, o = maps.kernel_map('down', ts)
         assert kmap_set(k, i, o) == kmap_set(*me.kernel_map(ocoords[ts], ocoords[2 * ts], D, 3, ts))
+    if D == 3:
+        # the dense neighbour tables of the output-stationary conv hold exactly the same pairs; the transposed
+        # table equals the oracle's transposed_kernel_map, triplet for triplet and in its order
+        for ts in (1, 2, 4, 8):
+            assert kmap_set(*maps.kernel_map('nbr_same', ts)) == kmap_set(*me.kernel_map(ocoords[ts], ocoords[ts], 3, 3, ts))
+        for ts in (1, 2, 4):
+            assert kmap_set(*maps.kernel_map('nbr_down', ts)) == kmap_set(*me.kernel_map(ocoords[ts], ocoords[2 * ts], 3, 3, ts))
+            k, i, o = maps.kernel_map('nbr_up', ts)
+            ok, oi, oo = me.transposed_kernel_map(ocoords[2 * ts], ocoords[ts], 3, 3, ts)
+            np.testing.assert_array_equal(np.stack([k, i, o]), np.stack([ok, oi, oo]))
 
 
 def test_duplicate_coordinates_are_rejected():
