@@ -64,7 +64,7 @@ __device__ __forceinline__ f32x4 dgr_y_load(const float *p) {
 //   * row indices travel through a 4-slot LDS ring, loaded two tiles ahead.
 // Timing ablations for tools/layer_bench.py (results in DESIGN.md 4.2; outputs are garbage): -DDGR_ABL_NOGATHER,
 // -DDGR_ABL_BONCE (weight operands loaded once), -DDGR_ABL_STORE0 (product rows to an L2-resident slab),
-// -DDGR_ABL_NOBARRIER; -DDGR_WIDE_CK=64 -DDGR_WIDE_WAVES=3 builds the widest configuration for 3 waves/SIMD.
+// -DDGR_ABL_NOBARRIER, -DDGR_ABL_NOMFMA; -DDGR_WIDE_CK=64 -DDGR_WIDE_WAVES=3 builds the widest configuration for 3 waves/SIMD.
 // ------------------------------------------------------------------------------------------
 #ifndef DGR_WIDE_CK
 #define DGR_WIDE_CK 128     // phase width (input channels) of the widest configuration
@@ -253,6 +253,12 @@ __global__ void __launch_bounds__(64 * WM * WN, (MB * NB >= 4 ? DGR_WIDE_WAVES :
       f32x4 av[MB];
 #pragma unroll
       for (int i = 0; i < MB; ++i) av[i] = *reinterpret_cast<const f32x4 *>(arow + i * 32 * LDA + s * 8);
+#ifdef DGR_ABL_NOMFMA   // timing ablation: the skeleton (gather, landing, LDS reads, weight loads, stores) without the matrix work
+#pragma unroll
+      for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j][0] += b[s % RING][j][0] * av[i][0] + b[s % RING][j][3] * av[i][3];
+#else
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -260,6 +266,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (MB * NB >= 4 ? DGR_WIDE_WAVES :
 #pragma unroll
           for (int j = 0; j < NB; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[s % RING][j][c], av[i][c], acc[i][j], 0, 0, 0);
+#endif
     }
     if (h == PPT - 1) {
       // ---- tile finished: request the next tile's first B operands BEFORE this tile's stores

@@ -179,6 +179,11 @@ struct DgrConvLaunch {
   int64_t tile_bound;                                        // host upper bound on the tile count (0 = unknown)
 };
 int dgr_conv_launch(const DgrConvLaunch &a, int num_cus, hipStream_t stream, const char **kernel_name = nullptr);
+// wide layers (Cout >= 128): the same phase 1 on the bf16 matrix pipe with every f32 operand split exactly into
+// three bf16 pieces (conv_bf3.hip); wb = the layer's pre-split weights, piece_stride in 16-byte units
+bool dgr_conv_bf3_supported(int cin_pad, int cin, int cout);
+int dgr_conv_bf3_launch(const DgrConvLaunch &a, const void *wb, int64_t piece_stride, int num_cus, hipStream_t stream,
+                        const char **kernel_name = nullptr);
 // out[o,:] = shift (+res[o,:]) + sum_{j in [ptr[o], ptr[o+1])} y[pos[j],:]   (ascending-k order)
 int dgr_reduce_rows(const float *y, int cout, const int32_t *ptr, const int32_t *pos, const int32_t *n_dev,
                     int64_t n_cap, float *out, int out_ld, const float *shift, const float *res, int res_ld,

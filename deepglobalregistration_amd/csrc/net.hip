@@ -28,6 +28,8 @@ struct DgrLayer {
   int K, cin, cout, cin_pad, cout_pad;
   float *w = nullptr;      // device, tiled
   float *w16 = nullptr;    // device, 16x16x4 fragment order (3-D K = 27 layers: output-stationary conv, conv_os.hip)
+  void *wb = nullptr;      // device, three exact bf16 pieces in 32x32x16 fragment order (wide layers, conv_bf3.hip)
+  int64_t wb_piece = 0;    // 16-byte units per piece
   float *shift = nullptr;  // device [cout] or nullptr
 };
 
@@ -108,6 +110,39 @@ static int make_layer(dgr_net *net, const dgr_weight_desc *descs, int nd, const 
     for (int c = 0; c < cout; ++c) shift[c] += bd->data[c];
     has_shift = true;
   }
+  // DGR_CONV_F32=1 keeps the exact-f32 MFMA kernel for the wide layers (A/B measurements); by default they run
+  // on the bf16 pipe with exactly split operands (conv_bf3.hip) and only that weight copy is made
+  static const bool f32_wide = getenv("DGR_CONV_F32") != nullptr;
+  const bool use_bf3 = K > 1 && !f32_wide && dgr_conv_bf3_supported(L.cin_pad, cin, cout) && !(net->D == 3 && K == 27);
+  if (use_bf3) {
+    const int S16 = cin / 16, NB32 = cout / 32;
+    L.wb_piece = (int64_t)K * S16 * NB32 * 64;
+    std::vector<uint16_t> pieces((size_t)3 * L.wb_piece * 8);
+    auto top16 = [](float x) { uint32_t b; memcpy(&b, &x, 4); return b & 0xffff0000u; };
+    auto asf = [](uint32_t b) { float x; memcpy(&x, &b, 4); return x; };
+    for (int k = 0; k < K; ++k) {
+      const float *src = kd->data + (size_t)k * cin * cout;
+      for (int s = 0; s < S16; ++s)
+        for (int nb = 0; nb < NB32; ++nb)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int col = 32 * nb + (lane & 31);
+            const size_t o = ((((size_t)k * S16 + s) * NB32 + nb) * 64 + lane) * 8;
+            for (int e = 0; e < 8; ++e) {
+              const float x = src[(size_t)(16 * s + 8 * (lane >> 5) + e) * cout + col] * scale[col];
+              const uint32_t h = top16(x);
+              const float r1 = x - asf(h);
+              const uint32_t m = top16(r1);
+              const float r2 = r1 - asf(m);          // <= 8 significant bits: exact in bf16
+              pieces[o + e] = (uint16_t)(h >> 16);
+              pieces[(size_t)L.wb_piece * 8 + o + e] = (uint16_t)(m >> 16);
+              pieces[(size_t)2 * L.wb_piece * 8 + o + e] = (uint16_t)(top16(r2) >> 16);
+            }
+          }
+    }
+    DGR_HIP_CHECK(hipMalloc(&L.wb, pieces.size() * sizeof(uint16_t)));
+    DGR_HIP_CHECK(hipMemcpy(L.wb, pieces.data(), pieces.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    net->param_bytes += pieces.size() * sizeof(uint16_t);
+  } else {
   const int S = L.cin_pad / 8, NBLK = L.cout_pad / 32;
   const size_t per_k = (size_t)S * NBLK * 256;
   std::vector<float> tiled((size_t)K * per_k);
@@ -128,6 +163,7 @@ static int make_layer(dgr_net *net, const dgr_weight_desc *descs, int nd, const 
   DGR_HIP_CHECK(hipMalloc((void **)&L.w, tiled.size() * sizeof(float)));
   DGR_HIP_CHECK(hipMemcpy(L.w, tiled.data(), tiled.size() * sizeof(float), hipMemcpyHostToDevice));
   net->param_bytes += tiled.size() * sizeof(float);
+  }
   if (net->D == 3 && K == 27 && L.cin_pad % 16 == 0 && cout % 32 == 0) {
     // second copy in v_mfma_f32_16x16x4_f32 operand order (conv_os.hip): W16[k][g][jb][lane][c]
     const int GT = L.cin_pad / 16, NB = cout / 16;
@@ -203,6 +239,7 @@ extern "C" void dgr_net_destroy(dgr_net *net) {
   for (auto &l : net->layers) {
     if (l.w) (void)hipFree(l.w);
     if (l.w16) (void)hipFree(l.w16);
+    if (l.wb) (void)hipFree(l.wb);
     if (l.shift) (void)hipFree(l.shift);
   }
   delete net;
@@ -303,6 +340,8 @@ struct Fwd {
     if (small_cin)
       DGR_CHECK(dgr_conv_small_cin(in.ptr, in.ld, in.relu, L.cin, L.w, L.shift, *km, cout_map.n_dev, cout_map.n_cap,
                                    out.ptr, out.ld, stream));
+    else if (L.wb && km)
+      DGR_CHECK(dgr_conv_bf3_launch(a, L.wb, L.wb_piece, ctx->num_cus, stream, &kname));
     else
       DGR_CHECK(dgr_conv_launch(a, ctx->num_cus, stream, &kname));
     if (prof) DGR_HIP_CHECK(hipEventRecord(em, stream));   // end of the MFMA phase
@@ -622,6 +661,8 @@ extern "C" int dgr_net_rerun_layer(dgr_ctx *ctx, dgr_net *net, int layer, int re
     else if (r.small_cin)
       DGR_CHECK(dgr_conv_small_cin(r.launch.in, r.launch.in_ld, r.launch.in_relu, L.cin, L.w, L.shift, r.km, r.n_out,
                                    r.n_out_cap, r.launch.out, r.launch.out_ld, nullptr));
+    else if (L.wb && r.has_reduce)
+      DGR_CHECK(dgr_conv_bf3_launch(r.launch, L.wb, L.wb_piece, ctx->num_cus, nullptr));
     else
       DGR_CHECK(dgr_conv_launch(r.launch, ctx->num_cus, nullptr));
     DGR_HIP_CHECK(hipEventRecord(e1, nullptr));
