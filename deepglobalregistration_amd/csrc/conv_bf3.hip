@@ -85,45 +85,48 @@ __global__ void __launch_bounds__(256, 2) sparse_conv_bf16x3(ConvBf3Args a) {
     locate(i, k, pstart, count);
     return tid < count ? a.pair_in[pstart + tid] : -1;
   };
-  f32x4 G[NCH];
-  uint32_t g_ok = 0;
-  auto gather = [&](int q) {   // requests only (see conv.hip)
+  // Gathered rows travel through TWO register sets (phase p uses set p & 1): a phase's rows are requested three
+  // phases before they are multiplied and landed one phase before -- two whole phases for the memory system
+  // (measured: with one phase of lead the kernel ran at the speed of the gather latency under load, ~7 us)
+  f32x4 G0[NCH], G1[NCH];
+  uint32_t ok0 = 0, ok1 = 0;
+  auto gather_piece = [&](int q, int i, f32x4 *G, uint32_t &g_ok) {   // requests only (see conv.hip)
     const int *idx = idxbuf[(q / PPT) & 3];
-    const int cbase = (q % PPT) * CK;
-    g_ok = 0;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int ch = tid + i * THREADS;
-      const int r = ch / C4K, c = cbase + (ch % C4K) * 4;
-      const int row = idx[r];
-      G[i] = *reinterpret_cast<const f32x4 *>(a.in + (int64_t)max(row, 0) * a.in_ld + min(c, a.cin - 4));
-      g_ok |= (row >= 0 && c < a.cin) ? (1u << i) : 0u;
-    }
+    const int ch = tid + i * THREADS;
+    const int r = ch / C4K, c = (q % PPT) * CK + (ch % C4K) * 4;
+    const int row = idx[r];
+#ifdef DGR_BF3_ABL_NOGATHER   // timing ablations for tools/layer_bench.py (outputs are garbage)
+    G[i] = f32x4{(float)row, (float)c, 1.f, 2.f};
+#else
+    G[i] = *reinterpret_cast<const f32x4 *>(a.in + (int64_t)max(row, 0) * a.in_ld + min(c, a.cin - 4));
+#endif
+    g_ok = (g_ok & ~(1u << i)) | ((row >= 0 && c < a.cin) ? (1u << i) : 0u);
   };
   const int relu_lo = a.in_relu ? 0 : (int)0x80000000;
-  auto land = [&](int q) {     // registers -> three bf16 planes of buffer q & 1
+  auto land_piece = [&](int q, int i, const f32x4 *G, uint32_t g_ok) {     // registers -> three bf16 planes of buffer q & 1
     unsigned short *dst = &Ps[q & 1][0][0];
+    const int ch = tid + i * THREADS;
+    const bool ok = (g_ok >> i) & 1u;
+    uint32_t h[4], m[4], l[4];
+    const i32x4 gi = __builtin_bit_cast(i32x4, G[i]);   // (bit_cast of a single vector ELEMENT reads element 0)
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int ch = tid + i * THREADS;
-      const bool ok = (g_ok >> i) & 1u;
-      uint32_t h[4], m[4], l[4];
-      const i32x4 gi = __builtin_bit_cast(i32x4, G[i]);   // (bit_cast of a single vector ELEMENT reads element 0)
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        int xb = max(gi[u], relu_lo);   // pending ReLU as one integer max
-        xb = ok ? xb : 0;
-        dgr_split3(__builtin_bit_cast(float, xb), h[u], m[u], l[u]);
-      }
-      const int o = (ch / C4K) * LDP + (ch % C4K) * 4;
-      *reinterpret_cast<u32x2 *>(dst + o) = u32x2{(h[0] >> 16) | h[1], (h[2] >> 16) | h[3]};
-      *reinterpret_cast<u32x2 *>(dst + PLANE + o) = u32x2{(m[0] >> 16) | m[1], (m[2] >> 16) | m[3]};
-      *reinterpret_cast<u32x2 *>(dst + 2 * PLANE + o) = u32x2{(l[0] >> 16) | (l[1] & 0xffff0000u), (l[2] >> 16) | (l[3] & 0xffff0000u)};
+    for (int u = 0; u < 4; ++u) {
+      int xb = max(gi[u], relu_lo);   // pending ReLU as one integer max
+      xb = ok ? xb : 0;
+      dgr_split3(__builtin_bit_cast(float, xb), h[u], m[u], l[u]);
     }
+    const int o = (ch / C4K) * LDP + (ch % C4K) * 4;
+    *reinterpret_cast<u32x2 *>(dst + o) = u32x2{(h[0] >> 16) | h[1], (h[2] >> 16) | h[3]};
+    *reinterpret_cast<u32x2 *>(dst + PLANE + o) = u32x2{(m[0] >> 16) | m[1], (m[2] >> 16) | m[3]};
+    *reinterpret_cast<u32x2 *>(dst + 2 * PLANE + o) = u32x2{(l[0] >> 16) | (l[1] & 0xffff0000u), (l[2] >> 16) | (l[3] & 0xffff0000u)};
   };
   // weight operands of k-step s (16 input channels) of rule k: 3 pieces x NB column blocks, 16 bytes per lane each
   auto wload = [&](int k, int s, uint4 (*w)[3]) {
+#ifdef DGR_BF3_ABL_BONCE
+    const uint4 *p = a.wb + ((int64_t)(0 * S + (s & 1)) * NBLK + wn * NB) * 64 + lane;   // L1-resident: no L2 weight stream
+#else
     const uint4 *p = a.wb + ((int64_t)(k * S + s) * NBLK + wn * NB) * 64 + lane;
+#endif
 #pragma unroll
     for (int j = 0; j < NB; ++j)
 #pragma unroll
@@ -132,27 +135,33 @@ __global__ void __launch_bounds__(256, 2) sparse_conv_bf16x3(ConvBf3Args a) {
 
   // ---- prologue
   {
-    const int i0 = load_idx(0), i1 = load_idx(1), i2 = load_idx(2);
-    if (tid < TM) { idxbuf[0][tid] = i0; idxbuf[1][tid] = i1; idxbuf[2][tid] = i2; }
+    const int i0 = load_idx(0), i1 = load_idx(1), i2 = load_idx(2), i3 = load_idx(3);
+    if (tid < TM) { idxbuf[0][tid] = i0; idxbuf[1][tid] = i1; idxbuf[2][tid] = i2; idxbuf[3][tid] = i3; }
   }
-  int next_pub = 3;
-  int idx_reg = load_idx(3);
+  int next_pub = 4;   // the ring holds the tiles of phases q + 1 .. q + 3; tile (q + 4) / PPT is published one phase ahead
+  int idx_reg = load_idx(4);
   int k, pstart, count;
   locate(0, k, pstart, count);
   uint4 w[2][NB][3];            // k-step ring of depth 2
   wload(k, 0, w[0]);
   __syncthreads();
-  gather(0);
-  land(0);
-  if (1 < NQ) gather(1);
+  // the index ring holds tiles 0..3: phases 0, 1, 2 can be requested now
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) gather_piece(0, i, G0, ok0);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) land_piece(0, i, G0, ok0);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) gather_piece(min(1, NQ - 1), i, G1, ok1);
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) gather_piece(min(2, NQ - 1), i, G0, ok0);
   __syncthreads();
 
   f32x16 acc[MB][NB];
-  for (int q = 0; q < NQ; ++q) {
+  static_assert(NCH == SK, "one gather piece per k-step");
+  // one phase; G / g_ok = the register set of phase q + 1 (landed here, then re-requested for phase q + 3)
+  auto phase = [&](int q, f32x4 *G, uint32_t &g_ok) {
     const int h = q % PPT;
-    if (q + 1 < NQ) land(q + 1);      // requested one phase ago
-    if (q + 2 < NQ) gather(q + 2);    // a whole phase to arrive
-    if ((q + 3) / PPT >= next_pub && next_pub < n_my) {
+    if ((q + 4) / PPT >= next_pub && next_pub < n_my) {
       if (tid < TM) idxbuf[next_pub & 3][tid] = idx_reg;
       ++next_pub;
       idx_reg = load_idx(next_pub);
@@ -167,6 +176,7 @@ __global__ void __launch_bounds__(256, 2) sparse_conv_bf16x3(ConvBf3Args a) {
     }
     const unsigned short *pl = &Ps[q & 1][0][0] + (lane & 31) * LDP + 8 * (lane >> 5);
     const int s0 = h * SK;
+    const int q_req = min(q + 3, NQ - 1);   // clamped: the tail re-requests the last phase, landed where nobody reads
 #pragma unroll
     for (int s = 0; s < SK; ++s) {
       // the next k-step's operands (of this tile, or the first of the next tile at the tile's last step)
@@ -192,15 +202,16 @@ __global__ void __launch_bounds__(256, 2) sparse_conv_bf16x3(ConvBf3Args a) {
 #define DGR_BF3_TERM(WP, AX)                                                                                        \
   _Pragma("unroll") for (int i = 0; i < MB; ++i) _Pragma("unroll") for (int j = 0; j < NB; ++j)                     \
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wc[j][WP]), AX[i], acc[i][j], 0, 0, 0);
-#ifndef DGR_BF3_DEBUG_HH
       DGR_BF3_TERM(2, ah)   // wl . ah
       DGR_BF3_TERM(0, al)   // wh . al
       DGR_BF3_TERM(1, am)   // wm . am
       DGR_BF3_TERM(1, ah)   // wm . ah
       DGR_BF3_TERM(0, am)   // wh . am
-#endif
       DGR_BF3_TERM(0, ah)   // wh . ah
 #undef DGR_BF3_TERM
+      // piece s of the NEXT phase: split + land (requested one phase ago), then request piece s of the phase after
+      land_piece(q + 1, s, G, g_ok);
+      gather_piece(q_req, s, G, g_ok);
     }
     if (h == PPT - 1) {
       const int pst = pstart, cnt = count;
@@ -210,7 +221,11 @@ __global__ void __launch_bounds__(256, 2) sparse_conv_bf16x3(ConvBf3Args a) {
       for (int i = 0; i < MB; ++i) {
         const int r = 32 * i + (lane & 31);
         if (r < cnt) {
+#ifdef DGR_BF3_ABL_STORE0
+          float *dst = a.y + (int64_t)(r + 64 * (blockIdx.x & 1023)) * a.cout;   // L2-resident product rows
+#else
           float *dst = a.y + (int64_t)(pst + r) * a.cout;
+#endif
 #pragma unroll
           for (int j = 0; j < NB; ++j)
 #pragma unroll
@@ -223,6 +238,10 @@ __global__ void __launch_bounds__(256, 2) sparse_conv_bf16x3(ConvBf3Args a) {
       }
     }
     __syncthreads();
+  };
+  for (int q = 0; q < NQ; q += 2) {   // register sets alternate statically
+    phase(q, G1, ok1);
+    if (q + 1 < NQ) phase(q + 1, G0, ok0);
   }
 }
 

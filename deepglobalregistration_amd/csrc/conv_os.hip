@@ -284,7 +284,7 @@ int dgr_conv_os_launch(const DgrConvOsLaunch &a, hipStream_t stream, const char 
   ka.res_ld = a.res_ld; ka.res_relu = a.res_relu;
   ka.cin = a.cin; ka.cout = a.cout; ka.nb16 = a.cout / 16;
 #ifndef DGR_OS_TM
-#define DGR_OS_TM 64
+#define DGR_OS_TM 32
 #endif
 #ifndef DGR_OS_MBBIG
 #define DGR_OS_MBBIG 64
