@@ -79,6 +79,7 @@ int DgrArena::reset() {
   cur = 0;
   offset = 0;
   used_total = 0;
+  ++generation;
   return DGR_OK;
 }
 

@@ -51,6 +51,7 @@ struct DgrArena {
   size_t cur = 0;     // index of the chunk being bumped
   size_t offset = 0;  // bump offset in chunks[cur]
   size_t high_water = 0, used_total = 0;
+  uint64_t generation = 0;  // bumped by reset(): pointers into the arena handed out before are dead afterwards
 
   struct Mark {
     size_t cur, offset, used_total;
@@ -215,6 +216,7 @@ int dgr_l2_normalize_rows(const float *in, int in_ld, float *out, int out_ld, in
 struct DgrBatchOutputs {
   const void *ptr[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   int64_t numel[5] = {0, 0, 0, 0, 0};
+  uint64_t generation = 0;   // arena generation the pointers belong to
 };
 
 struct DgrEventPool {  // HIP events bracketing the conv kernels when profiling is on

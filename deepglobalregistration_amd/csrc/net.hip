@@ -64,6 +64,7 @@ struct dgr_net {
   int64_t param_bytes = 0;
   LayerRun runs[23];
   std::map<std::string, DgrTensorRef> inter;
+  uint64_t run_generation = 0;   // arena generation `runs` / `inter` point into
 };
 
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -488,6 +489,7 @@ int dgr_resunet_forward_impl(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, 
     DGR_CHECK(dgr_l2_normalize_rows(fin, net->cout, out, net->cout, net->cout, 0, ms.cm[0].n_dev, n1, stream));
 
   auto &I = net->inter;
+  net->run_generation = ctx->arena.generation;
   I.clear();
   I["s1"] = {S1.ptr, 96, 32, ms.cm[0].n_dev};
   I["s2"] = {S2.ptr, 128, 64, ms.cm[1].n_dev};
@@ -565,6 +567,8 @@ int dgr_ctx_check_flag(dgr_ctx *ctx, hipStream_t stream) {
   return check_flag(ctx, ctx->flag_dev, stream);
 }
 
+// the fused pipeline rewinds the arena region of a forward and reuses it: its maps / activations are gone
+void dgr_net_invalidate_runs(dgr_net *net) { net->run_generation = ~0ull; }
 int dgr_net_out_channels(const dgr_net *net) { return net->cout; }
 int dgr_net_in_channels(const dgr_net *net) { return net->cin; }
 int dgr_net_dim(const dgr_net *net) { return net->D; }
@@ -592,6 +596,8 @@ extern "C" int dgr_net_get_intermediate(dgr_ctx *ctx, dgr_net *net, const char *
   DGR_REQUIRE(ctx && net && name && rows && cols, "NULL argument");
   auto it = net->inter.find(name);
   DGR_REQUIRE(it != net->inter.end() && it->second.n_dev, "no intermediate named '%s' (run a forward first)", name);
+  DGR_REQUIRE(net->run_generation == ctx->arena.generation,
+              "the activations of the last forward are gone: a later call on this context reused its workspace");
   const DgrTensorRef &t = it->second;
   int32_t n = 0;
   DGR_HIP_CHECK(hipDeviceSynchronize());
@@ -612,6 +618,8 @@ extern "C" int dgr_net_layer_stats(dgr_ctx *ctx, dgr_net *net, int layer, int64_
   DGR_REQUIRE(layer >= 0 && layer < (int)net->layers.size(), "layer %d out of range", layer);
   const LayerRun &r = net->runs[layer];
   DGR_REQUIRE(r.n_in && r.n_out, "run a forward first");
+  DGR_REQUIRE(net->run_generation == ctx->arena.generation,
+              "the kernel maps of the last forward are gone: a later call on this context reused its workspace");
   const DgrLayer &L = net->layers[layer];
   DGR_HIP_CHECK(hipDeviceSynchronize());
   int32_t n_in = 0, n_out = 0;
@@ -649,6 +657,8 @@ extern "C" int dgr_net_rerun_layer(dgr_ctx *ctx, dgr_net *net, int layer, int re
   DGR_REQUIRE(layer >= 0 && layer < (int)net->layers.size(), "layer %d out of range", layer);
   const LayerRun &r = net->runs[layer];
   DGR_REQUIRE(r.n_in && r.n_out, "run a forward first");
+  DGR_REQUIRE(net->run_generation == ctx->arena.generation,
+              "the kernel maps of the last forward are gone: a later call on this context reused its workspace");
   DGR_REQUIRE(!r.fused_pairs, "layer %d ran fused with its neighbour search; not re-runnable", layer);
   const DgrLayer &L = net->layers[layer];
   hipEvent_t e0, e1, e2;

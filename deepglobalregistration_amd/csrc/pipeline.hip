@@ -14,6 +14,7 @@ int dgr_registration_launch_ctx(dgr_ctx *ctx, const float *xyz0, const float *xy
 int dgr_ctx_new_flag(dgr_ctx *ctx, hipStream_t stream);
 int dgr_ctx_check_flag(dgr_ctx *ctx, hipStream_t stream);
 int dgr_net_out_channels(const dgr_net *net);
+void dgr_net_invalidate_runs(dgr_net *net);
 int dgr_net_in_channels(const dgr_net *net);
 int dgr_net_dim(const dgr_net *net);
 
@@ -215,6 +216,7 @@ extern "C" int dgr_register_batch(dgr_ctx *ctx, dgr_net *fcgf, dgr_net *inlier, 
     concat_coords_kernel<<<(int)dgr_ceil_div(n0 + n1, 256), 256, 0, stream>>>(coords0, n0, coords1, n1, coords01);
     DGR_CHECK(dgr_resunet_forward_impl(ctx, fcgf, coords01, ones, n0 + n1, F0, stream));
     A.rewind(mk);
+    dgr_net_invalidate_runs(fcgf);
   }
   DGR_CHECK(tm.rec(0, 1));
   // Step 2: coarse correspondences, per pair (corres_idx0 = arange)
@@ -238,6 +240,7 @@ extern "C" int dgr_register_batch(dgr_ctx *ctx, dgr_net *fcgf, dgr_net *inlier, 
     DgrArena::Mark mk = A.mark();
     DGR_CHECK(dgr_resunet_forward_impl(ctx, inlier, coords6, feats6, n0, logit, stream));
     A.rewind(mk);
+    dgr_net_invalidate_runs(inlier);
   }
   DGR_CHECK(tm.rec(3, 1));
   // Step 5 case 0: gate + weighted Procrustes + robust refinement, one workgroup per pair
@@ -276,6 +279,7 @@ extern "C" int dgr_register_batch(dgr_ctx *ctx, dgr_net *fcgf, dgr_net *inlier, 
   ctx->last.ptr[2] = weights; ctx->last.numel[2] = n0;
   ctx->last.ptr[3] = F0;      ctx->last.numel[3] = n0 * C;
   ctx->last.ptr[4] = F1;      ctx->last.numel[4] = n1 * C;
+  ctx->last.generation = ctx->arena.generation;
   if (ctx->profiling) {
     memset(ctx->stage_ms, 0, sizeof(ctx->stage_ms));
     for (int s = 0; s < 5; ++s) DGR_HIP_CHECK(hipEventElapsedTime(&ctx->stage_ms[s], tm.e[s][0], tm.e[s][1]));
@@ -288,6 +292,9 @@ extern "C" int dgr_register_batch_output(dgr_ctx *ctx, int which, void *dst_dev,
                                          int64_t *numel, dgr_stream stream) {
   DGR_REQUIRE(ctx && numel && which >= 0 && which < 5, "dgr_register_batch_output: bad argument");
   DGR_REQUIRE(ctx->last.ptr[which] != nullptr, "no dgr_register_batch has run on this ctx");
+  DGR_REQUIRE(ctx->last.generation == ctx->arena.generation,
+              "the outputs of the last dgr_register_batch are gone: a later call on this context reused its workspace "
+              "(fetch them before the next library call)");
   *numel = ctx->last.numel[which];
   if (dst_dev) {
     const int64_t bytes = ctx->last.numel[which] * (which == 0 ? 8 : 4);

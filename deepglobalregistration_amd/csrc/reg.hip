@@ -163,6 +163,19 @@ __device__ __forceinline__ void ortho_backward(const Ortho &o, const float G[9],
   for (int i = 0; i < 3; ++i) gp[3 + i] = gb[i];
 }
 
+// HighDimSmoothL1Loss per point (core/loss.py:51-61) of s = sum(((X - Y) / q)^2): value and d/ds;
+// discontinuous at s == 1 (0.5 vs 0.25) like the reference
+__device__ __forceinline__ void dgr_smooth_l1(float s, float eps, float &per, float &dps) {
+  if (s < 1.f) {
+    per = 0.5f * s;
+    dps = 0.5f;
+  } else {
+    const float rt = sqrtf(s + eps);
+    per = 0.5f * (rt - 0.5f);
+    dps = 0.25f / rt;
+  }
+}
+
 __global__ void __launch_bounds__(REG_THREADS) registration_kernel(RegArgs a) {
   __shared__ double red[REG_WAVES * 17 + 17];
   __shared__ double slab[2 * REG_WAVES * 16];
@@ -312,26 +325,22 @@ __global__ void __launch_bounds__(REG_THREADS) registration_kernel(RegArgs a) {
       const float px = A.x * R00 + A.y * R01 + A.z * R02 + prm[6];
       const float py = A.x * R10 + A.y * R11 + A.z * R12 + prm[7];
       const float pz = A.x * R20 + A.y * R21 + A.z * R22 + prm[8];
-      // `(X - Y) / quantization_size` (core/loss.py:54) divides a tensor by a Python scalar: on the reference's CUDA
-      // device ATen evaluates that as a multiplication by the f32 reciprocal (div_true_kernel_cuda, "compute
-      // a * reciprocal(b)"), on the CPU as a true division.  The multiplication also saves three ~10-instruction
-      // IEEE divisions per point (-12 % per iteration); -DDGR_REG_TRUE_DIV gives the CPU behaviour.
-#ifndef DGR_REG_TRUE_DIV
+      // `(X - Y) / quantization_size` (core/loss.py:54) divides a tensor by a Python scalar: on the reference's CPU
+      // path a true division (the default here: it is what the oracle and the golden vectors do), on its CUDA
+      // device ATen multiplies by the f32 reciprocal (div_true_kernel_cuda).  -DDGR_REG_RECIP_MUL selects the
+      // latter (three ~10-instruction IEEE divisions less per point, -12 % per iteration).  Measured: the two
+      // differ by one ulp in s for q = 0.05, which moves points across the s = 1 discontinuity of the loss; after
+      // 334 Adam iterations on a 113 k-point pair the result was 1.0e-3 away from the CPU reference with the
+      // reciprocal and 3.4e-5 with the division (tests/test_gpu_configs.py, iteration-matched).
+#ifdef DGR_REG_RECIP_MUL
       const float rx = (px - B.x) * inv_q, ry = (py - B.y) * inv_q, rz = (pz - B.z) * inv_q;
 #else
       const float rx = (px - B.x) / q, ry = (py - B.y) / q, rz = (pz - B.z) / q;
 #endif
       const float s = rx * rx + ry * ry + rz * rz;
       float per, dps;
-      if (s < 1.f) {
-        per = 0.5f * s;
-        dps = 0.5f;
-      } else {
-        const float rt = sqrtf(s + a.eps);
-        per = 0.5f * (rt - 0.5f);  // discontinuous at s == 1 like core/loss.py:55-56
-        dps = 0.25f / rt;
-      }
-#ifndef DGR_REG_TRUE_DIV
+      dgr_smooth_l1(s, a.eps, per, dps);
+#ifdef DGR_REG_RECIP_MUL
       const float wk = A.w * dps * 2.f * inv_q;   // DivBackward by the same scalar: again a reciprocal multiply
 #else
       const float wk = A.w * dps * 2.f / q;
@@ -503,5 +512,58 @@ extern "C" int dgr_se3_refine(dgr_ctx *ctx, const float *X, const float *Y, cons
   if (iterations) *iterations = r.iterations;
   if (loss) *loss = r.loss;
   if (break_count) *break_count = r.break_count;
+  return DGR_OK;
+}
+
+// ---- debug entry points: the device functions of the registration kernel on their own, so that the parity tests
+//      can hold them against the reference-generated vectors directly (tests/golden/ortho6d*.npz, loss.npz) ----
+__global__ void debug_ortho_kernel(const float *__restrict__ P, int64_t n, const float *__restrict__ G,
+                                   float *__restrict__ R, float *__restrict__ dP) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float p[6];
+  for (int d = 0; d < 6; ++d) p[d] = P[i * 6 + d];
+  Ortho o;
+  ortho_forward(p, o);
+  for (int a = 0; a < 3; ++a) {   // R = [x y z] as columns
+    R[i * 9 + 3 * a + 0] = o.x[a];
+    R[i * 9 + 3 * a + 1] = o.y[a];
+    R[i * 9 + 3 * a + 2] = o.z[a];
+  }
+  if (G && dP) {
+    float g[9], gp[6];
+    for (int d = 0; d < 9; ++d) g[d] = G[i * 9 + d];
+    ortho_backward(o, g, gp);
+    for (int d = 0; d < 6; ++d) dP[i * 6 + d] = gp[d];
+  }
+}
+
+__global__ void debug_loss_kernel(const float *__restrict__ X, const float *__restrict__ Y, int64_t n, float inv_q,
+                                  float eps, float *__restrict__ per_point) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float rx = (X[i * 3] - Y[i * 3]) * inv_q, ry = (X[i * 3 + 1] - Y[i * 3 + 1]) * inv_q,
+              rz = (X[i * 3 + 2] - Y[i * 3 + 2]) * inv_q;
+  float per, dps;
+  dgr_smooth_l1(rx * rx + ry * ry + rz * rz, eps, per, dps);
+  per_point[i] = per;
+}
+
+extern "C" int dgr_debug_ortho2rotation(dgr_ctx *ctx, const float *p6, int64_t n, const float *grad_R9, float *R9_out,
+                                        float *grad_p6_out, dgr_stream stream) {
+  DGR_REQUIRE(ctx && p6 && R9_out && n > 0, "dgr_debug_ortho2rotation: bad argument");
+  DGR_HIP_CHECK(hipSetDevice(ctx->device));
+  debug_ortho_kernel<<<(int)dgr_ceil_div(n, 64), 64, 0, (hipStream_t)stream>>>(p6, n, grad_R9, R9_out, grad_p6_out);
+  DGR_LAUNCH_CHECK();
+  return DGR_OK;
+}
+
+extern "C" int dgr_debug_smooth_l1(dgr_ctx *ctx, const float *X, const float *Y, int64_t n, float quantization_size,
+                                   float *per_point_out, dgr_stream stream) {
+  DGR_REQUIRE(ctx && X && Y && per_point_out && n > 0 && quantization_size > 0, "dgr_debug_smooth_l1: bad argument");
+  DGR_HIP_CHECK(hipSetDevice(ctx->device));
+  debug_loss_kernel<<<(int)dgr_ceil_div(n, 64), 64, 0, (hipStream_t)stream>>>(X, Y, n, 1.f / quantization_size,
+                                                                              1.1920928955078125e-07f, per_point_out);
+  DGR_LAUNCH_CHECK();
   return DGR_OK;
 }

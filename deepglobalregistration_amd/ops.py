@@ -405,3 +405,27 @@ def conv_launch_kinds(device):
     check(_lib.load().dgr_ctx_conv_launch_kinds(get_ctx(device), buf, cap, C.byref(n)))
     names = buf.value.decode().split('\n')
     return names[:n.value]
+
+
+def debug_ortho2rotation(p6, grad_R=None):
+    """ortho2rotation forward (and backward for `grad_R` [n,3,3]) exactly as the registration kernel computes it."""
+    dev = _dev(p6)
+    p6 = _as(p6, torch.float32, dev).reshape(-1, 6)
+    n = p6.shape[0]
+    R = torch.empty((n, 3, 3), dtype=torch.float32, device=dev)
+    g = dp = None
+    if grad_R is not None:
+        g = _as(grad_R, torch.float32, dev).reshape(n, 9)
+        dp = torch.empty((n, 6), dtype=torch.float32, device=dev)
+    check(_lib.load().dgr_debug_ortho2rotation(get_ctx(dev), ptr(p6), n, ptr(g), ptr(R), ptr(dp), stream_ptr(dev.index)))
+    return (R, dp) if grad_R is not None else R
+
+
+def debug_smooth_l1(X, Y, quantization_size):
+    """HighDimSmoothL1Loss per point, the device function of the registration kernel."""
+    dev = _dev(X)
+    X, Y = _as(X, torch.float32, dev), _as(Y, torch.float32, dev)
+    out = torch.empty(X.shape[0], dtype=torch.float32, device=dev)
+    check(_lib.load().dgr_debug_smooth_l1(get_ctx(dev), ptr(X), ptr(Y), X.shape[0], float(quantization_size), ptr(out),
+                                          stream_ptr(dev.index)))
+    return out

@@ -231,6 +231,17 @@ int dgr_ctx_conv_launch_times(dgr_ctx *ctx, float *times_ms, float *gemm_ms, int
  * newline-separated and NUL-terminated in buf; *n = number of names written */
 int dgr_ctx_conv_launch_kinds(dgr_ctx *ctx, char *buf, int64_t capacity, int64_t *n);
 
+
+/* ---- debug entry points (parity tests): the device functions of the registration kernel on their own.
+ * ortho2rotation (core/registration.py:16-64) forward for n parameter rows p6 [n,6] -> R9_out [n,9] (row-major 3x3) and,
+ * when grad_R9 [n,9] and grad_p6_out [n,6] are given, its backward (what autograd computes for sum(R * grad_R)).
+ * All pointers are device pointers. */
+int dgr_debug_ortho2rotation(dgr_ctx *ctx, const float *p6, int64_t n, const float *grad_R9, float *R9_out,
+                             float *grad_p6_out, dgr_stream stream);
+/* HighDimSmoothL1Loss (core/loss.py:51-61) per point of X, Y [n,3] (device) with quantization_size q -> per_point_out [n] */
+int dgr_debug_smooth_l1(dgr_ctx *ctx, const float *X, const float *Y, int64_t n, float quantization_size,
+                        float *per_point_out, dgr_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

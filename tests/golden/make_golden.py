@@ -145,6 +145,84 @@ def main():
     P[4] = [1, 0, 0, 0, 1, 0]
     Rm = ortho2rotation(torch.from_numpy(P)).numpy()
     np.savez_compressed(os.path.join(HERE, 'ortho6d.npz'), P=P, R=Rm)
+
+    # ---- sections added in round 2: their own generators, so that the vectors above do not change ----
+    # (vi) ortho2rotation backward (autograd through core/registration.py:16-64, incl. the clamped cases)
+    r2 = np.random.default_rng(4321)
+    P2 = r2.standard_normal((32, 6)).astype(np.float32)
+    P2[0] = 0
+    P2[1, :3] = 0
+    P2[2, 3:] = P2[2, :3] * 2.5
+    P2[3] = [1e-9, 0, 0, 0, 1e-9, 0]
+    P2[4] = [1, 0, 0, 0, 1, 0]
+    P2[5] = [3, 0, 0, 0, 0, 1e-9]
+    G2 = r2.standard_normal((32, 3, 3)).astype(np.float32)
+    Pt = torch.from_numpy(P2).clone().requires_grad_(True)
+    Rt = ortho2rotation(Pt)
+    (Rt * torch.from_numpy(G2)).sum().backward()
+    np.savez_compressed(os.path.join(HERE, 'ortho6d_grad.npz'), P=P2, G=G2, R=Rt.detach().numpy(), dP=Pt.grad.numpy())
+
+    # (vii) find_knn_gpu_batch (core/knn.py:106-140): per-pair 1-NN over a concatenated feature batch
+    from core.knn import find_knn_gpu_batch
+    r3 = np.random.default_rng(777)
+    lens = [[700, 900], [1300, 1100], [33, 5]]
+    n0, n1 = sum(a for a, _ in lens), sum(b for _, b in lens)
+    F0 = r3.standard_normal((n0, 32)).astype(np.float32)
+    F1 = r3.standard_normal((n1, 32)).astype(np.float32)
+    F0 /= np.linalg.norm(F0, axis=1, keepdims=True)
+    F1 /= np.linalg.norm(F1, axis=1, keepdims=True)
+    per = find_knn_gpu_batch(torch.from_numpy(F0), torch.from_numpy(F1), lens, nn_max_n=250)
+    cat, dist = find_knn_gpu_batch(torch.from_numpy(F0), torch.from_numpy(F1), lens, nn_max_n=250,
+                                   return_distance=True, concat_results=True)
+    np.savez_compressed(os.path.join(HERE, 'knn_batch.npz'), F0=F0, F1=F1, len_batch=np.array(lens),
+                        per_pair=np.concatenate([t.numpy().reshape(-1) for t in per]),
+                        cat_idx=cat.numpy(), cat_dist=dist.numpy())
+
+    # (viii) evaluation formats / metrics.  util/file.py imports cleanly; scripts/test_3dmatch.py pulls in open3d and
+    # MinkowskiEngine at module level, so its `rte_rre` (:38-46) is executed from its own source text, alone.
+    import ast
+    import math
+    import tempfile
+    from util.file import read_trajectory
+    r4 = np.random.default_rng(99)
+    n_rec = 7
+    poses = []
+    lines = []
+    for i in range(n_rec):
+        Rr, tr = rand_pose(r4)
+        T = np.eye(4)
+        T[:3, :3], T[:3, 3] = Rr, tr
+        poses.append(T)
+        lines.append(f'{i}\t{i + 1 + (i % 3)}\t{n_rec + 30}')
+        for row in T:                       # the 3DMatch gt.log layout: tab-separated scientific notation
+            lines.append('\t'.join(f'{v: .8e}' for v in row))
+    text = '\n'.join(lines) + '\n'
+    with tempfile.NamedTemporaryFile('w', suffix='.log', delete=False) as f:
+        f.write(text)
+    traj = read_trajectory(f.name)
+    os.unlink(f.name)
+    src = open(os.path.join(REF, 'scripts', 'test_3dmatch.py')).read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == 'rte_rre'][0]
+    ns = {'np': np, 'math': math}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), 'scripts/test_3dmatch.py', 'exec'), ns)
+    ref_rte_rre = ns['rte_rre']
+    Tp, Tg, res = [], [], []
+    for i in range(24):
+        Rg, tg = rand_pose(r4)
+        a = Tg_ = np.eye(4)
+        Tg_[:3, :3], Tg_[:3, 3] = Rg, tg
+        ang = [0.0, 1e-9, 0.05, 0.2, 0.3, 1.0][i % 6]         # radians: identical, ~equal, below / above 15 degrees
+        ax = r4.standard_normal(3); ax /= np.linalg.norm(ax)
+        Kx = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        dR = np.eye(3) + math.sin(ang) * Kx + (1 - math.cos(ang)) * Kx @ Kx
+        Tp_ = np.eye(4)
+        Tp_[:3, :3] = dR @ Rg
+        Tp_[:3, 3] = tg + r4.standard_normal(3) * [0.0, 0.05, 0.2, 0.4][i % 4]
+        Tp.append(Tp_); Tg.append(Tg_.copy()); res.append(ref_rte_rre(Tp_, Tg_, 0.3, 15))
+    np.savez_compressed(os.path.join(HERE, 'eval_formats.npz'), gt_log_text=np.array(text),
+                        traj_meta=np.array([t.metadata for t in traj]), traj_pose=np.stack([t.pose for t in traj]),
+                        poses_written=np.stack(poses), T_pred=np.stack(Tp), T_gt=np.stack(Tg), rte_rre=np.stack(res),
+                        rte_rre_none=ref_rte_rre(None, Tg[0], 0.3, 15))
     print('golden vectors written to', HERE)
 
 

@@ -1,4 +1,6 @@
 """Evaluation harness and file formats -- host-side, CPU only."""
+import os
+
 import numpy as np
 import pytest
 
@@ -149,3 +151,25 @@ def test_kitti_pairs_ground_truth_and_loop(tmp_path):
     assert stats.shape == (2, 5) and summary['recall'] == 1.0 and (stats[:, 4] == 3).all() and lines
     with pytest.raises(FileNotFoundError):
         ev.KITTIOdometryPairs(str(root), [7])
+
+
+def test_trajectory_reader_and_rte_rre_match_the_reference(golden):
+    """`read_trajectory` (util/file.py:69-90) and `rte_rre` (scripts/test_3dmatch.py:38-46): the reference's own
+    functions were run on a generated gt.log / pose set by tests/golden/make_golden.py; the product's reader and
+    metric must reproduce their outputs on the same inputs."""
+    from deepglobalregistration_amd.eval import formats, metrics
+    g = golden('eval_formats')
+    path = os.path.join(os.environ.get('TMPDIR', '/tmp'), 'dgr_gt_golden.log')
+    with open(path, 'w') as f:
+        f.write(str(g['gt_log_text']))
+    traj = formats.read_trajectory(path)
+    os.unlink(path)
+    assert len(traj) == len(g['traj_meta'])
+    for rec, meta, pose in zip(traj, g['traj_meta'], g['traj_pose']):
+        m, T = (rec.metadata, rec.pose) if hasattr(rec, 'pose') else rec
+        np.testing.assert_array_equal(np.asarray(m), meta)
+        np.testing.assert_array_equal(np.asarray(T), pose)        # both parse the same text: bit-identical
+    np.testing.assert_allclose(g['traj_pose'], g['poses_written'], rtol=1e-8)
+    for Tp, Tg, ref in zip(g['T_pred'], g['T_gt'], g['rte_rre']):
+        np.testing.assert_allclose(metrics.rte_rre(Tp, Tg, 0.3, 15), ref, rtol=1e-12, atol=1e-12)
+    np.testing.assert_array_equal(metrics.rte_rre(None, g['T_gt'][0], 0.3, 15), g['rte_rre_none'])

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from conftest import rot_angle_deg
-from helpers import assert_refine_parity, rel_err
+from helpers import assert_iteration_matched, assert_refine_parity, rel_err
 from oracle import pipeline as opipe
 from oracle import registration as oreg
 from oracle import resunet as oresunet
@@ -45,7 +45,10 @@ def test_stagewise_matches_oracle(setup):
     from oracle import knn as oknn
     oi1 = oknn.find_knn(oF0, oF1, nn_max_n=250).reshape(-1)
     mism = np.nonzero(i1.cpu().numpy() != oi1)[0]
-    assert len(mism) <= max(2, len(oi1) // 200), len(mism)   # flat synthetic walls produce near-ties
+    if len(mism):   # only genuine rounding ties may differ: both candidates equally near in float64
+        d_a = oknn.knn_sqdist_f64(oF0[mism], oF1, i1.cpu().numpy()[mism])
+        d_b = oknn.knn_sqdist_f64(oF0[mism], oF1, oi1[mism])
+        assert np.all(np.abs(d_a - d_b) <= 2e-6), (len(mism), np.abs(d_a - d_b).max())
     # untrained weights give ~0 % correct matches: override a share with ground-truth matches
     gt = synth.gt_correspondences(op0, op1, T_gt, VOXEL)
     oi1 = np.where(gt >= 0, gt, oi1)
@@ -70,6 +73,8 @@ def test_stagewise_matches_oracle(setup):
                                   quantization_size=2 * VOXEL)
     Ro, to, sto = assert_refine_parity(op0, op1[oi1], ow, R.cpu().numpy(), t.cpu().numpy(), st,
                                        break_threshold_ratio=1e-4, quantization_size=2 * VOXEL)
+    # the same pipeline-shaped input with the iteration count pinned on both sides: 1e-4
+    assert_iteration_matched(op0, op1[oi1], ow, break_threshold_ratio=1e-4, quantization_size=2 * VOXEL)
     # and the estimate is close to the ground truth pose
     assert rot_angle_deg(Ro, T_gt[:3, :3]) < 2.0 and np.linalg.norm(to - T_gt[:3, 3]) < 0.1
 
@@ -114,9 +119,7 @@ def test_fused_batch_matches_stagewise_and_oracle(setup):
     T, status, stats = dgr.register_voxelized(C0, X0, off0, C1, X1, off1, override_idx1=ovr_t,
                                               forced_logits=torch.from_numpy(forced).cuda())
     idx1_b = ops.batch_output('cuda', 'idx1').cpu().numpy()
-    changed = np.nonzero(idx1_b != idx1)[0]       # atomics => a few near-tie matches may flip run to run
-    assert len(changed) <= len(idx1) // 200
-    idx1 = idx1_b                                  # the oracle below sees exactly what the second run saw
+    assert np.array_equal(idx1_b, idx1)            # the search is deterministic (packed-key atomicMin: value, then index)
     logit = ops.batch_output('cuda', 'logit').cpu().numpy()
     F0 = ops.batch_output('cuda', 'F0').reshape(-1, 32).cpu().numpy()
     assert status.tolist() == [0, 0]

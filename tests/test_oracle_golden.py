@@ -66,3 +66,29 @@ def test_ortho6d_matches_reference(golden):
     g = golden('ortho6d')
     R = oreg.rot6d_to_matrix(torch.from_numpy(g['P'])).numpy()
     np.testing.assert_allclose(R, g['R'], atol=1e-7)
+
+
+def test_oracle_batch_knn_matches_reference(golden):
+    """`find_knn_gpu_batch` (core/knn.py:106-140) restated with the oracle's per-pair search."""
+    g = golden('knn_batch')
+    s0 = s1 = 0
+    for a, b in g['len_batch'].tolist():
+        idx = oknn.find_knn(g['F0'][s0:s0 + a], g['F1'][s1:s1 + b], nn_max_n=250).reshape(-1)
+        np.testing.assert_array_equal(idx, g['per_pair'][s0:s0 + a])
+        np.testing.assert_array_equal(idx + s1, g['cat_idx'].reshape(-1)[s0:s0 + a])
+        s0 += a; s1 += b
+
+
+def test_ortho6d_gradient_matches_reference(golden):
+    """autograd of `ortho2rotation` (reference) vs the oracle's `rot6d_to_matrix` under torch autograd."""
+    import torch
+    g = golden('ortho6d_grad')
+    P = torch.from_numpy(g['P']).clone().requires_grad_(True)
+    R = oreg.rot6d_to_matrix(P)
+    (R * torch.from_numpy(g['G'])).sum().backward()
+    np.testing.assert_allclose(R.detach().numpy(), g['R'], atol=1e-6)
+    # rows with a zero vector differentiate sqrt at 0: autograd yields NaN in the reference and in the restatement alike
+    fin = np.isfinite(g['dP']).all(axis=1)
+    assert fin.sum() >= 28 and np.array_equal(np.isnan(P.grad.numpy()), np.isnan(g['dP']))
+    scale = np.maximum(1.0, np.abs(g['dP'][fin]).max(axis=1, keepdims=True))
+    assert (np.abs(P.grad.numpy()[fin] - g['dP'][fin]) / scale).max() < 1e-5
