@@ -4,8 +4,8 @@ surface (core/deep_global_registration.py:67-324), executed on one MI355X by lib
 Scope: steps 0-5 of `register()` -- voxelisation, FCGF features, feature
 matching, 6-D inlier network, confidence gate, weighted Procrustes + robust refinement -- plus the two
 Open3D steps around it, re-implemented on the GPU: the safeguard RANSAC from the
-putative correspondences (:50-64, 302-315) when the gate fails or the SVD does not converge, and the
-final point-to-point ICP (:317-322) when `use_icp` is set (the reference's default, :75).  The
+putative correspondences (:50-64, 302-315) when the confidence gate fails (an SVD failure leaves T = identity,
+exactly like the reference's `except RuntimeError` branch :295-300), and the final point-to-point ICP (:317-322) when `use_icp` is set (the reference's default, :75).  The
 `fcgf_feature_matching` safeguard variant (:31-46) is not implemented.
 """
 import os
@@ -46,6 +46,7 @@ class DeepGlobalRegistration:
         self.reg_timer = Timer()
         self.last_status = None
         self.last_stats = None
+        self.last_icp = None
 
         weights = _cfg_get(config, 'weights')
         if isinstance(weights, (str, os.PathLike)):
@@ -182,9 +183,14 @@ class DeepGlobalRegistration:
                 T[0:3, 0:3] = rot.detach().cpu().numpy()
                 T[0:3, 3] = trans.detach().cpu().numpy()
                 self.last_status, self.last_stats = 'ok', opt_output
-            except RuntimeError:
-                self.last_status = 'svd_failed'   # reference: "Will directly go to Safeguard" (:295-300);
-                # there T simply stays the identity -- the SVD branch never reaches the `else` below
+            except _lib.DgrError as e:
+                # reference (:295-300): `except RuntimeError` around the SVD, "Will directly go to Safeguard" -- there
+                # T simply stays the identity (the SVD branch never reaches the `else` below).  Only the SVD failure
+                # is that case here: a workspace or HIP error is an infrastructure failure and must not be counted
+                # as a registration failure.
+                if e.code != _lib.DGR_ESVD:
+                    raise
+                self.last_status = 'svd_failed'
         else:
             # Case 1 (:302-315): safeguard RANSAC on the putative correspondences
             T = self.safeguard_registration(xyz0, xyz1, corres_idx0, corres_idx1, feats0, feats1,
@@ -236,9 +242,10 @@ class DeepGlobalRegistration:
     def register_voxelized(self, coords0, xyz0, off0, coords1, xyz1, off1, forced_logits=None,
                            skip_refinement=False, override_idx1=None, safeguard=False, icp=False):
         """Fused batched path (one `dgr_register_batch`).  With `safeguard`, pairs that fail the confidence
-        gate (status 1) or the SVD (status 2) are re-estimated by the RANSAC safeguard over their putative
-        correspondences and get status 3; with `icp`, every pair is finally refined by point-to-point ICP
-        -- the two Open3D steps of `register()` (:302-322), run per pair after the batched call."""
+        gate (status 1) are re-estimated by the RANSAC safeguard over their putative correspondences and get
+        status 3 -- like `register()` and the reference, a pair whose SVD failed (status 2) keeps T = identity
+        (:295-300 never reaches the safeguard branch); with `icp`, every pair is finally refined by
+        point-to-point ICP -- the two Open3D steps of `register()` (:302-322), run per pair after the batched call."""
         T, status, stats = ops.register_batch(
             self.fcgf_model._handle(), self.inlier_model._handle(), coords0, xyz0, off0, coords1, xyz1, off1,
             self.voxel_size, clip_weight_thresh=self.clip_weight_thresh,
@@ -247,12 +254,12 @@ class DeepGlobalRegistration:
         T = T.astype(np.float64)
         if safeguard or icp:
             # the correspondences live in the context's workspace: take them before the next library call
-            idx1 = ops.batch_output(self.device, 'idx1') if safeguard and (status != 0).any() else None
+            idx1 = ops.batch_output(self.device, 'idx1') if safeguard and (status == 1).any() else None
             xyz0 = torch.as_tensor(xyz0).to(self.device).float()
             xyz1 = torch.as_tensor(xyz1).to(self.device).float()
             for p in range(len(status)):
                 s0, e0, s1, e1 = int(off0[p]), int(off0[p + 1]), int(off1[p]), int(off1[p + 1])
-                if safeguard and status[p] != 0:
+                if safeguard and status[p] == 1:
                     Y = ops.gather_rows3(xyz1, idx1[s0:e0])
                     T[p], _, _, _ = ops.ransac_correspondence(xyz0[s0:e0], Y, 2 * self.voxel_size, 4000000,
                                                               seed=self.ransac_seed)

@@ -799,9 +799,116 @@ __global__ void __launch_bounds__(256)
   if (lane == 0 && pair_count) atomicAdd(pair_count, pairs);
 }
 
+// ------------------------------------------------------------------------------------------
+// The same layer on the matrix cores, for ONE input channel (FCGF: feats = ones [N, 1]): per voxel the layer is a
+// 343-term (ks = 7) dot product per output channel, i.e. out[16 voxels x 32 channels] = G[16 x ks^3] . W[ks^3 x 32]
+// with G[v][k] = x[neighbour k of v] or 0 -- a GEMM whose left operand is gathered from the dense grid.  A wave owns
+// 16 voxels and walks the ks z-slabs of the kernel: lanes = (voxel, y-row) items read their ks consecutive grid cells
+// (+ the hit rows' input values) into a [16 x ks^2] slab of G in LDS, double-buffered per wave (no block barrier),
+// and ceil(ks^2 / 4) x 2 v_mfma_f32_16x16x4_f32 multiply it with the slab's weights.  Zeros of G contribute exactly
+// 0 to the fma chain, so a channel's value is the ascending-k chain over the hits, as in the scalar kernels
+// (one rounding per term instead of two).  Measured (8 clouds, 195 k voxels, 16 M pairs): 280 us vs 667 us scalar.
+// Compact weights wc[k][32] (net.hip); operands are swapped (D = W^T G^T): a lane ends with one voxel and 4
+// consecutive channels per 16-channel block.
+// ------------------------------------------------------------------------------------------
+template <int KS>
+__global__ void __launch_bounds__(256)
+    conv1_grid_mfma(const int32_t *__restrict__ coords, const int32_t *n_dev, const DgrGridMeta *__restrict__ m,
+                    const int32_t *__restrict__ cells, const float *__restrict__ in, int in_ld,
+                    const float *__restrict__ wc, const float *__restrict__ shift, float *__restrict__ out, int out_ld,
+                    int32_t *pair_count) {
+  constexpr int KS2 = KS * KS, HALF = KS / 2;
+  constexpr int RS = (KS2 + 3) / 4 * 4;          // slab length padded to MFMA k-steps
+  constexpr int LDG = RS + 1;
+  constexpr int ITEMS = 16 * KS;                 // (voxel, y-row) items per slab
+  constexpr int ROUNDS = (ITEMS + 63) / 64;
+  __shared__ float G[4][2][16][LDG];
+  __shared__ int4 vc[4][16];
+  if (!m->ok) return;
+  const int n = *n_dev;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t v0 = ((int64_t)blockIdx.x * 4 + wv) * 16;
+  if (v0 >= n) return;
+  if (lane < 16) vc[wv][lane] = v0 + lane < n ? *reinterpret_cast<const int4 *>(coords + (v0 + lane) * 4) : make_int4(-1, 0, 0, 0);
+  // the padding columns stay zero for the whole kernel
+  for (int e = lane; e < 2 * 16 * (LDG - KS2); e += 64) {
+    const int b = e / (16 * (LDG - KS2)), r = (e / (LDG - KS2)) % 16, c = KS2 + e % (LDG - KS2);
+    G[wv][b][r][c] = 0.f;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  int pairs = 0;
+  int hit[ROUNDS][KS];
+  // request the grid cells of slab kz for this lane's items (a deeper pipeline -- cells two slabs ahead, input
+  // values one slab ahead -- measured slower: 333 vs 280 us, register pressure)
+  auto cells_of = [&](int kz) {
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      const int it = lane + 64 * r;
+      const int v = it / KS, ky = it % KS;
+      const int4 c = vc[wv][min(v, 15)];
+      const bool live = it < ITEMS && c.x >= 0;
+      const long long c0 = live ? grid_cell(m, c.x, c.y - HALF, c.z + ky - HALF, c.w + kz - HALF, HALF) : 0;
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx) hit[r][kx] = live ? cells[c0 + kx] : -1;
+    }
+  };
+  // input values of the hits -> slab buffer b
+  auto fill = [&](int b) {
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+      const int it = lane + 64 * r;
+      const int v = it / KS, ky = it % KS;
+      float xv[KS];
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx) xv[kx] = in[(int64_t)max(hit[r][kx], 0) * in_ld];
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx) {
+        pairs += hit[r][kx] >= 0;
+        if (it < ITEMS) G[wv][b][v][kx + KS * ky] = hit[r][kx] >= 0 ? xv[kx] : 0.f;
+      }
+    }
+  };
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  cells_of(0);
+  fill(0);
+  for (int kz = 0; kz < KS; ++kz) {
+    if (kz + 1 < KS) cells_of(kz + 1);          // in flight while this slab is multiplied
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const float *g = &G[wv][kz & 1][lane & 15][lane >> 4];
+    const float *w = wc + ((int64_t)kz * KS2 + (lane >> 4)) * 32 + (lane & 15);
+#pragma unroll
+    for (int s = 0; s < RS / 4; ++s) {
+      const float b = g[4 * s];
+      const int kk = min(4 * s + (lane >> 4), KS2 - 1) - (lane >> 4);   // padded steps read a valid weight (times G = 0)
+      const float a0 = w[kk * 32], a1 = w[kk * 32 + 16];
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[1], 0, 0, 0);
+    }
+    if (kz + 1 < KS) fill((kz + 1) & 1);
+  }
+  const int64_t o = v0 + (lane & 15);
+  if (o < n) {
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb) {
+      f32x4 v = acc[jb];
+      if (shift) v += *reinterpret_cast<const f32x4 *>(shift + 16 * jb + 4 * (lane >> 4));
+      *reinterpret_cast<f32x4 *>(out + o * out_ld + 16 * jb + 4 * (lane >> 4)) = v;
+    }
+  }
+  if (pair_count) {
+    for (int d = 32; d > 0; d >>= 1) pairs += __shfl_down(pairs, d, 64);
+    if (lane == 0) atomicAdd(pair_count, pairs);
+  }
+}
+
 int dgr_conv1_probe(DgrArena &arena, const DgrCoordMap &cm, int ks, const float *in, int in_ld, int cin,
                     const float *w_tiled, const float *shift, float *out, int out_ld, int32_t *pair_count,
-                    hipStream_t stream) {
+                    hipStream_t stream, const float *w_compact, const char **kernel_name) {
   DGR_REQUIRE(cin >= 1 && cin <= 8 && ks % 2 == 1, "conv1 probe: cin=%d ks=%d", cin, ks);
   if (pair_count) DGR_HIP_CHECK(hipMemsetAsync(pair_count, 0, sizeof(int32_t), stream));
   const int32_t *grid_done = nullptr;
@@ -828,10 +935,20 @@ int dgr_conv1_probe(DgrArena &arena, const DgrCoordMap &cm, int ks, const float 
       DGR_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
       resident = (per_cu < 1 ? 1 : per_cu) * (cus < 1 ? 1 : cus);
     }
+    static const bool scalar_conv1 = getenv("DGR_CONV1_SCALAR") != nullptr;   // A/B switch
+    if (cin == 1 && w_compact && (out_ld & 3) == 0 && (ks == 3 || ks == 5 || ks == 7) && !scalar_conv1) {
+      const int wgs = (int)dgr_ceil_div(cm.n_cap, 64);
+      if (ks == 7) conv1_grid_mfma<7><<<wgs, 256, 0, stream>>>(cm.coords, cm.n_dev, meta, cells, in, in_ld, w_compact, shift, out, out_ld, pair_count);
+      else if (ks == 5) conv1_grid_mfma<5><<<wgs, 256, 0, stream>>>(cm.coords, cm.n_dev, meta, cells, in, in_ld, w_compact, shift, out, out_ld, pair_count);
+      else conv1_grid_mfma<3><<<wgs, 256, 0, stream>>>(cm.coords, cm.n_dev, meta, cells, in, in_ld, w_compact, shift, out, out_ld, pair_count);
+      if (kernel_name) *kernel_name = ks == 7 ? "conv1_grid_mfma<7>" : ks == 5 ? "conv1_grid_mfma<5>" : "conv1_grid_mfma<3>";
+    } else {
     int64_t blocks = dgr_ceil_div(cm.n_cap, 8);
     if (blocks > resident) blocks = (int64_t)resident * std::min<int64_t>(4, blocks / resident);
     conv1_grid_kernel<<<(int)blocks, 256, 0, stream>>>(cm.coords, cm.n_dev, meta, cells, ks, in, in_ld, cin, w_tiled, shift,
                                                        out, out_ld, pair_count);
+    if (kernel_name) *kernel_name = "conv1_grid_kernel";
+    }
     DGR_LAUNCH_CHECK();
     grid_done = &meta->ok;
     arena.rewind(mk);   // stream order keeps the grid alive until the kernels above are done

@@ -153,7 +153,7 @@ int dgr_nbr_counts(const DgrNbrTable &t, const int32_t *n_out_dev, int64_t count
 // conv1 fused with its neighbour search (D = 3, Cin <= 8, Cout = 32): no kernel map for the ks^3 offsets
 int dgr_conv1_probe(DgrArena &arena, const DgrCoordMap &cm, int ks, const float *in, int in_ld, int cin,
                     const float *w_tiled, const float *shift, float *out, int out_ld, int32_t *pair_count,
-                    hipStream_t stream);
+                    hipStream_t stream, const float *w_compact = nullptr, const char **kernel_name = nullptr);
 // voxelise helper (coordmap.hip)
 int dgr_unique_rows(DgrArena &arena, const int32_t *keys, int64_t n, int nc, int32_t *first_flag,
                     int32_t *rank, int32_t *n_unique_dev, int32_t **table_out, uint32_t *mask_out,

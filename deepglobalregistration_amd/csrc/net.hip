@@ -28,6 +28,7 @@ struct DgrLayer {
   int K, cin, cout, cin_pad, cout_pad;
   float *w = nullptr;      // device, tiled
   float *w16 = nullptr;    // device, 16x16x4 fragment order (3-D K = 27 layers: output-stationary conv, conv_os.hip)
+  float *wc = nullptr;     // device, compact [K][32] (3-D conv1 with one input channel: conv1_grid_mfma, conv.hip)
   void *wb = nullptr;      // device, three exact bf16 pieces in 32x32x16 fragment order (wide layers, conv_bf3.hip)
   int64_t wb_piece = 0;    // 16-byte units per piece
   float *shift = nullptr;  // device [cout] or nullptr
@@ -186,6 +187,13 @@ static int make_layer(dgr_net *net, const dgr_weight_desc *descs, int nd, const 
     DGR_HIP_CHECK(hipMemcpy(L.w16, t16.data(), t16.size() * sizeof(float), hipMemcpyHostToDevice));
     net->param_bytes += t16.size() * sizeof(float);
   }
+  if (net->D == 3 && name == "conv1" && cin == 1 && cout == 32) {
+    std::vector<float> wc((size_t)K * 32);
+    for (int k = 0; k < K; ++k)
+      for (int c = 0; c < 32; ++c) wc[(size_t)k * 32 + c] = kd->data[(size_t)k * cout + c] * scale[c];
+    DGR_HIP_CHECK(hipMalloc((void **)&L.wc, wc.size() * sizeof(float)));
+    DGR_HIP_CHECK(hipMemcpy(L.wc, wc.data(), wc.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
   if (has_shift) {
     DGR_HIP_CHECK(hipMalloc((void **)&L.shift, cout * sizeof(float)));
     DGR_HIP_CHECK(hipMemcpy(L.shift, shift.data(), cout * sizeof(float), hipMemcpyHostToDevice));
@@ -241,6 +249,7 @@ extern "C" void dgr_net_destroy(dgr_net *net) {
     if (l.w) (void)hipFree(l.w);
     if (l.w16) (void)hipFree(l.w16);
     if (l.wb) (void)hipFree(l.wb);
+    if (l.wc) (void)hipFree(l.wc);
     if (l.shift) (void)hipFree(l.shift);
   }
   delete net;
@@ -443,12 +452,14 @@ int dgr_resunet_forward_impl(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, 
       e0 = ctx->events.next(); e1 = ctx->events.next();
       DGR_HIP_CHECK(hipEventRecord(e0, stream));
     }
-    DGR_CHECK(dgr_conv1_probe(A, ms.cm[0], net->conv1_ks, feats, net->cin, net->cin, L0.w, L0.shift, t1, 32, pc, stream));
+    const char *k1name = "conv1_grid_kernel";
+    DGR_CHECK(dgr_conv1_probe(A, ms.cm[0], net->conv1_ks, feats, net->cin, net->cin, L0.w, L0.shift, t1, 32, pc, stream,
+                              L0.wc, &k1name));
     if (f.prof) {
       DGR_HIP_CHECK(hipEventRecord(e1, stream));
       ctx->conv_spans.push_back({e0, e1});
       ctx->gemm_spans.push_back({e0, e1});
-      ctx->conv_kinds.push_back("conv1_grid_kernel");
+      ctx->conv_kinds.push_back(k1name);
     }
     LayerRun &r0 = net->runs[0];
     r0 = LayerRun();

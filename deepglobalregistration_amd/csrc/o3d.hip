@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(ICP_THREADS)
     icp_bbox_kernel(const float *__restrict__ dst, int64_t n, IcpState *st) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
-  if (i < n)
+  if (i < n && isfinite(dst[i * 3] + dst[i * 3 + 1] + dst[i * 3 + 2]))   // non-finite target points take no part
     for (int d = 0; d < 3; ++d) lo[d] = hi[d] = ord_f32(dst[i * 3 + d]);
   for (int s = 32; s >= 1; s >>= 1)
     for (int d = 0; d < 3; ++d) {
@@ -109,14 +109,14 @@ __device__ __forceinline__ int icp_cell_of(const IcpState *st, double x, double 
 
 __global__ void icp_count_kernel(const float *__restrict__ dst, int64_t n, const IcpState *st, int32_t *counts) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  if (i >= n || !isfinite(dst[i * 3] + dst[i * 3 + 1] + dst[i * 3 + 2])) return;
   atomicAdd(&counts[icp_cell_of(st, dst[i * 3], dst[i * 3 + 1], dst[i * 3 + 2])], 1);
 }
 
 __global__ void icp_fill_kernel(const float *__restrict__ dst, int64_t n, const IcpState *st,
                                 const int32_t *__restrict__ starts, int32_t *cursor, double *__restrict__ sorted) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  if (i >= n || !isfinite(dst[i * 3] + dst[i * 3 + 1] + dst[i * 3 + 2])) return;
   const int c = icp_cell_of(st, dst[i * 3], dst[i * 3 + 1], dst[i * 3 + 2]);
   const int pos = starts[c] + atomicAdd(&cursor[c], 1);
   for (int d = 0; d < 3; ++d) sorted[(int64_t)pos * 3 + d] = (double)dst[i * 3 + d];
@@ -276,14 +276,19 @@ extern "C" int dgr_icp_point_to_point(dgr_ctx *ctx, const float *src, int64_t N0
   double Ti[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   if (T_init) memcpy(Ti, T_init, sizeof(Ti));
   DGR_HIP_CHECK(hipMemcpyAsync(Tdev, Ti, sizeof(Ti), hipMemcpyHostToDevice, stream));
-  DGR_HIP_CHECK(hipStreamSynchronize(stream));   // Ti is a stack buffer
   icp_init_kernel<<<1, 64, 0, stream>>>(st, Tdev);
   icp_bbox_kernel<<<(int)dgr_ceil_div(N1, ICP_THREADS), ICP_THREADS, 0, stream>>>(dst, N1, st);
   icp_layout_kernel<<<1, 64, 0, stream>>>(st, max_dist, CELL_CAP);
-  DGR_HIP_CHECK(hipMemsetAsync(counts, 0, (size_t)(CELL_CAP + 1) * sizeof(int32_t), stream));
-  DGR_HIP_CHECK(hipMemsetAsync(cursor, 0, (size_t)(CELL_CAP + 1) * sizeof(int32_t), stream));
+  // one host round trip (the stack buffer Ti needs one anyway): the actual cell count bounds the clears and the scan
+  // below -- a 3DMatch fragment at 10 cm cells has ~10^5 cells, not the 4 M of the budget
+  int32_t ncell = 0;
+  DGR_HIP_CHECK(hipMemcpyAsync(&ncell, &st->ncell, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  DGR_HIP_CHECK(hipStreamSynchronize(stream));
+  DGR_REQUIRE(ncell >= 1 && ncell <= CELL_CAP, "ICP: target grid of %d cells (non-finite or empty target cloud?)", ncell);
+  DGR_HIP_CHECK(hipMemsetAsync(counts, 0, (size_t)(ncell + 1) * sizeof(int32_t), stream));
+  DGR_HIP_CHECK(hipMemsetAsync(cursor, 0, (size_t)(ncell + 1) * sizeof(int32_t), stream));
   icp_count_kernel<<<(int)dgr_ceil_div(N1, 256), 256, 0, stream>>>(dst, N1, st, counts);
-  DGR_CHECK(dgr_exclusive_scan_i32(A, counts, starts, CELL_CAP + 1, nullptr, stream));
+  DGR_CHECK(dgr_exclusive_scan_i32(A, counts, starts, (int64_t)ncell + 1, nullptr, stream));
   icp_fill_kernel<<<(int)dgr_ceil_div(N1, 256), 256, 0, stream>>>(dst, N1, st, starts, cursor, sorted);
   icp_transform_init_kernel<<<(int)dgr_ceil_div(N0, 256), 256, 0, stream>>>(src, N0, st, P);
   DGR_LAUNCH_CHECK();

@@ -29,10 +29,15 @@ def main():
     if args.kitti_dir:
         from .. import ops
 
-        def refine(src, dst, init):   # kitti_loader.py:139-158: 5 cm voxels, 0.2 m, 200 iterations
-            s5, _, _ = ops.voxelize(src, 0.05)
-            d5, _, _ = ops.voxelize(dst, 0.05)
-            return ops.icp_point_to_point(s5, d5, 0.2, init=init, max_iter=200)[0]
+        def refine(xyz0, xyz1, M):   # kitti_loader.py:139-158
+            # the reference selects the 5 cm subsample of cloud 0 BEFORE moving it (sparse_quantize(xyz0 / 0.05) on the
+            # untransformed scan, :142), applies M to the selected points (:147) and runs ICP from the identity with
+            # max distance 0.2 m and 200 iterations (:150-152)
+            s5, _, _ = ops.voxelize(xyz0, 0.05)
+            d5, _, _ = ops.voxelize(xyz1, 0.05)
+            Mt = torch.as_tensor(M, dtype=torch.float32, device=s5.device)
+            s5 = s5 @ Mt[:3, :3].T + Mt[:3, 3]
+            return ops.icp_point_to_point(s5, d5, 0.2, init=np.eye(4), max_iter=200)[0]
         ds = KITTIOdometryPairs(args.kitti_dir, args.drives, icp_refine=None if args.no_gt_icp else refine)
         stats, _ = evaluate_kitti(dgr, ds)
         np.savez('kitti-stats_DeepGlobalRegistration.npz' if args.out.startswith('3dmatch') else args.out, stats=stats)

@@ -32,8 +32,10 @@ class KITTIOdometryPairs:
     MIN_DIST = 10.0
 
     def __init__(self, root, drives, min_dist=None, icp_refine=None, exclude=((8, 15, 58),)):
-        """`icp_refine(src_xyz, dst_xyz, init) -> T` (e.g. a wrapper of ops.icp_point_to_point on 5 cm voxels with
-        max distance 0.2 and 200 iterations, like :152-154) or None for the raw odometry ground truth."""
+        """`icp_refine(xyz0, xyz1, M) -> reg` gets the UNTRANSFORMED scans and the odometry pose M; it is expected to
+        do what kitti_loader.py:139-154 does -- subsample both at 5 cm, move the selected points of cloud 0 by M,
+        run ICP from the identity (max distance 0.2, 200 iterations) and return the ICP transformation -- or None
+        for the raw odometry ground truth."""
         self.root = root
         self.min_dist = self.MIN_DIST if min_dist is None else float(min_dist)
         self.icp_refine = icp_refine
@@ -73,8 +75,8 @@ class KITTIOdometryPairs:
         xyz0, xyz1 = self.scan(drive, t0), self.scan(drive, t1)
         M = relative_velodyne_pose(self.poses[drive][t0], self.poses[drive][t1])
         if self.icp_refine is not None:
-            # the reference moves cloud 0 by M, runs ICP from the identity and stores M @ reg (:147-158)
-            reg = self.icp_refine(xyz0 @ M[:3, :3].T + M[:3, 3], xyz1, np.eye(4))
+            # the reference subsamples cloud 0, moves it by M, runs ICP from the identity and stores M @ reg (:142-158)
+            reg = self.icp_refine(xyz0, xyz1, M)
             M = M @ reg
         return drive, xyz0, xyz1, M
 

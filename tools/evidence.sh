@@ -1,21 +1,35 @@
 #!/bin/bash
-# Round evidence bundle, run on the GPU box from the repo root: bench lines, rocprofv3 kernel stats and the
-# PMC HBM-traffic passes.  Everything lands in gpurun_out/final/ (copy what should be judged into profiles/).
-R=$PWD; O=$R/gpurun_out/final; mkdir -p $O; rm -f $O/*
+# Round evidence bundle, run on the GPU box from the repo root: bench lines (configs[1], [2], [4], the 512-pair
+# configs[3] shape on one GPU), rocprofv3 kernel stats and the PMC passes of the dominant kernel.  Everything lands
+# in gpurun_out/final/ (copy what should be judged into profiles/).   bash tools/evidence.sh [quick]
+R=$PWD; O=$R/gpurun_out/final; mkdir -p $O; rm -rf $O/*
 cd /tmp && export TMPDIR=/tmp
-timeout 600 python $R/bench.py > $O/bench_default_3x4.json 2> $O/bench_default.err
-timeout 300 python $R/bench.py --streams 1 --pairs-per-step 1 --no-cpu-baseline > $O/bench_s1_b1.json 2> $O/bench_s1_b1.err
-timeout 300 rocprofv3 --kernel-trace -d $O/kt -o kt -- python $R/bench.py --no-cpu-baseline --steps 5 > $O/kt.log 2>&1
-python $R/tools/rocpd_summary.py $O/kt/kt_results.db $O/kernel_stats.csv --trace sparse_conv $O/conv_trace.csv
-# the roofline leg of bench.py is a single-stream re-run (4 pairs per batch): the same command with one stream gives
-# kernel durations free of time-slicing, comparable with roofline.dominant_kernel.avg_launch_us
-timeout 300 python $R/bench.py --streams 1 --pairs-per-step 4 --no-cpu-baseline > $O/bench_s1_b4.json 2> $O/bench_s1_b4.err
-timeout 300 rocprofv3 --kernel-trace -d $O/kt1 -o kt -- python $R/bench.py --streams 1 --pairs-per-step 4 --no-cpu-baseline --steps 5 > $O/kt1.log 2>&1
-python $R/tools/rocpd_summary.py $O/kt1/kt_results.db $O/kernel_stats_s1_b4.csv
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "sparse_conv|reduce_rows|conv_small|conv1_" -d $O/p_$c -o p -- \
-    python $R/bench.py --streams 1 --pairs-per-step 4 --steps 2 --warmup 1 --no-cpu-baseline > $O/p_$c.log 2>&1
+B="python $R/bench.py"
+timeout 900 $B > $O/bench_c1_default.json 2> $O/bench_c1_default.err
+timeout 300 $B --streams 1 --pairs-per-step 4 --no-parity > $O/bench_c1_s1_b4.json 2> $O/bench_c1_s1_b4.err
+timeout 300 $B --streams 1 --pairs-per-step 1 --no-parity > $O/bench_c1_s1_b1.json 2> $O/bench_c1_s1_b1.err
+timeout 600 $B --kind outdoor --n-raw 120000 --voxel 0.3 --conv1-ks 5 > $O/bench_c3.json 2> $O/bench_c3.err
+timeout 600 $B --n-raw 200000 --voxel 0.025 --pairs-per-step 1 --no-parity > $O/bench_c5.json 2> $O/bench_c5.err
+timeout 600 $B --n-raw 200000 --voxel 0.025 --pairs-per-step 1 --no-parity --no-refine > $O/bench_c5_norefine.json 2> $O/bench_c5_norefine.err
+if [ "$1" != quick ]; then
+  timeout 900 $B --total-pairs 512 --steps 2 --warmup 1 --no-parity > $O/bench_c4shape_512pairs_1gpu.json 2> $O/bench_c4shape.err
+  timeout 300 $B --from-host --no-parity > $O/bench_c1_from_host.json 2> $O/bench_c1_from_host.err
+fi
+# kernel stats: the single-stream command gives durations free of time-slicing (comparable with roofline.avg_launch_us)
+timeout 300 rocprofv3 --kernel-trace -d $O/kt1 -o kt -- $B --streams 1 --pairs-per-step 4 --no-parity --steps 5 > $O/kt1.log 2>&1
+python $R/tools/rocpd_summary.py $O/kt1/kt_results.db $O/kernel_stats_s1_b4.csv --trace sparse_conv $O/conv_trace_s1_b4.csv
+timeout 300 rocprofv3 --kernel-trace -d $O/kt3 -o kt -- $B --no-parity --steps 5 > $O/kt3.log 2>&1
+python $R/tools/rocpd_summary.py $O/kt3/kt_results.db $O/kernel_stats_s3_b4.csv
+# PMC: one pass per counter set, never combined with other trace domains
+K=$(python -c "import json;print(json.loads(open('$O/bench_c1_s1_b4.json').read().strip().splitlines()[-1])['roofline']['kernel'])")
+i=0; DBS=""
+for set in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVES" "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --kernel-trace --pmc $set -d $O/pmc -o p$i -- $B --streams 1 --pairs-per-step 4 --steps 2 --warmup 1 --no-parity > $O/pmc_$i.log 2>&1
+  DBS="$DBS $O/pmc/p${i}_results.db"
 done
-python $R/tools/pmc_traffic.py $O/p_FETCH_SIZE/p_results.db $O/p_WRITE_SIZE/p_results.db > $O/conv_hbm_traffic.json
-rm -rf $O/kt $O/kt1 $O/p_FETCH_SIZE $O/p_WRITE_SIZE
-ls -la $O; tail -c 600 $O/bench_default_3x4.json
+python $R/tools/pmc_dominant.py "$K" "BASELINE configs[1]" $DBS > $O/dominant_pmc.json
+python $R/tools/pmc_dominant.py "sparse_conv_os<64, 64" "BASELINE configs[1]" $DBS > $O/os_conv_pmc.json
+python $R/tools/pmc_dominant.py "reduce_rows_kernel<64>" "BASELINE configs[1]" $DBS > $O/reduce_rows_pmc.json
+rm -rf $O/kt1 $O/kt3 $O/pmc
+ls -la $O; tail -c 400 $O/bench_c1_default.json
