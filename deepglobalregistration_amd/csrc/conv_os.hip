@@ -22,17 +22,23 @@
 // Weight layout (net.hip, per layer): W16[k][g][jb][lane][c] = W_folded[k][16 g + 4 (lane >> 4) + c][16 jb + (lane & 15)]
 // (g = Cin_pad/16 groups, jb = Cout/16 channel blocks): one coalesced 16-byte load per lane = the A
 // operands of 4 consecutive MFMAs.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "dgr_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct ConvOsArgs {
   const float *in;
   float *out;
   const float *w16, *shift, *res;
+  const uint4 *wb3;        // BF3: three exact bf16 pieces, each [27][CP/32][cout/16][64] x 16 bytes
+  int64_t piece_stride;    // 16-byte units per piece
   const int32_t *nbr, *n_out_dev;
   int64_t n_pad;
   int in_ld, in_relu, out_ld, out_relu, res_ld, res_relu;
@@ -41,7 +47,10 @@ struct ConvOsArgs {
 
 // CP = input channels (multiple of 32), CS = output-channel slice of a workgroup (32 | 64), MB = output rows
 // per workgroup (16 | 32 | 64), CK = input channels per pipeline phase (32 | 64), TM = pair slots per tile (32 | 64)
-template <int CP, int CS, int MB, int CK, int TM>
+// BF3: the products run on the bf16 matrix pipe with every f32 operand split exactly into three bf16 pieces (six
+// v_mfma_f32_16x16x32_bf16 per 32 input channels instead of eight v_mfma_f32_16x16x4_f32: 2.67x fewer matrix
+// cycles, f32-level error -- see conv_bf3.hip); false = exact-f32 MFMA (DGR_OS_F32=1, A/B measurements)
+template <int CP, int CS, int MB, int CK, int TM, bool BF3>
 __global__ void __launch_bounds__(CS * 4) sparse_conv_os(ConvOsArgs a) {
   constexpr int NW = CS / 16;            // waves: one 16-channel block each
   constexpr int THREADS = 64 * NW;
@@ -56,7 +65,13 @@ __global__ void __launch_bounds__(CS * 4) sparse_conv_os(ConvOsArgs a) {
   constexpr int KPW = (KV + NW - 1) / NW;   // offsets compacted per wave
   constexpr int NGMAX = KV * (MB / 16);
   static_assert(TM * C4K % THREADS == 0 && CP % CK == 0, "shape");
-  __shared__ __attribute__((aligned(16))) float As[2][TM][LDA];
+  constexpr int LDP = CK + 8;                 // BF3: bf16 elements per plane row
+  constexpr int PLANE = TM * LDP;             // bf16 elements per plane
+  constexpr int G32 = CK / 32;                // BF3: 32-channel k-steps per phase
+  constexpr int ABYTES = BF3 ? 2 * 3 * PLANE * 2 : 2 * TM * LDA * 4;
+  __shared__ __attribute__((aligned(16))) char abuf[ABYTES];   // f32: As[2][TM][LDA]; BF3: planes [2][3][TM][LDP] bf16
+  float (*As)[TM][LDA] = reinterpret_cast<float (*)[TM][LDA]>(abuf);
+  unsigned short *Ps = reinterpret_cast<unsigned short *>(abuf);
   __shared__ __attribute__((aligned(16))) float acc_s[MB][LDC];
   __shared__ int in_idx[KV][MB];
   __shared__ unsigned char out_loc[KV][MB];
@@ -157,47 +172,84 @@ __global__ void __launch_bounds__(CS * 4) sparse_conv_os(ConvOsArgs a) {
   // canonicalising second instruction as with fmaxf on freshly loaded data)
   const int relu_lo = a.in_relu ? 0 : (int)0x80000000;
   auto land = [&](int q) {
-    float *dst = &As[q & 1][0][0];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int ch = tid + i * THREADS;
       i32x4 v = __builtin_bit_cast(i32x4, Gr[i]);
       v.x = max(v.x, relu_lo); v.y = max(v.y, relu_lo); v.z = max(v.z, relu_lo); v.w = max(v.w, relu_lo);
-      *reinterpret_cast<i32x4 *>(dst + (ch / C4K) * LDA + (ch % C4K) * 4) = v;
+      if constexpr (!BF3) {
+        *reinterpret_cast<i32x4 *>(&As[q & 1][0][0] + (ch / C4K) * LDA + (ch % C4K) * 4) = v;
+      } else {
+        // x = h + m + l exactly (8 + 8 + 8 significant bits by truncation), three bf16 planes
+        uint32_t h[4], m[4], l[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int vi = v[u];   // (bit_cast straight from a vector ELEMENT reads element 0)
+          const float x = __builtin_bit_cast(float, vi);
+          h[u] = (uint32_t)vi & 0xffff0000u;
+          const float r1 = x - __builtin_bit_cast(float, h[u]);
+          m[u] = __builtin_bit_cast(uint32_t, r1) & 0xffff0000u;
+          l[u] = __builtin_bit_cast(uint32_t, r1 - __builtin_bit_cast(float, m[u]));
+        }
+        unsigned short *dst = Ps + (q & 1) * 3 * PLANE + (ch / C4K) * LDP + (ch % C4K) * 4;
+        *reinterpret_cast<u32x2 *>(dst) = u32x2{(h[0] >> 16) | h[1], (h[2] >> 16) | h[3]};
+        *reinterpret_cast<u32x2 *>(dst + PLANE) = u32x2{(m[0] >> 16) | m[1], (m[2] >> 16) | m[3]};
+        *reinterpret_cast<u32x2 *>(dst + 2 * PLANE) = u32x2{(l[0] >> 16) | (l[1] & 0xffff0000u), (l[2] >> 16) | (l[3] & 0xffff0000u)};
+      }
     }
   };
-  // A operands (weights) of step s = GP q + rb (group rb of phase q): G coalesced 16-byte loads per lane,
-  // straight from L2 (a layer's 27 slices are at most 7 MB and shared by every workgroup)
+  // A operands (weights) of step s = GP q + rb (group rb of phase q): coalesced 16-byte loads per lane, straight
+  // from L2 (a layer's 27 slices are at most 7 MB and shared by every workgroup)
   const int jb = slice * NW + wave;
-  const f32x4 *wbase = reinterpret_cast<const f32x4 *>(a.w16) + (int64_t)jb * 64 + lane;
-  auto wstep = [&](int s, f32x4 *w) {
+  constexpr int WREGS = BF3 ? 3 * G32 : G;     // 16-byte operand registers per group
+  struct WSet { uint4 v[WREGS]; };
+  auto wstep = [&](int s, WSet &w) {
     const int q = min(s / GP, NQ - 1);
     const int k = __builtin_amdgcn_readfirstlane(grp[GP * (q / PPT) + (s % GP)]) & 255;
-    const f32x4 *p = wbase + (int64_t)(k * GT + (q % PPT) * G) * a.nb16 * 64;
+    if constexpr (!BF3) {
+      const uint4 *p = reinterpret_cast<const uint4 *>(a.w16) + (int64_t)jb * 64 + lane + (int64_t)(k * GT + (q % PPT) * G) * a.nb16 * 64;
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-#ifdef DGR_OS_ABL_NOW
-      w[g] = f32x4{(float)k, 1.f, 2.f, 3.f};
-#else
-      w[g] = p[(int64_t)g * a.nb16 * 64];
-#endif
+      for (int g = 0; g < G; ++g) w.v[g] = p[(int64_t)g * a.nb16 * 64];
+    } else {
+      const uint4 *p = a.wb3 + (int64_t)jb * 64 + lane + (int64_t)(k * (CP / 32) + (q % PPT) * G32) * a.nb16 * 64;
+#pragma unroll
+      for (int g = 0; g < G32; ++g)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) w.v[3 * g + pc] = p[(int64_t)pc * a.piece_stride + (int64_t)g * a.nb16 * 64];
     }
   };
 
   f32x4 acc[GP];
-  f32x4 w[GP][G];   // weights of the tile's four groups; each set is re-requested for the NEXT phase right after its use
-  // one 16-row group: 4 G MFMAs on its accumulator
-  auto mfma_group = [&](int rb, const float *arow) {
-#ifndef DGR_OS_ABL_NOMFMA
+  WSet w[GP];   // weights of the tile's groups; each set is re-requested for the NEXT phase right after its use
+  // one 16-row group on its accumulator
+  auto mfma_group = [&](int rb, int buf) {
+    if constexpr (!BF3) {
+      const float *arow = &As[buf][lane & 15][4 * (lane >> 4)];
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-      const f32x4 av = *reinterpret_cast<const f32x4 *>(arow + rb * 16 * LDA + g * 16);
+      for (int g = 0; g < G; ++g) {
+        const f32x4 av = *reinterpret_cast<const f32x4 *>(arow + rb * 16 * LDA + g * 16);
+        const f32x4 wv = __builtin_bit_cast(f32x4, w[rb].v[g]);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[rb][g][c], av[c], acc[rb], 0, 0, 0);
+        for (int c = 0; c < 4; ++c) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c], av[c], acc[rb], 0, 0, 0);
+      }
+    } else {
+      const unsigned short *prow = Ps + buf * 3 * PLANE + (rb * 16 + (lane & 15)) * LDP + 8 * (lane >> 4);
+#pragma unroll
+      for (int g = 0; g < G32; ++g) {
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(prow + 32 * g));
+        const bf16x8 am = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(prow + PLANE + 32 * g));
+        const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(prow + 2 * PLANE + 32 * g));
+        const bf16x8 wh = __builtin_bit_cast(bf16x8, w[rb].v[3 * g]), wm = __builtin_bit_cast(bf16x8, w[rb].v[3 * g + 1]),
+                     wl = __builtin_bit_cast(bf16x8, w[rb].v[3 * g + 2]);
+        // six products, small terms first
+        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah, acc[rb], 0, 0, 0);
+        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, al, acc[rb], 0, 0, 0);
+        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, am, acc[rb], 0, 0, 0);
+        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, ah, acc[rb], 0, 0, 0);
+        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, am, acc[rb], 0, 0, 0);
+        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah, acc[rb], 0, 0, 0);
+      }
     }
-#else
-    acc[rb] += *reinterpret_cast<const f32x4 *>(arow + rb * 16 * LDA) + w[rb][0];
-#endif
   };
   if (NQ > 0) {
     gather(0);
@@ -219,13 +271,12 @@ __global__ void __launch_bounds__(CS * 4) sparse_conv_os(ConvOsArgs a) {
       for (int rb = 0; rb < GP; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const int live = min(GP, NG - GP * t);   // groups of this tile (wave-uniform)
-    const float *arow = &As[q & 1][lane & 15][4 * (lane >> 4)];
     // a group's weights were requested a whole phase ago (right after their previous use): the other groups'
     // MFMAs, the barrier and the next landing cover the L2 latency
 #pragma unroll
     for (int rb = 0; rb < GP; ++rb) {
       __builtin_amdgcn_sched_barrier(0);
-      if (rb == 0 || live > rb) mfma_group(rb, arow);
+      if (rb == 0 || live > rb) mfma_group(rb, q & 1);
       wstep(GP * (q + 1) + rb, w[rb]);
     }
     if (PPT == 1 || h == PPT - 1) {
@@ -265,7 +316,10 @@ static int launch_os(const ConvOsArgs &ka, int64_t n_out_cap, hipStream_t stream
   int64_t blocks = dgr_ceil_div(n_out_cap, MB);
   blocks = (blocks + 7) / 8 * 8;
   dim3 grid((unsigned)blocks, (unsigned)(ka.cout / CS));
-  sparse_conv_os<CP, CS, MB, CK, TM><<<grid, CS * 4, 0, stream>>>(ka);
+  if (ka.wb3)
+    sparse_conv_os<CP, CS, MB, CK, TM, true><<<grid, CS * 4, 0, stream>>>(ka);
+  else
+    sparse_conv_os<CP, CS, MB, CK, TM, false><<<grid, CS * 4, 0, stream>>>(ka);
   DGR_LAUNCH_CHECK();
   return DGR_OK;
 }
@@ -278,7 +332,10 @@ int dgr_conv_os_launch(const DgrConvOsLaunch &a, hipStream_t stream, const char 
               a.cin, a.cout);
   DGR_REQUIRE(a.n_out_cap * (int64_t)a.in_ld < (1ll << 32) / 4 * 4, "output-stationary conv: input tensor beyond 32-bit element offsets");
   ConvOsArgs ka;
+  static const bool os_f32 = getenv("DGR_OS_F32") != nullptr;
   ka.in = a.in; ka.out = a.out; ka.w16 = a.w16; ka.shift = a.shift; ka.res = a.res;
+  ka.wb3 = os_f32 ? nullptr : static_cast<const uint4 *>(a.wb3);
+  ka.piece_stride = a.piece_stride;
   ka.nbr = a.nbr->nbr; ka.n_out_dev = a.n_out_dev; ka.n_pad = a.nbr->n_pad;
   ka.in_ld = a.in_ld; ka.in_relu = a.in_relu; ka.out_ld = a.out_ld; ka.out_relu = a.out_relu;
   ka.res_ld = a.res_ld; ka.res_relu = a.res_relu;
@@ -294,7 +351,8 @@ int dgr_conv_os_launch(const DgrConvOsLaunch &a, hipStream_t stream, const char 
 #define DGR_OS(CPV, CSV, MBV, CKV)                                                                      \
   do {                                                                                                  \
     constexpr int tm = (MBV) < DGR_OS_TM ? ((MBV) < 32 ? 32 : (MBV)) : DGR_OS_TM;                       \
-    if (kernel_name) *kernel_name = "sparse_conv_os<" #CPV ", " #CSV ", " DGR_STR(MBV) ", " DGR_STR(CKV) ">"; \
+    if (kernel_name) *kernel_name = ka.wb3 ? "sparse_conv_os<" #CPV ", " #CSV ", " DGR_STR(MBV) ", " DGR_STR(CKV) ", bf16x3>"  \
+                                           : "sparse_conv_os<" #CPV ", " #CSV ", " DGR_STR(MBV) ", " DGR_STR(CKV) ", f32>"; \
     return launch_os<CPV, CSV, MBV, CKV, tm>(ka, a.n_out_cap, stream);                                  \
   } while (0)
   // rows per workgroup by level: the coarse levels have few rows (1/3, 1/12, 1/60 of the input on

@@ -199,6 +199,7 @@ struct DgrConvOsLaunch {
   const float *in; int in_ld, in_relu;
   float *out; int out_ld, out_relu;
   const float *w16, *shift;
+  const void *wb3; int64_t piece_stride;   // three exact bf16 pieces of the weights (16-byte units per piece), or null
   const float *res; int res_ld, res_relu;
   int rows_per_block;   // 64 | 32 | 16 output rows per workgroup
   const DgrNbrTable *nbr;

@@ -28,6 +28,8 @@ struct DgrLayer {
   int K, cin, cout, cin_pad, cout_pad;
   float *w = nullptr;      // device, tiled
   float *w16 = nullptr;    // device, 16x16x4 fragment order (3-D K = 27 layers: output-stationary conv, conv_os.hip)
+  void *w16b = nullptr;    // device, the same as three exact bf16 pieces in 16x16x32 fragment order (conv_os.hip, BF3)
+  int64_t w16b_piece = 0;
   float *wc = nullptr;     // device, compact [K][32] (3-D conv1 with one input channel: conv1_grid_mfma, conv.hip)
   void *wb = nullptr;      // device, three exact bf16 pieces in 32x32x16 fragment order (wide layers, conv_bf3.hip)
   int64_t wb_piece = 0;    // 16-byte units per piece
@@ -186,6 +188,35 @@ static int make_layer(dgr_net *net, const dgr_weight_desc *descs, int nd, const 
     DGR_HIP_CHECK(hipMalloc((void **)&L.w16, t16.size() * sizeof(float)));
     DGR_HIP_CHECK(hipMemcpy(L.w16, t16.data(), t16.size() * sizeof(float), hipMemcpyHostToDevice));
     net->param_bytes += t16.size() * sizeof(float);
+    if (cin % 32 == 0) {
+      // WB[piece][k][s][jb][lane] = 8 bf16 = piece of W[k][32 s + 8 (lane >> 4) + e][16 jb + (lane & 15)]
+      const int S32 = cin / 32;
+      L.w16b_piece = (int64_t)K * S32 * NB * 64;
+      std::vector<uint16_t> pcs((size_t)3 * L.w16b_piece * 8);
+      auto top16 = [](float x) { uint32_t b; memcpy(&b, &x, 4); return b & 0xffff0000u; };
+      auto asf = [](uint32_t b) { float x; memcpy(&x, &b, 4); return x; };
+      for (int k = 0; k < K; ++k) {
+        const float *src = kd->data + (size_t)k * cin * cout;
+        for (int sI = 0; sI < S32; ++sI)
+          for (int jb = 0; jb < NB; ++jb)
+            for (int lane = 0; lane < 64; ++lane) {
+              const int col = 16 * jb + (lane & 15);
+              const size_t o = ((((size_t)k * S32 + sI) * NB + jb) * 64 + lane) * 8;
+              for (int e = 0; e < 8; ++e) {
+                const float x = src[(size_t)(32 * sI + 8 * (lane >> 4) + e) * cout + col] * scale[col];
+                const uint32_t h = top16(x);
+                const float r1 = x - asf(h);
+                const uint32_t m = top16(r1);
+                pcs[o + e] = (uint16_t)(h >> 16);
+                pcs[(size_t)L.w16b_piece * 8 + o + e] = (uint16_t)(m >> 16);
+                pcs[(size_t)2 * L.w16b_piece * 8 + o + e] = (uint16_t)(top16(r1 - asf(m)) >> 16);
+              }
+            }
+      }
+      DGR_HIP_CHECK(hipMalloc(&L.w16b, pcs.size() * sizeof(uint16_t)));
+      DGR_HIP_CHECK(hipMemcpy(L.w16b, pcs.data(), pcs.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+      net->param_bytes += pcs.size() * sizeof(uint16_t);
+    }
   }
   if (net->D == 3 && name == "conv1" && cin == 1 && cout == 32) {
     std::vector<float> wc((size_t)K * 32);
@@ -250,6 +281,7 @@ extern "C" void dgr_net_destroy(dgr_net *net) {
     if (l.w16) (void)hipFree(l.w16);
     if (l.wb) (void)hipFree(l.wb);
     if (l.wc) (void)hipFree(l.wc);
+    if (l.w16b) (void)hipFree(l.w16b);
     if (l.shift) (void)hipFree(l.shift);
   }
   delete net;
@@ -324,6 +356,7 @@ struct Fwd {
       o.out = out.ptr; o.out_ld = out.ld; o.out_relu = out.relu;
       o.rows_per_block = lvl_out <= 1 ? 64 : lvl_out == 2 ? 32 : 16;
       o.w16 = L.w16; o.shift = L.shift;
+      o.wb3 = L.w16b; o.piece_stride = L.w16b_piece;
       o.res = res ? res->ptr : nullptr; o.res_ld = res ? res->ld : 0; o.res_relu = res ? res->relu : 0;
       o.nbr = t; o.n_out_dev = cout_map.n_dev; o.n_out_cap = cout_map.n_cap;
       o.cin = L.cin; o.cin_pad = L.cin_pad; o.cout = L.cout;
