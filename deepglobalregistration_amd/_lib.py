@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DGR_HIP_LIB') or os.path.join(_HERE, 'lib', 'libdgr_hip.so')  # override: experiments only
 
 DGR_OK, DGR_EINVAL, DGR_EHIP, DGR_ENOMEM, DGR_ESVD, DGR_EINTERNAL = 0, -1, -2, -3, -4, -5
-STATUS_OK, STATUS_LOW_CONFIDENCE, STATUS_SVD_FAILED = 0, 1, 2
+STATUS_OK, STATUS_LOW_CONFIDENCE, STATUS_SVD_FAILED, STATUS_SAFEGUARD = 0, 1, 2, 3
 
 c_i32p, c_i64p, c_f32p, c_f64p = (C.POINTER(C.c_int32), C.POINTER(C.c_int64),
                                   C.POINTER(C.c_float), C.POINTER(C.c_double))
@@ -30,7 +30,8 @@ class Params(C.Structure):
     _fields_ = [('clip_weight_thresh', C.c_float), ('voxel_size', C.c_float),
                 ('inlier_feature_type', C.c_int), ('max_iter', C.c_int),
                 ('max_break_count', C.c_int), ('break_threshold_ratio', C.c_double),
-                ('skip_refinement', C.c_int)]
+                ('skip_refinement', C.c_int), ('safeguard', C.c_int), ('ransac_hypotheses', C.c_int64),
+                ('ransac_seed', C.c_uint32), ('use_icp', C.c_int)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/dgr_hip.h

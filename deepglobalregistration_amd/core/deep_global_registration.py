@@ -250,20 +250,7 @@ class DeepGlobalRegistration:
             self.fcgf_model._handle(), self.inlier_model._handle(), coords0, xyz0, off0, coords1, xyz1, off1,
             self.voxel_size, clip_weight_thresh=self.clip_weight_thresh,
             inlier_feature_type=self.inlier_feature_type, break_threshold_ratio=1e-4,
-            skip_refinement=skip_refinement, forced_logit=forced_logits, override_idx1=override_idx1)
+            skip_refinement=skip_refinement, forced_logit=forced_logits, override_idx1=override_idx1,
+            safeguard=safeguard, use_icp=icp, ransac_seed=self.ransac_seed)
         T = T.astype(np.float64)
-        if safeguard or icp:
-            # the correspondences live in the context's workspace: take them before the next library call
-            idx1 = ops.batch_output(self.device, 'idx1') if safeguard and (status == 1).any() else None
-            xyz0 = torch.as_tensor(xyz0).to(self.device).float()
-            xyz1 = torch.as_tensor(xyz1).to(self.device).float()
-            for p in range(len(status)):
-                s0, e0, s1, e1 = int(off0[p]), int(off0[p + 1]), int(off1[p]), int(off1[p + 1])
-                if safeguard and status[p] == 1:
-                    Y = ops.gather_rows3(xyz1, idx1[s0:e0])
-                    T[p], _, _, _ = ops.ransac_correspondence(xyz0[s0:e0], Y, 2 * self.voxel_size, 4000000,
-                                                              seed=self.ransac_seed)
-                    status[p] = 3
-                if icp:
-                    T[p] = ops.icp_point_to_point(xyz0[s0:e0], xyz1[s1:e1], 2 * self.voxel_size, init=T[p])[0]
         return T, status, stats

@@ -35,56 +35,6 @@ __device__ __forceinline__ int block_exclusive_scan_256(int v, int *lds /*>=4 in
   return base + x - v;
 }
 
-__global__ void __launch_bounds__(SCAN_THREADS) scan_block_sums(const int32_t *__restrict__ in,
-                                                                int64_t n,
-                                                                int32_t *__restrict__ sums) {
-  __shared__ int lds[4];
-  int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_ITEMS;
-  int s = 0;
-#pragma unroll
-  for (int i = 0; i < SCAN_ITEMS; ++i)
-    if (base + i < n) s += in[base + i];
-  int tot;
-  block_exclusive_scan_256(s, lds, &tot);
-  if (threadIdx.x == 0) sums[blockIdx.x] = tot;
-}
-
-__global__ void __launch_bounds__(SCAN_THREADS) scan_sums_serial(int32_t *sums, int nblocks,
-                                                                 int32_t *total_out) {
-  __shared__ int lds[4];
-  int carry = 0;
-  for (int b0 = 0; b0 < nblocks; b0 += SCAN_THREADS) {
-    int i = b0 + threadIdx.x;
-    int v = i < nblocks ? sums[i] : 0;
-    int tot;
-    int ex = block_exclusive_scan_256(v, lds, &tot);
-    if (i < nblocks) sums[i] = carry + ex;
-    carry += tot;
-  }
-  if (threadIdx.x == 0 && total_out) *total_out = carry;
-}
-
-__global__ void __launch_bounds__(SCAN_THREADS) scan_final(const int32_t *__restrict__ in, int64_t n,
-                                                           const int32_t *__restrict__ sums,
-                                                           int32_t *__restrict__ out) {
-  __shared__ int lds[4];
-  int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_ITEMS;
-  int v[SCAN_ITEMS];
-  int s = 0;
-#pragma unroll
-  for (int i = 0; i < SCAN_ITEMS; ++i) {
-    v[i] = (base + i < n) ? in[base + i] : 0;
-    s += v[i];
-  }
-  int tot;
-  int ex = block_exclusive_scan_256(s, lds, &tot) + sums[blockIdx.x];
-#pragma unroll
-  for (int i = 0; i < SCAN_ITEMS; ++i) {
-    if (base + i < n) out[base + i] = ex;
-    ex += v[i];
-  }
-}
-
 // one workgroup, 1024 threads x 4 items per round with a running carry: ONE launch instead of three
 // for the many small scans of the map build (n <= a few 100 k), where launch boundaries dominate
 __global__ void __launch_bounds__(1024) scan_single_block(const int32_t *__restrict__ in, int64_t n,
@@ -117,6 +67,93 @@ __global__ void __launch_bounds__(1024) scan_single_block(const int32_t *__restr
   if (threadIdx.x == 0 && total_out) *total_out = carry_s;
 }
 
+// Up to DGR_SCAN_MAX independent scans in the SAME three launches (blockIdx.y = array): the map builders need two or
+// three scans at the same point (row pointers of the out-major and the in-major CSR, cell bases), and at these
+// sizes a scan is three ~4 us kernels + two launch boundaries, i.e. pure launch overhead.
+struct ScanJobs {
+  const int32_t *in[DGR_SCAN_MAX];
+  int32_t *out[DGR_SCAN_MAX], *sums[DGR_SCAN_MAX], *total[DGR_SCAN_MAX];
+  long long n[DGR_SCAN_MAX];
+  int nblocks[DGR_SCAN_MAX];
+};
+
+__global__ void __launch_bounds__(SCAN_THREADS) scan_block_sums_multi(ScanJobs j) {
+  __shared__ int lds[4];
+  const int a = blockIdx.y;
+  if ((int)blockIdx.x >= j.nblocks[a]) return;
+  const int32_t *in = j.in[a];
+  const long long n = j.n[a];
+  long long base = (long long)blockIdx.x * SCAN_BLOCK + (long long)threadIdx.x * SCAN_ITEMS;
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i)
+    if (base + i < n) s += in[base + i];
+  int tot;
+  block_exclusive_scan_256(s, lds, &tot);
+  if (threadIdx.x == 0) j.sums[a][blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) scan_sums_serial_multi(ScanJobs j) {
+  __shared__ int lds[4];
+  const int a = blockIdx.x;
+  int32_t *sums = j.sums[a];
+  const int nblocks = j.nblocks[a];
+  int carry = 0;
+  for (int b0 = 0; b0 < nblocks; b0 += SCAN_THREADS) {
+    int i = b0 + threadIdx.x;
+    int v = i < nblocks ? sums[i] : 0;
+    int tot;
+    int ex = block_exclusive_scan_256(v, lds, &tot);
+    if (i < nblocks) sums[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0 && j.total[a]) *j.total[a] = carry;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) scan_final_multi(ScanJobs j) {
+  __shared__ int lds[4];
+  const int a = blockIdx.y;
+  if ((int)blockIdx.x >= j.nblocks[a]) return;
+  const int32_t *in = j.in[a];
+  int32_t *out = j.out[a];
+  const long long n = j.n[a];
+  long long base = (long long)blockIdx.x * SCAN_BLOCK + (long long)threadIdx.x * SCAN_ITEMS;
+  int v[SCAN_ITEMS];
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    v[i] = (base + i < n) ? in[base + i] : 0;
+    s += v[i];
+  }
+  int tot;
+  int ex = block_exclusive_scan_256(s, lds, &tot) + j.sums[a][blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    if (base + i < n) out[base + i] = ex;
+    ex += v[i];
+  }
+}
+
+int dgr_exclusive_scan_multi(DgrArena &arena, int count, const int32_t *const *in, int32_t *const *out, const int64_t *n,
+                             int32_t *const *total_out, hipStream_t stream) {
+  DGR_REQUIRE(count >= 1 && count <= DGR_SCAN_MAX, "scan: %d arrays", count);
+  ScanJobs j;
+  int maxb = 0;
+  for (int a = 0; a < count; ++a) {
+    DGR_REQUIRE(n[a] > 0, "scan: empty array");
+    j.in[a] = in[a]; j.out[a] = out[a]; j.total[a] = total_out ? total_out[a] : nullptr; j.n[a] = n[a];
+    j.nblocks[a] = (int)dgr_ceil_div(n[a], SCAN_BLOCK);
+    DGR_ALLOC(j.sums[a], arena, int32_t, j.nblocks[a]);
+    maxb = j.nblocks[a] > maxb ? j.nblocks[a] : maxb;
+  }
+  for (int a = count; a < DGR_SCAN_MAX; ++a) { j.in[a] = nullptr; j.out[a] = j.sums[a] = j.total[a] = nullptr; j.n[a] = 0; j.nblocks[a] = 0; }
+  scan_block_sums_multi<<<dim3(maxb, count), SCAN_THREADS, 0, stream>>>(j);
+  scan_sums_serial_multi<<<count, SCAN_THREADS, 0, stream>>>(j);
+  scan_final_multi<<<dim3(maxb, count), SCAN_THREADS, 0, stream>>>(j);
+  DGR_LAUNCH_CHECK();
+  return DGR_OK;
+}
+
 int dgr_exclusive_scan_i32(DgrArena &arena, const int32_t *in, int32_t *out, int64_t n,
                            int32_t *total_out, hipStream_t stream) {
   if (n <= 0) {
@@ -128,14 +165,10 @@ int dgr_exclusive_scan_i32(DgrArena &arena, const int32_t *in, int32_t *out, int
     DGR_LAUNCH_CHECK();
     return DGR_OK;
   }
-  int nblocks = (int)dgr_ceil_div(n, SCAN_BLOCK);
-  int32_t *sums;
-  DGR_ALLOC(sums, arena, int32_t, nblocks);
-  scan_block_sums<<<nblocks, SCAN_THREADS, 0, stream>>>(in, n, sums);
-  scan_sums_serial<<<1, SCAN_THREADS, 0, stream>>>(sums, nblocks, total_out);
-  scan_final<<<nblocks, SCAN_THREADS, 0, stream>>>(in, n, sums, out);
-  DGR_LAUNCH_CHECK();
-  return DGR_OK;
+  const int32_t *ins[1] = {in};
+  int32_t *outs[1] = {out}, *tots[1] = {total_out};
+  const int64_t ns[1] = {n};
+  return dgr_exclusive_scan_multi(arena, 1, ins, outs, ns, tots, stream);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -160,6 +160,10 @@ int dgr_unique_rows(DgrArena &arena, const int32_t *keys, int64_t n, int nc, int
                     hipStream_t stream);
 int dgr_exclusive_scan_i32(DgrArena &arena, const int32_t *in, int32_t *out, int64_t n,
                            int32_t *total_out, hipStream_t stream);
+constexpr int DGR_SCAN_MAX = 4;
+// `count` independent exclusive scans in the same three launches (total_out / its entries may be null)
+int dgr_exclusive_scan_multi(DgrArena &arena, int count, const int32_t *const *in, int32_t *const *out, const int64_t *n,
+                             int32_t *const *total_out, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------
 // sparse convolution (conv.hip)
@@ -256,6 +260,12 @@ int dgr_knn1_impl(dgr_ctx *ctx, const float *F0, int64_t N0, const float *F1, in
 int dgr_inlier_inputs_impl(const int32_t *coords0, const float *xyz0, int64_t N0,
                            const int32_t *coords1, const float *xyz1, const int64_t *idx1,
                            int feature_type, int32_t *coords6, float *feats, hipStream_t stream);
+// o3d.hip: the two Open3D steps without resetting the context's arena (scratch behind the caller's allocations)
+int dgr_icp_impl(dgr_ctx *ctx, const float *src, int64_t N0, const float *dst, int64_t N1, double max_dist,
+                 const double *T_init, int max_iter, double rel_fitness, double rel_rmse, double *T_out,
+                 double *stats_out, hipStream_t stream);
+int dgr_ransac_impl(dgr_ctx *ctx, const float *X, const float *Y, int64_t N, double max_dist, int64_t num_hypotheses,
+                    uint32_t seed, double *T_out, double *stats_out, hipStream_t stream);
 struct DgrRegResult {  // device-side result record of the registration kernel
   float R[9];
   float t[3];

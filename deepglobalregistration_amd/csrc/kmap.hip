@@ -433,12 +433,19 @@ static int build_kernel_map_t(DgrArena &arena, const DgrCoordMap &in, const DgrC
   uint32_t *mask_out, *mask_in = nullptr;
   int32_t *cnt_out, *cnt_in = nullptr;
   DGR_ALLOC(mask_out, arena, uint32_t, (n_cap + 1) * KW);
+  if (need_in_csr) DGR_ALLOC(mask_in, arena, uint32_t, (n_in_cap + 1) * KW);
   DGR_ALLOC(cnt_out, arena, int32_t, n_cap + 1);
-  DGR_HIP_CHECK(hipMemsetAsync(mask_out, 0, (size_t)(n_cap + 1) * KW * sizeof(uint32_t), stream));
-  if (need_in_csr) {
-    DGR_ALLOC(mask_in, arena, uint32_t, (n_in_cap + 1) * KW);
-    DGR_ALLOC(cnt_in, arena, int32_t, n_in_cap + 1);
-    DGR_HIP_CHECK(hipMemsetAsync(mask_in, 0, (size_t)(n_in_cap + 1) * KW * sizeof(uint32_t), stream));
+  if (need_in_csr) DGR_ALLOC(cnt_in, arena, int32_t, n_in_cap + 1);
+  {
+    // the two bit matrices sit back to back in the arena (unless a chunk boundary fell between them): one clear
+    const size_t b_out = (size_t)(n_cap + 1) * KW * sizeof(uint32_t), b_in = (size_t)(n_in_cap + 1) * KW * sizeof(uint32_t);
+    char *lo = reinterpret_cast<char *>(mask_out), *hi = reinterpret_cast<char *>(mask_in);
+    if (need_in_csr && hi > lo && (size_t)(hi - lo) < b_out + 4096) {
+      DGR_HIP_CHECK(hipMemsetAsync(mask_out, 0, (size_t)(hi - lo) + b_in, stream));
+    } else {
+      DGR_HIP_CHECK(hipMemsetAsync(mask_out, 0, b_out, stream));
+      if (need_in_csr) DGR_HIP_CHECK(hipMemsetAsync(mask_in, 0, b_in, stream));
+    }
   }
   int32_t *hits = nullptr;
   int4 *cell = nullptr;
@@ -471,13 +478,16 @@ static int build_kernel_map_t(DgrArena &arena, const DgrCoordMap &in, const DgrC
   DGR_LAUNCH_CHECK();
   // per-row pair counts -> CSR row pointers (out rows; in rows for maps used swapped)
   mask_count_kernel<<<(int)dgr_ceil_div(n_cap + 1, 256), 256, 0, stream>>>(mask_out, KW, out.n_dev, n_cap + 1, cnt_out);
-  DGR_CHECK(dgr_exclusive_scan_i32(arena, cnt_out, km->out_ptr, n_cap + 1, nullptr, stream));
-  if (need_in_csr) {
-    mask_count_kernel<<<(int)dgr_ceil_div(n_in_cap + 1, 256), 256, 0, stream>>>(mask_in, KW, in.n_dev, n_in_cap + 1,
-                                                                                cnt_in);
-    DGR_CHECK(dgr_exclusive_scan_i32(arena, cnt_in, km->in_ptr, n_in_cap + 1, nullptr, stream));
+  if (need_in_csr)
+    mask_count_kernel<<<(int)dgr_ceil_div(n_in_cap + 1, 256), 256, 0, stream>>>(mask_in, KW, in.n_dev, n_in_cap + 1, cnt_in);
+  {
+    // row pointers of the out-major CSR (and of the in-major one for maps used swapped) + the cell bases: one
+    // multi-array scan = three launches for all of them
+    const int32_t *ins[3] = {cnt_out, counts, cnt_in};
+    int32_t *outs[3] = {km->out_ptr, base, km->in_ptr}, *tots[3] = {nullptr, total, nullptr};
+    const int64_t ns[3] = {n_cap + 1, (int64_t)K * RB, n_in_cap + 1};
+    DGR_CHECK(dgr_exclusive_scan_multi(arena, need_in_csr ? 3 : 2, ins, outs, ns, tots, stream));
   }
-  DGR_CHECK(dgr_exclusive_scan_i32(arena, counts, base, (int64_t)K * RB, total, stream));
   kmap_finalize<<<1, 1024, 0, stream>>>(base, total, K, RB, km->rule_ptr, km->tile_ptr);
   tile_desc_kernel<<<(int)dgr_ceil_div(km->tile_cap, 256), 256, 0, stream>>>(km->tile_ptr, km->rule_ptr, K,
                                                                             km->tile_desc, km->tile_cap);

@@ -7,6 +7,12 @@
 // Everything is stream-ordered and free of host round trips until the final result copy.
 #include "dgr_internal.h"
 #include "svd3.h"
+
+int dgr_icp_impl(dgr_ctx *ctx, const float *src, int64_t N0, const float *dst, int64_t N1, double max_dist,
+                 const double *T_init, int max_iter, double rel_fitness, double rel_rmse, double *T_out,
+                 double *stats_out, hipStream_t stream);
+int dgr_ransac_impl(dgr_ctx *ctx, const float *X, const float *Y, int64_t N, double max_dist, int64_t num_hypotheses,
+                    uint32_t seed, double *T_out, double *stats_out, hipStream_t stream);
 #include <cstring>
 
 // ------------------------------------------------------------------------------------------------
@@ -254,12 +260,21 @@ extern "C" int dgr_icp_point_to_point(dgr_ctx *ctx, const float *src, int64_t N0
                                       double max_dist, const double *T_init, int max_iter, double rel_fitness,
                                       double rel_rmse, double *T_out, double *stats_out, dgr_stream stream_) {
   DGR_REQUIRE(ctx && src && dst && T_out, "dgr_icp_point_to_point: NULL argument");
-  DGR_REQUIRE(N0 > 0 && N1 > 0, "ICP: empty point cloud (N0=%lld, N1=%lld)", (long long)N0, (long long)N1);
-  DGR_REQUIRE(max_dist > 0.0 && max_iter >= 0 && max_iter <= 10000, "ICP: bad max_dist / max_iter");
-  hipStream_t stream = (hipStream_t)stream_;
   DGR_HIP_CHECK(hipSetDevice(ctx->device));
   DGR_CHECK(ctx->arena.reset());
+  return dgr_icp_impl(ctx, src, N0, dst, N1, max_dist, T_init, max_iter, rel_fitness, rel_rmse, T_out, stats_out,
+                      (hipStream_t)stream_);
+}
+
+// the same without resetting the context's arena (scratch is taken behind the caller's allocations and given back):
+// the fused batched pipeline calls it per pair
+int dgr_icp_impl(dgr_ctx *ctx, const float *src, int64_t N0, const float *dst, int64_t N1, double max_dist,
+                 const double *T_init, int max_iter, double rel_fitness, double rel_rmse, double *T_out,
+                 double *stats_out, hipStream_t stream) {
+  DGR_REQUIRE(N0 > 0 && N1 > 0, "ICP: empty point cloud (N0=%lld, N1=%lld)", (long long)N0, (long long)N1);
+  DGR_REQUIRE(max_dist > 0.0 && max_iter >= 0 && max_iter <= 10000, "ICP: bad max_dist / max_iter");
   DgrArena &A = ctx->arena;
+  const DgrArena::Mark icp_mark = A.mark();
   constexpr int32_t CELL_CAP = 4 << 20;
   IcpState *st;
   double *Tdev, *P, *sorted, *partial;
@@ -306,6 +321,7 @@ extern "C" int dgr_icp_point_to_point(dgr_ctx *ctx, const float *src, int64_t N0
     stats_out[1] = host.rmse;
     stats_out[2] = (double)host.iters;
   }
+  A.rewind(icp_mark);   // the stream was synchronised above: nothing is in flight on the scratch
   return DGR_OK;
 }
 
@@ -448,12 +464,17 @@ extern "C" int dgr_ransac_correspondence(dgr_ctx *ctx, const float *X, const flo
                                          int64_t num_hypotheses, uint32_t seed, double *T_out, double *stats_out,
                                          dgr_stream stream_) {
   DGR_REQUIRE(ctx && X && Y && T_out, "dgr_ransac_correspondence: NULL argument");
+  DGR_HIP_CHECK(hipSetDevice(ctx->device));
+  DGR_CHECK(ctx->arena.reset());
+  return dgr_ransac_impl(ctx, X, Y, N, max_dist, num_hypotheses, seed, T_out, stats_out, (hipStream_t)stream_);
+}
+
+int dgr_ransac_impl(dgr_ctx *ctx, const float *X, const float *Y, int64_t N, double max_dist, int64_t num_hypotheses,
+                    uint32_t seed, double *T_out, double *stats_out, hipStream_t stream) {
   DGR_REQUIRE(N > 0 && N < (1ll << 31), "RANSAC: bad correspondence count %lld", (long long)N);
   DGR_REQUIRE(num_hypotheses > 0 && num_hypotheses <= (1ll << 30), "RANSAC: bad hypothesis count");
   DGR_REQUIRE(max_dist > 0.0, "RANSAC: bad distance threshold");
-  hipStream_t stream = (hipStream_t)stream_;
-  DGR_HIP_CHECK(hipSetDevice(ctx->device));
-  DGR_CHECK(ctx->arena.reset());
+  const DgrArena::Mark rs_mark = ctx->arena.mark();
   const int nblocks = (int)dgr_ceil_div(num_hypotheses, RS_THREADS);
   RsBest *bb;
   RsResult *res;
@@ -472,5 +493,6 @@ extern "C" int dgr_ransac_correspondence(dgr_ctx *ctx, const float *X, const flo
     stats_out[1] = host.count;
     stats_out[2] = host.rmse;
   }
+  ctx->arena.rewind(rs_mark);   // the stream was synchronised above
   return DGR_OK;
 }

@@ -267,6 +267,28 @@ extern "C" int dgr_register_batch(dgr_ctx *ctx, dgr_net *fcgf, dgr_net *inlier, 
       }
     }
     status_out[p] = r.status;
+    // the two Open3D steps that end register() (:302-322), per pair, without leaving the library
+    if ((prm->safeguard && r.status == DGR_STATUS_LOW_CONFIDENCE) || prm->use_icp) {
+      const int64_t m0 = off0[p + 1] - off0[p], m1 = off1[p + 1] - off1[p];
+      double Td[16];
+      for (int i = 0; i < 16; ++i) Td[i] = T[i];
+      if (prm->safeguard && r.status == DGR_STATUS_LOW_CONFIDENCE) {
+        // Case 1 (:302-315): RANSAC over the putative correspondences xyz0[i] <-> xyz1[idx1[i]]
+        const DgrArena::Mark mk = A.mark();
+        float *Y;
+        DGR_ALLOC(Y, A, float, m0 * 3);
+        gather_rows3_kernel<<<(int)dgr_ceil_div(m0, 256), 256, 0, stream>>>(xyz1, idx1 + off0[p], m0, Y);
+        DGR_CHECK(dgr_ransac_impl(ctx, xyz0 + off0[p] * 3, Y, m0, 2.0 * prm->voxel_size,
+                                  prm->ransac_hypotheses > 0 ? prm->ransac_hypotheses : 4000000, prm->ransac_seed, Td,
+                                  nullptr, stream));
+        A.rewind(mk);
+        status_out[p] = DGR_STATUS_SAFEGUARD;
+      }
+      if (prm->use_icp)   // :317-322: max correspondence distance 2 voxel, Open3D defaults (1e-6, 1e-6, 30)
+        DGR_CHECK(dgr_icp_impl(ctx, xyz0 + off0[p] * 3, m0, xyz1 + off1[p] * 3, m1, 2.0 * prm->voxel_size, Td, 30, 1e-6,
+                               1e-6, Td, nullptr, stream));
+      for (int i = 0; i < 16; ++i) T[i] = (float)Td[i];
+    }
     if (stats_out) {
       stats_out[p * 4 + 0] = (float)r.iterations;
       stats_out[p * 4 + 1] = r.loss;

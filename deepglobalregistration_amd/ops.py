@@ -321,7 +321,8 @@ def ransac_correspondence(X, Y, distance_threshold, num_hypotheses, seed=0):
 def register_batch(fcgf, inlier, coords0, xyz0, off0, coords1, xyz1, off1, voxel_size,
                    clip_weight_thresh=0.05, inlier_feature_type='coords', max_iter=1000,
                    max_break_count=20, break_threshold_ratio=1e-4, skip_refinement=False,
-                   forced_logit=None, override_idx1=None):
+                   forced_logit=None, override_idx1=None, safeguard=False, use_icp=False, ransac_hypotheses=4000000,
+                   ransac_seed=0):
     """Fused pipeline over a batch of voxelised pairs (dgr_register_batch).  Returns
     T [npairs,4,4] float32, status [npairs] int32, stats [npairs,4] float32."""
     lib = _lib.load()
@@ -335,8 +336,9 @@ def register_batch(fcgf, inlier, coords0, xyz0, off0, coords1, xyz1, off1, voxel
         raise ValueError('offset arrays do not match the coordinate arrays')
     prm = _lib.Params(float(clip_weight_thresh), float(voxel_size),
                       {'ones': 0, 'coords': 1}[inlier_feature_type], int(max_iter), int(max_break_count),
-                      float(break_threshold_ratio), int(bool(skip_refinement)))
-    T = np.empty((npairs, 16), np.float32)
+                      float(break_threshold_ratio), int(bool(skip_refinement)), int(bool(safeguard)),
+                      int(ransac_hypotheses), int(ransac_seed) & 0xffffffff, int(bool(use_icp)))
+    T = np.empty((npairs, 16), np.float32)   # (float32 at the ABI; the ICP / RANSAC stages compute in float64 inside)
     status = np.empty(npairs, np.int32)
     stats = np.empty((npairs, 4), np.float32)
     fl = None

@@ -45,7 +45,8 @@ enum {
 };
 
 /* per-pair status of the confidence gate, core/deep_global_registration.py:276-281 */
-enum { DGR_STATUS_OK = 0, DGR_STATUS_LOW_CONFIDENCE = 1, DGR_STATUS_SVD_FAILED = 2 };
+enum { DGR_STATUS_OK = 0, DGR_STATUS_LOW_CONFIDENCE = 1, DGR_STATUS_SVD_FAILED = 2,
+       DGR_STATUS_SAFEGUARD = 3 /* gate failed, T from the safeguard RANSAC (dgr_params.safeguard) */ };
 
 const char *dgr_last_error(void);
 const char *dgr_version(void);
@@ -201,6 +202,12 @@ typedef struct {
   int max_break_count;          /* 20 */
   double break_threshold_ratio; /* 1e-4 as passed at :286 */
   int skip_refinement;          /* ablation (config C5): stop after weighted Procrustes */
+  /* the two Open3D steps that end register() (:302-322), inside the same call (0 = leave them to the caller): */
+  int safeguard;                /* pairs that fail the confidence gate: RANSAC over the putative correspondences (:302-315,
+                                 * :50-64), status DGR_STATUS_SAFEGUARD; an SVD failure keeps T = identity (:295-300) */
+  int64_t ransac_hypotheses;    /* 4000000 in the reference (:58) */
+  uint32_t ransac_seed;
+  int use_icp;                  /* point-to-point ICP from the estimate, max distance 2 voxel, 30 iterations (:317-322) */
 } dgr_params;
 
 int dgr_register_batch(dgr_ctx *ctx, dgr_net *fcgf, dgr_net *inlier, const int32_t *coords0,

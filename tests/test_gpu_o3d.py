@@ -124,7 +124,7 @@ def test_register_runs_safeguard_and_icp():
 def test_batched_call_with_safeguard_and_icp():
     """Pairs rejected by the gate inside the fused batched call are rescued by the safeguard (status 3) and
     refined by ICP; with 20 % ground-truth matches among the putative correspondences RANSAC finds the pose."""
-    from deepglobalregistration_amd import synth
+    from deepglobalregistration_amd import ops, synth
     from deepglobalregistration_amd.core.deep_global_registration import DeepGlobalRegistration
     dgr = DeepGlobalRegistration({'weights': synth.synth_checkpoint(0)}, torch.device('cuda'))
     pairs = [synth.synth_pair(s, 20000) for s in (0, 1)]
@@ -144,3 +144,17 @@ def test_batched_call_with_safeguard_and_icp():
     assert status.tolist() == [3, 3]
     for p, (_, _, T_gt) in enumerate(pairs):
         assert rot_angle_deg(T[p, :3, :3], T_gt[:3, :3]) < 2.0 and np.linalg.norm(T[p, :3, 3] - T_gt[:3, 3]) < 0.1
+    # the two steps run inside dgr_register_batch are the stand-alone entry points: same hypotheses, same ICP
+    idx1 = ops.batch_output('cuda', 'idx1')      # the override keeps the 1-NN answer where it holds -1
+    X1 = torch.cat(x1)
+    for p in range(2):
+        sl = slice(off0[p], off0[p + 1])
+        Y = ops.gather_rows3(X1, idx1[sl])
+        Tr, _, _, _ = ops.ransac_correspondence(x0[p], Y, 2 * dgr.voxel_size, 4000000, seed=dgr.ransac_seed)
+        Ti, _, _, _ = ops.icp_point_to_point(x0[p], x1[p], 2 * dgr.voxel_size, init=Tr)
+        assert np.abs(Ti - T[p]).max() < 1e-6          # the batched call returns float32 at the ABI
+    # without the flags the rejected pairs stay at identity with status 1 (register_batch proper, :288-300)
+    T0, status0, _ = dgr.register_voxelized(torch.cat(c0), torch.cat(x0), off0, torch.cat(c1), torch.cat(x1), off1,
+                                            forced_logits=forced,
+                                            override_idx1=torch.from_numpy(np.concatenate(ov)).cuda())
+    assert status0.tolist() == [1, 1] and np.array_equal(T0[0], np.eye(4))
