@@ -32,6 +32,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 struct ConvOsArgs {
   const float *in;
@@ -43,6 +45,8 @@ struct ConvOsArgs {
   int64_t n_pad;
   int in_ld, in_relu, out_ld, out_relu, res_ld, res_relu;
   int cin, cout, nb16;   // nb16 = cout / 16
+  const float *row_scale;  // PM = 2: power-of-two scale per input row (dgr_row_scale)
+  float w_unscale;         // PM = 2: inverse of the layer's weight scale
 };
 
 // CP = input channels (multiple of 32), CS = output-channel slice of a workgroup (32 | 64), MB = output rows
@@ -50,8 +54,12 @@ struct ConvOsArgs {
 // BF3: the products run on the bf16 matrix pipe with every f32 operand split exactly into three bf16 pieces (six
 // v_mfma_f32_16x16x32_bf16 per 32 input channels instead of eight v_mfma_f32_16x16x4_f32: 2.67x fewer matrix
 // cycles, f32-level error -- see conv_bf3.hip); false = exact-f32 MFMA (DGR_OS_F32=1, A/B measurements)
-template <int CP, int CS, int MB, int CK, int TM, bool BF3>
+// PM = pieces per operand: 0 = exact-f32 MFMA, 3 = bf16 x 3 (six products), 2 = f16 x 2 with exact power-of-two
+// row / layer scales (three v_mfma_f32_16x16x32_f16 per 32 input channels; conv_bf3.hip has the error analysis)
+template <int CP, int CS, int MB, int CK, int TM, int PM>
 __global__ void __launch_bounds__(CS * 4) sparse_conv_os(ConvOsArgs a) {
+  constexpr bool BF3 = PM != 0;
+  constexpr int NP = PM == 0 ? 1 : PM;
   constexpr int NW = CS / 16;            // waves: one 16-channel block each
   constexpr int THREADS = 64 * NW;
   constexpr int GP = TM / 16;            // 16-row groups per tile
@@ -68,12 +76,13 @@ __global__ void __launch_bounds__(CS * 4) sparse_conv_os(ConvOsArgs a) {
   constexpr int LDP = CK + 8;                 // BF3: bf16 elements per plane row
   constexpr int PLANE = TM * LDP;             // bf16 elements per plane
   constexpr int G32 = CK / 32;                // BF3: 32-channel k-steps per phase
-  constexpr int ABYTES = BF3 ? 2 * 3 * PLANE * 2 : 2 * TM * LDA * 4;
+  constexpr int ABYTES = BF3 ? 2 * NP * PLANE * 2 : 2 * TM * LDA * 4;
   __shared__ __attribute__((aligned(16))) char abuf[ABYTES];   // f32: As[2][TM][LDA]; BF3: planes [2][3][TM][LDP] bf16
   float (*As)[TM][LDA] = reinterpret_cast<float (*)[TM][LDA]>(abuf);
   unsigned short *Ps = reinterpret_cast<unsigned short *>(abuf);
   __shared__ __attribute__((aligned(16))) float acc_s[MB][LDC];
   __shared__ int in_idx[KV][MB];
+  __shared__ float in_scale[PM == 2 ? KV : 1][MB];   // PM = 2: scale of the listed input rows
   __shared__ unsigned char out_loc[KV][MB];
   __shared__ int cnt[KV];
   __shared__ int grp[NGMAX + GP];   // k | first list entry << 8 | entries << 16, ascending k
@@ -109,6 +118,7 @@ __global__ void __launch_bounds__(CS * 4) sparse_conv_os(ConvOsArgs a) {
           const int pos = __popcll(m & ((1ull << lane) - 1ull));
           in_idx[k][pos] = v[u];
           out_loc[k][pos] = (unsigned char)lane;
+          if constexpr (PM == 2) in_scale[k][pos] = a.row_scale[v[u]];
         }
         if (lane == 0) cnt[k] = __popcll(m);
       }
@@ -179,6 +189,25 @@ __global__ void __launch_bounds__(CS * 4) sparse_conv_os(ConvOsArgs a) {
       v.x = max(v.x, relu_lo); v.y = max(v.y, relu_lo); v.z = max(v.z, relu_lo); v.w = max(v.w, relu_lo);
       if constexpr (!BF3) {
         *reinterpret_cast<i32x4 *>(&As[q & 1][0][0] + (ch / C4K) * LDA + (ch % C4K) * 4) = v;
+      } else if constexpr (PM == 2) {
+        // s x = h + m (+ <= 2^-22): two f16 planes; slots past their group's entries carry row 0 under a
+        // finite foreign scale and are never accumulated
+        const int r = ch / C4K;
+        const int info = grp[GP * (q / PPT) + (r >> 4)];
+        const float sx = in_scale[info & 255][min(((info >> 8) & 255) + (r & 15), MB - 1)];
+        _Float16 hh[4], mm[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int vi = v[u];
+          const float xs = __builtin_bit_cast(float, vi) * sx;
+          hh[u] = (_Float16)xs;
+          mm[u] = (_Float16)(xs - (float)hh[u]);
+        }
+        unsigned short *dst = Ps + (q & 1) * NP * PLANE + r * LDP + (ch % C4K) * 4;
+        *reinterpret_cast<u32x2 *>(dst) = u32x2{__builtin_bit_cast(uint32_t, f16x2{hh[0], hh[1]}),
+                                                __builtin_bit_cast(uint32_t, f16x2{hh[2], hh[3]})};
+        *reinterpret_cast<u32x2 *>(dst + PLANE) = u32x2{__builtin_bit_cast(uint32_t, f16x2{mm[0], mm[1]}),
+                                                        __builtin_bit_cast(uint32_t, f16x2{mm[2], mm[3]})};
       } else {
         // x = h + m + l exactly (8 + 8 + 8 significant bits by truncation), three bf16 planes
         uint32_t h[4], m[4], l[4];
@@ -201,7 +230,7 @@ __global__ void __launch_bounds__(CS * 4) sparse_conv_os(ConvOsArgs a) {
   // A operands (weights) of step s = GP q + rb (group rb of phase q): coalesced 16-byte loads per lane, straight
   // from L2 (a layer's 27 slices are at most 7 MB and shared by every workgroup)
   const int jb = slice * NW + wave;
-  constexpr int WREGS = BF3 ? 3 * G32 : G;     // 16-byte operand registers per group
+  constexpr int WREGS = BF3 ? NP * G32 : G;    // 16-byte operand registers per group
   struct WSet { uint4 v[WREGS]; };
   auto wstep = [&](int s, WSet &w) {
     const int q = min(s / GP, NQ - 1);
@@ -215,7 +244,7 @@ __global__ void __launch_bounds__(CS * 4) sparse_conv_os(ConvOsArgs a) {
 #pragma unroll
       for (int g = 0; g < G32; ++g)
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc) w.v[3 * g + pc] = p[(int64_t)pc * a.piece_stride + (int64_t)g * a.nb16 * 64];
+        for (int pc = 0; pc < NP; ++pc) w.v[NP * g + pc] = p[(int64_t)pc * a.piece_stride + (int64_t)g * a.nb16 * 64];
     }
   };
 
@@ -231,6 +260,17 @@ __global__ void __launch_bounds__(CS * 4) sparse_conv_os(ConvOsArgs a) {
         const f32x4 wv = __builtin_bit_cast(f32x4, w[rb].v[g]);
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c], av[c], acc[rb], 0, 0, 0);
+      }
+    } else if constexpr (PM == 2) {
+      const unsigned short *prow = Ps + buf * NP * PLANE + (rb * 16 + (lane & 15)) * LDP + 8 * (lane >> 4);
+#pragma unroll
+      for (int g = 0; g < G32; ++g) {
+        const f16x8 ah = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(prow + 32 * g));
+        const f16x8 am = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(prow + PLANE + 32 * g));
+        const f16x8 wh = __builtin_bit_cast(f16x8, w[rb].v[2 * g]), wm = __builtin_bit_cast(f16x8, w[rb].v[2 * g + 1]);
+        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm, ah, acc[rb], 0, 0, 0);
+        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, am, acc[rb], 0, 0, 0);
+        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ah, acc[rb], 0, 0, 0);
       }
     } else {
       const unsigned short *prow = Ps + buf * 3 * PLANE + (rb * 16 + (lane & 15)) * LDP + 8 * (lane >> 4);
@@ -289,9 +329,15 @@ __global__ void __launch_bounds__(CS * 4) sparse_conv_os(ConvOsArgs a) {
 #else
         if ((lane & 15) < (info >> 16)) {
 #endif
-          float *p = &acc_s[out_loc[info & 255][((info >> 8) & 255) + (lane & 15)]][16 * wave + 4 * (lane >> 4)];
+          const int e = ((info >> 8) & 255) + (lane & 15);
+          float *p = &acc_s[out_loc[info & 255][e]][16 * wave + 4 * (lane >> 4)];
           f32x4 v = *reinterpret_cast<f32x4 *>(p);
-          v += acc[rb];
+          if constexpr (PM == 2) {
+            const float f = __builtin_bit_cast(float, 0x7f000000u - __builtin_bit_cast(uint32_t, in_scale[info & 255][e])) * a.w_unscale;
+            v += acc[rb] * f;
+          } else {
+            v += acc[rb];
+          }
           *reinterpret_cast<f32x4 *>(p) = v;
         }
       }
@@ -316,10 +362,12 @@ static int launch_os(const ConvOsArgs &ka, int64_t n_out_cap, hipStream_t stream
   int64_t blocks = dgr_ceil_div(n_out_cap, MB);
   blocks = (blocks + 7) / 8 * 8;
   dim3 grid((unsigned)blocks, (unsigned)(ka.cout / CS));
-  if (ka.wb3)
-    sparse_conv_os<CP, CS, MB, CK, TM, true><<<grid, CS * 4, 0, stream>>>(ka);
+  if (ka.wb3 && ka.row_scale)
+    sparse_conv_os<CP, CS, MB, CK, TM, 2><<<grid, CS * 4, 0, stream>>>(ka);
+  else if (ka.wb3)
+    sparse_conv_os<CP, CS, MB, CK, TM, 3><<<grid, CS * 4, 0, stream>>>(ka);
   else
-    sparse_conv_os<CP, CS, MB, CK, TM, false><<<grid, CS * 4, 0, stream>>>(ka);
+    sparse_conv_os<CP, CS, MB, CK, TM, 0><<<grid, CS * 4, 0, stream>>>(ka);
   DGR_LAUNCH_CHECK();
   return DGR_OK;
 }
@@ -336,6 +384,9 @@ int dgr_conv_os_launch(const DgrConvOsLaunch &a, hipStream_t stream, const char 
   ka.in = a.in; ka.out = a.out; ka.w16 = a.w16; ka.shift = a.shift; ka.res = a.res;
   ka.wb3 = os_f32 ? nullptr : static_cast<const uint4 *>(a.wb3);
   ka.piece_stride = a.piece_stride;
+  ka.row_scale = (ka.wb3 && a.pieces == 2) ? a.row_scale : nullptr;
+  ka.w_unscale = a.w_unscale;
+  DGR_REQUIRE(!ka.wb3 || a.pieces == 3 || ka.row_scale, "output-stationary conv: 2-piece weights need the input's row scales");
   ka.nbr = a.nbr->nbr; ka.n_out_dev = a.n_out_dev; ka.n_pad = a.nbr->n_pad;
   ka.in_ld = a.in_ld; ka.in_relu = a.in_relu; ka.out_ld = a.out_ld; ka.out_relu = a.out_relu;
   ka.res_ld = a.res_ld; ka.res_relu = a.res_relu;
@@ -351,7 +402,8 @@ int dgr_conv_os_launch(const DgrConvOsLaunch &a, hipStream_t stream, const char 
 #define DGR_OS(CPV, CSV, MBV, CKV)                                                                      \
   do {                                                                                                  \
     constexpr int tm = (MBV) < DGR_OS_TM ? ((MBV) < 32 ? 32 : (MBV)) : DGR_OS_TM;                       \
-    if (kernel_name) *kernel_name = ka.wb3 ? "sparse_conv_os<" #CPV ", " #CSV ", " DGR_STR(MBV) ", " DGR_STR(CKV) ", bf16x3>"  \
+    if (kernel_name) *kernel_name = ka.row_scale ? "sparse_conv_os<" #CPV ", " #CSV ", " DGR_STR(MBV) ", " DGR_STR(CKV) ", f16x2>"  \
+                                    : ka.wb3 ? "sparse_conv_os<" #CPV ", " #CSV ", " DGR_STR(MBV) ", " DGR_STR(CKV) ", bf16x3>"  \
                                            : "sparse_conv_os<" #CPV ", " #CSV ", " DGR_STR(MBV) ", " DGR_STR(CKV) ", f32>"; \
     return launch_os<CPV, CSV, MBV, CKV, tm>(ka, a.n_out_cap, stream);                                  \
   } while (0)

@@ -187,8 +187,14 @@ int dgr_conv_launch(const DgrConvLaunch &a, int num_cus, hipStream_t stream, con
 // wide layers (Cout >= 128): the same phase 1 on the bf16 matrix pipe with every f32 operand split exactly into
 // three bf16 pieces (conv_bf3.hip); wb = the layer's pre-split weights, piece_stride in 16-byte units
 bool dgr_conv_bf3_supported(int cin_pad, int cin, int cout);
-int dgr_conv_bf3_launch(const DgrConvLaunch &a, const void *wb, int64_t piece_stride, int num_cus, hipStream_t stream,
-                        const char **kernel_name = nullptr);
+// pieces = 3: bf16 x 3 (six products); pieces = 2: f16 x 2 (three products) with the input's power-of-two row
+// scales (dgr_row_scale) and the inverse of the layer's weight scale
+int dgr_conv_bf3_launch(const DgrConvLaunch &a, const void *wb, int64_t piece_stride, int pieces, float w_unscale,
+                        const float *row_scale, int num_cus, hipStream_t stream, const char **kernel_name = nullptr);
+// out[r] = 2^(14 - floor(log2 max_c |in[r][c]|)) (after the pending ReLU): the row's largest entry lands in
+// [2^14, 2^15) when multiplied by it; 1 for rows of zeros
+int dgr_row_scale(const float *in, int in_ld, int cin, int relu, const int32_t *n_dev, int64_t n_cap, float *out,
+                  hipStream_t stream);
 // out[o,:] = shift (+res[o,:]) + sum_{j in [ptr[o], ptr[o+1])} y[pos[j],:]   (ascending-k order)
 int dgr_reduce_rows(const float *y, int cout, const int32_t *ptr, const int32_t *pos, const int32_t *n_dev,
                     int64_t n_cap, float *out, int out_ld, const float *shift, const float *res, int res_ld,
@@ -203,7 +209,9 @@ struct DgrConvOsLaunch {
   const float *in; int in_ld, in_relu;
   float *out; int out_ld, out_relu;
   const float *w16, *shift;
-  const void *wb3; int64_t piece_stride;   // three exact bf16 pieces of the weights (16-byte units per piece), or null
+  const void *wb3; int64_t piece_stride;   // split weights (16-byte units per piece), or null
+  int pieces = 3;                          // 3 = bf16 x 3; 2 = f16 x 2 (needs row_scale, w_unscale)
+  const float *row_scale = nullptr; float w_unscale = 1.f;
   const float *res; int res_ld, res_relu;
   int rows_per_block;   // 64 | 32 | 16 output rows per workgroup
   const DgrNbrTable *nbr;

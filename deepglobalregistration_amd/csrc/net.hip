@@ -33,6 +33,8 @@ struct DgrLayer {
   float *wc = nullptr;     // device, compact [K][32] (3-D conv1 with one input channel: conv1_grid_mfma, conv.hip)
   void *wb = nullptr;      // device, three exact bf16 pieces in 32x32x16 fragment order (wide layers, conv_bf3.hip)
   int64_t wb_piece = 0;    // 16-byte units per piece
+  int pieces = 3;          // wb / w16b: 3 = bf16 x 3 (exact), 2 = f16 x 2 scaled by 1 / w_unscale (a power of two)
+  float w_unscale = 1.f;
   float *shift = nullptr;  // device [cout] or nullptr
 };
 
@@ -41,6 +43,7 @@ struct LayerRun {  // bookkeeping of the last forward, for dgr_net_layer_stats /
   const int32_t *n_in = nullptr, *n_out = nullptr;
   int K = 1;
   DgrConvLaunch launch;   // the exact launch of phase 1
+  const float *row_scale = nullptr;   // f16 x 2 wide-layer kernel: the input's row scales
   bool small_cin = false;  // conv1 ran through the output-stationary kernel instead
   const int32_t *fused_pairs = nullptr;  // conv1 fused with its neighbour search: device pair counter
   bool os = false;                       // ran through the output-stationary kernel
@@ -117,11 +120,29 @@ static int make_layer(dgr_net *net, const dgr_weight_desc *descs, int nd, const 
   // DGR_CONV_F32=1 keeps the exact-f32 MFMA kernel for the wide layers (A/B measurements); by default they run
   // on the bf16 pipe with exactly split operands (conv_bf3.hip) and only that weight copy is made
   static const bool f32_wide = getenv("DGR_CONV_F32") != nullptr;
+  // split-operand kernels: two f16 pieces under power-of-two scales (default) or three exact bf16 pieces
+  // (DGR_CONV_BF3=1; twice the matrix work, kept for A/B measurements)
+  static const bool three_pieces = getenv("DGR_CONV_BF3") != nullptr;
+  L.pieces = three_pieces ? 3 : 2;
+  float w_scale = 1.f;
+  if (L.pieces == 2) {
+    float mx = 0.f;
+    for (int k = 0; k < K; ++k)
+      for (int r = 0; r < cin; ++r)
+        for (int c = 0; c < cout; ++c) mx = std::max(mx, fabsf(kd->data[((size_t)k * cin + r) * cout + c] * scale[c]));
+    int e = 0;
+    if (mx > 0.f && std::isfinite(mx)) (void)frexpf(mx, &e);   // mx in [2^(e-1), 2^e)
+    e = std::min(std::max(e, -100), 100);
+    w_scale = ldexpf(1.f, 15 - e);                              // largest |w| lands in [2^14, 2^15)
+    L.w_unscale = ldexpf(1.f, e - 15);
+  }
+  auto f16_bits = [](float x) { _Float16 h = (_Float16)x; uint16_t b; memcpy(&b, &h, 2); return b; };
+  auto f16_val = [](float x) { return (float)(_Float16)x; };
   const bool use_bf3 = K > 1 && !f32_wide && dgr_conv_bf3_supported(L.cin_pad, cin, cout) && !(net->D == 3 && K == 27);
   if (use_bf3) {
     const int S16 = cin / 16, NB32 = cout / 32;
     L.wb_piece = (int64_t)K * S16 * NB32 * 64;
-    std::vector<uint16_t> pieces((size_t)3 * L.wb_piece * 8);
+    std::vector<uint16_t> pieces((size_t)L.pieces * L.wb_piece * 8);
     auto top16 = [](float x) { uint32_t b; memcpy(&b, &x, 4); return b & 0xffff0000u; };
     auto asf = [](uint32_t b) { float x; memcpy(&x, &b, 4); return x; };
     for (int k = 0; k < K; ++k) {
@@ -133,6 +154,12 @@ static int make_layer(dgr_net *net, const dgr_weight_desc *descs, int nd, const 
             const size_t o = ((((size_t)k * S16 + s) * NB32 + nb) * 64 + lane) * 8;
             for (int e = 0; e < 8; ++e) {
               const float x = src[(size_t)(16 * s + 8 * (lane >> 5) + e) * cout + col] * scale[col];
+              if (L.pieces == 2) {
+                const float xs = x * w_scale;
+                pieces[o + e] = f16_bits(xs);
+                pieces[(size_t)L.wb_piece * 8 + o + e] = f16_bits(xs - f16_val(xs));
+                continue;
+              }
               const uint32_t h = top16(x);
               const float r1 = x - asf(h);
               const uint32_t m = top16(r1);
@@ -192,7 +219,7 @@ static int make_layer(dgr_net *net, const dgr_weight_desc *descs, int nd, const 
       // WB[piece][k][s][jb][lane] = 8 bf16 = piece of W[k][32 s + 8 (lane >> 4) + e][16 jb + (lane & 15)]
       const int S32 = cin / 32;
       L.w16b_piece = (int64_t)K * S32 * NB * 64;
-      std::vector<uint16_t> pcs((size_t)3 * L.w16b_piece * 8);
+      std::vector<uint16_t> pcs((size_t)L.pieces * L.w16b_piece * 8);
       auto top16 = [](float x) { uint32_t b; memcpy(&b, &x, 4); return b & 0xffff0000u; };
       auto asf = [](uint32_t b) { float x; memcpy(&x, &b, 4); return x; };
       for (int k = 0; k < K; ++k) {
@@ -204,6 +231,12 @@ static int make_layer(dgr_net *net, const dgr_weight_desc *descs, int nd, const 
               const size_t o = ((((size_t)k * S32 + sI) * NB + jb) * 64 + lane) * 8;
               for (int e = 0; e < 8; ++e) {
                 const float x = src[(size_t)(32 * sI + 8 * (lane >> 4) + e) * cout + col] * scale[col];
+                if (L.pieces == 2) {
+                  const float xs = x * w_scale;
+                  pcs[o + e] = f16_bits(xs);
+                  pcs[(size_t)L.w16b_piece * 8 + o + e] = f16_bits(xs - f16_val(xs));
+                  continue;
+                }
                 const uint32_t h = top16(x);
                 const float r1 = x - asf(h);
                 const uint32_t m = top16(r1);
@@ -357,6 +390,13 @@ struct Fwd {
       o.rows_per_block = lvl_out <= 1 ? 64 : lvl_out == 2 ? 32 : 16;
       o.w16 = L.w16; o.shift = L.shift;
       o.wb3 = L.w16b; o.piece_stride = L.w16b_piece;
+      o.pieces = L.pieces; o.w_unscale = L.w_unscale;
+      if (L.w16b && L.pieces == 2 && !getenv("DGR_OS_F32")) {
+        float *rs;
+        DGR_ALLOC(rs, ctx->arena, float, cin_map.n_cap);
+        DGR_CHECK(dgr_row_scale(in.ptr, in.ld, L.cin, in.relu, cin_map.n_dev, cin_map.n_cap, rs, stream));
+        o.row_scale = rs;
+      }
       o.res = res ? res->ptr : nullptr; o.res_ld = res ? res->ld : 0; o.res_relu = res ? res->relu : 0;
       o.nbr = t; o.n_out_dev = cout_map.n_dev; o.n_out_cap = cout_map.n_cap;
       o.cin = L.cin; o.cin_pad = L.cin_pad; o.cout = L.cout;
@@ -380,11 +420,19 @@ struct Fwd {
     }
     const bool small_cin = km && !swapped && !res && L.cin <= 8 && L.cout == 32 && L.cin_pad == 8;
     const char *kname = "conv_small_cin_kernel";
+    const float *row_scale = nullptr;
     if (small_cin)
       DGR_CHECK(dgr_conv_small_cin(in.ptr, in.ld, in.relu, L.cin, L.w, L.shift, *km, cout_map.n_dev, cout_map.n_cap,
                                    out.ptr, out.ld, stream));
-    else if (L.wb && km)
-      DGR_CHECK(dgr_conv_bf3_launch(a, L.wb, L.wb_piece, ctx->num_cus, stream, &kname));
+    else if (L.wb && km) {
+      if (L.pieces == 2) {
+        float *rs;
+        DGR_ALLOC(rs, ctx->arena, float, cin_map.n_cap);
+        DGR_CHECK(dgr_row_scale(in.ptr, in.ld, L.cin, in.relu, cin_map.n_dev, cin_map.n_cap, rs, stream));
+        row_scale = rs;
+      }
+      DGR_CHECK(dgr_conv_bf3_launch(a, L.wb, L.wb_piece, L.pieces, L.w_unscale, row_scale, ctx->num_cus, stream, &kname));
+    }
     else
       DGR_CHECK(dgr_conv_launch(a, ctx->num_cus, stream, &kname));
     if (prof) DGR_HIP_CHECK(hipEventRecord(em, stream));   // end of the MFMA phase
@@ -400,6 +448,7 @@ struct Fwd {
     }
     LayerRun &r = net->runs[li];
     r.launch = a;
+    r.row_scale = row_scale;
     r.has_reduce = km != nullptr;
     r.small_cin = small_cin;
     if (km) r.km = *km;
@@ -716,7 +765,7 @@ extern "C" int dgr_net_rerun_layer(dgr_ctx *ctx, dgr_net *net, int layer, int re
       DGR_CHECK(dgr_conv_small_cin(r.launch.in, r.launch.in_ld, r.launch.in_relu, L.cin, L.w, L.shift, r.km, r.n_out,
                                    r.n_out_cap, r.launch.out, r.launch.out_ld, nullptr));
     else if (L.wb && r.has_reduce)
-      DGR_CHECK(dgr_conv_bf3_launch(r.launch, L.wb, L.wb_piece, ctx->num_cus, nullptr));
+      DGR_CHECK(dgr_conv_bf3_launch(r.launch, L.wb, L.wb_piece, L.pieces, L.w_unscale, r.row_scale, ctx->num_cus, nullptr));
     else
       DGR_CHECK(dgr_conv_launch(r.launch, ctx->num_cus, nullptr));
     DGR_HIP_CHECK(hipEventRecord(e1, nullptr));
