@@ -56,23 +56,30 @@ struct ConvOsArgs {
 // cycles, f32-level error -- see conv_bf3.hip); false = exact-f32 MFMA (DGR_OS_F32=1, A/B measurements)
 // PM = pieces per operand: 0 = exact-f32 MFMA, 3 = bf16 x 3 (six products), 2 = f16 x 2 with exact power-of-two
 // row / layer scales (three v_mfma_f32_16x16x32_f16 per 32 input channels; conv_bf3.hip has the error analysis)
-template <int CP, int CS, int MB, int CK, int TM, int PM>
-__global__ void __launch_bounds__(CS * 4) sparse_conv_os(ConvOsArgs a) {
+// GW = groups of a tile per wave: GW = TM / 16 -> CS / 16 waves, each walks all groups of the tile (the coarse levels,
+// where an offset rarely fills more than one group); GW = 1 -> (TM / 16) x (CS / 16) waves, one group each: twice
+// the waves on the same LDS for the two finest levels, whose phases are chains of dependent LDS round trips
+template <int CP, int CS, int MB, int CK, int TM, int PM, int GW>
+__global__ void __launch_bounds__(CS * 4 * (TM / 16 / GW)) sparse_conv_os(ConvOsArgs a) {
   constexpr bool BF3 = PM != 0;
   constexpr int NP = PM == 0 ? 1 : PM;
-  constexpr int NW = CS / 16;            // waves: one 16-channel block each
-  constexpr int THREADS = 64 * NW;
   constexpr int GP = TM / 16;            // 16-row groups per tile
+  constexpr int NCW = CS / 16;           // 16-channel blocks of the slice
+  constexpr int NWR = GP / GW;           // wave rows: each owns GW consecutive groups of every tile
+  static_assert(GP % GW == 0, "groups per wave must divide the groups per tile");
+  constexpr int NW = NCW * NWR;
+  constexpr int THREADS = 64 * NW;
   constexpr int KV = 27;
   constexpr int PPT = CP / CK;           // phases per tile
   constexpr int LDA = CK + 4, LDC = CS + 4;
   constexpr int C4K = CK / 4;
-  constexpr int NCH = TM * C4K / THREADS;   // 16-byte gather pieces per thread per phase
+  constexpr int NCH = (TM * C4K + THREADS - 1) / THREADS;   // 16-byte gather pieces per thread per phase
+  constexpr bool PIECE_GUARD = TM * C4K % THREADS != 0;      // (Cin = 32 into a 64-channel slice: half the threads have none)
   constexpr int G = CK / 16;                // MFMA groups (4 MFMAs, 16 input channels) per phase
   constexpr int GT = CP / 16;               // groups per tile
   constexpr int KPW = (KV + NW - 1) / NW;   // offsets compacted per wave
-  constexpr int NGMAX = KV * (MB / 16);
-  static_assert(TM * C4K % THREADS == 0 && CP % CK == 0, "shape");
+  constexpr int NGMAX = KV * ((MB / 16 + GP - 1) / GP * GP) + GP;
+  static_assert(CP % CK == 0, "shape");
   constexpr int LDP = CK + 8;                 // BF3: bf16 elements per plane row
   constexpr int PLANE = TM * LDP;             // bf16 elements per plane
   constexpr int G32 = CK / 32;                // BF3: 32-channel k-steps per phase
@@ -91,6 +98,8 @@ __global__ void __launch_bounds__(CS * 4) sparse_conv_os(ConvOsArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cw = wave % NCW;   // this wave's 16-channel block
+  const int rb0 = (wave / NCW) * GW;   // ... and its first group of every tile
   const int n_out = *a.n_out_dev;
   const int nblocks = (n_out + MB - 1) / MB;
   // XCD-aware block order: workgroup b runs on XCD b % 8; give every XCD a contiguous range of row blocks
@@ -138,9 +147,12 @@ __global__ void __launch_bounds__(CS * 4) sparse_conv_os(ConvOsArgs a) {
   __syncthreads();
   // ---- 3. 16-row groups in ascending offset order: an offset with c pairs yields ceil(c / 16) groups; four
   //         groups (of possibly different offsets) make one 64-slot tile
+  // A tile never mixes offsets (an offset's group count is padded to a multiple of GP with empty groups): the GP
+  // waves that share a 16-channel block work on the groups of ONE offset, whose output rows are distinct, so
+  // their LDS read-modify-writes never meet
   if (wave == 0) {
     const int c = lane < KV ? cnt[lane] : 0;
-    const int ng = (c + 15) >> 4;
+    const int ng = NWR > 1 ? (((c + 15) >> 4) + GP - 1) / GP * GP : ((c + 15) >> 4);
     int x = ng;
 #pragma unroll
     for (int d = 1; d < 32; d <<= 1) {
@@ -148,7 +160,7 @@ __global__ void __launch_bounds__(CS * 4) sparse_conv_os(ConvOsArgs a) {
       if (lane >= d) x += y;
     }
     const int first = x - ng;
-    for (int u = 0; u < ng; ++u) grp[first + u] = lane | ((16 * u) << 8) | (min(16, c - 16 * u) << 16);
+    for (int u = 0; u < ng; ++u) grp[first + u] = lane | ((16 * u) << 8) | (max(0, min(16, c - 16 * u)) << 16);
     if (lane == KV - 1) {
       n_grp = x;
       for (int u = 0; u < GP; ++u) grp[x + u] = 0;   // padding groups: offset 0, no entries
@@ -166,7 +178,7 @@ __global__ void __launch_bounds__(CS * 4) sparse_conv_os(ConvOsArgs a) {
     const int t = q / PPT, cbase = (q % PPT) * CK;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int ch = tid + i * THREADS;
+      const int ch = PIECE_GUARD ? min(tid + i * THREADS, TM * C4K - 1) : tid + i * THREADS;
       const int r = ch / C4K, c = cbase + (ch % C4K) * 4;
       const int info = grp[GP * t + (r >> 4)];
       const int row = in_idx[info & 255][((info >> 8) & 255) + (r & 15)];
@@ -185,6 +197,7 @@ __global__ void __launch_bounds__(CS * 4) sparse_conv_os(ConvOsArgs a) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int ch = tid + i * THREADS;
+      if (PIECE_GUARD && ch >= TM * C4K) continue;
       i32x4 v = __builtin_bit_cast(i32x4, Gr[i]);
       v.x = max(v.x, relu_lo); v.y = max(v.y, relu_lo); v.z = max(v.z, relu_lo); v.w = max(v.w, relu_lo);
       if constexpr (!BF3) {
@@ -227,14 +240,18 @@ __global__ void __launch_bounds__(CS * 4) sparse_conv_os(ConvOsArgs a) {
       }
     }
   };
-  // A operands (weights) of step s = GP q + rb (group rb of phase q): coalesced 16-byte loads per lane, straight
+  // A operands (weights) of this wave's group in phase q: coalesced 16-byte loads per lane, straight
   // from L2 (a layer's 27 slices are at most 7 MB and shared by every workgroup)
-  const int jb = slice * NW + wave;
+  const int jb = slice * NCW + cw;
   constexpr int WREGS = BF3 ? NP * G32 : G;    // 16-byte operand registers per group
   struct WSet { uint4 v[WREGS]; };
-  auto wstep = [&](int s, WSet &w) {
-    const int q = min(s / GP, NQ - 1);
-    const int k = __builtin_amdgcn_readfirstlane(grp[GP * (q / PPT) + (s % GP)]) & 255;
+  auto wstep = [&](int qq, int u, WSet &w) {   // weights of this wave's u-th group in phase qq (clamped)
+    const int q = min(qq, NQ - 1);
+#ifdef DGR_OS_ABL_WONCE   // timing ablation: every group reads offset 0's slice (L1-resident)
+    const int k = 0;
+#else
+    const int k = __builtin_amdgcn_readfirstlane(grp[GP * (q / PPT) + rb0 + u]) & 255;
+#endif
     if constexpr (!BF3) {
       const uint4 *p = reinterpret_cast<const uint4 *>(a.w16) + (int64_t)jb * 64 + lane + (int64_t)(k * GT + (q % PPT) * G) * a.nb16 * 64;
 #pragma unroll
@@ -248,18 +265,22 @@ __global__ void __launch_bounds__(CS * 4) sparse_conv_os(ConvOsArgs a) {
     }
   };
 
-  f32x4 acc[GP];
-  WSet w[GP];   // weights of the tile's groups; each set is re-requested for the NEXT phase right after its use
-  // one 16-row group on its accumulator
-  auto mfma_group = [&](int rb, int buf) {
+  f32x4 acc[GW];
+  WSet w[GW];   // weights of this wave's groups; each set is re-requested for the NEXT phase right after its use
+  // the wave's u-th 16-row group on its accumulator
+  auto mfma_group = [&](int u, int buf) {
+    const int rb = rb0 + u;
+#ifdef DGR_OS_ABL_NOMFMA
+    if (w[u].v[0].x != 0x12345678u) return;
+#endif
     if constexpr (!BF3) {
       const float *arow = &As[buf][lane & 15][4 * (lane >> 4)];
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         const f32x4 av = *reinterpret_cast<const f32x4 *>(arow + rb * 16 * LDA + g * 16);
-        const f32x4 wv = __builtin_bit_cast(f32x4, w[rb].v[g]);
+        const f32x4 wv = __builtin_bit_cast(f32x4, w[u].v[g]);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c], av[c], acc[rb], 0, 0, 0);
+        for (int c = 0; c < 4; ++c) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c], av[c], acc[u], 0, 0, 0);
       }
     } else if constexpr (PM == 2) {
       const unsigned short *prow = Ps + buf * NP * PLANE + (rb * 16 + (lane & 15)) * LDP + 8 * (lane >> 4);
@@ -267,10 +288,10 @@ __global__ void __launch_bounds__(CS * 4) sparse_conv_os(ConvOsArgs a) {
       for (int g = 0; g < G32; ++g) {
         const f16x8 ah = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(prow + 32 * g));
         const f16x8 am = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(prow + PLANE + 32 * g));
-        const f16x8 wh = __builtin_bit_cast(f16x8, w[rb].v[2 * g]), wm = __builtin_bit_cast(f16x8, w[rb].v[2 * g + 1]);
-        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm, ah, acc[rb], 0, 0, 0);
-        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, am, acc[rb], 0, 0, 0);
-        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ah, acc[rb], 0, 0, 0);
+        const f16x8 wh = __builtin_bit_cast(f16x8, w[u].v[2 * g]), wm = __builtin_bit_cast(f16x8, w[u].v[2 * g + 1]);
+        acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm, ah, acc[u], 0, 0, 0);
+        acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, am, acc[u], 0, 0, 0);
+        acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ah, acc[u], 0, 0, 0);
       }
     } else {
       const unsigned short *prow = Ps + buf * 3 * PLANE + (rb * 16 + (lane & 15)) * LDP + 8 * (lane >> 4);
@@ -279,22 +300,22 @@ __global__ void __launch_bounds__(CS * 4) sparse_conv_os(ConvOsArgs a) {
         const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(prow + 32 * g));
         const bf16x8 am = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(prow + PLANE + 32 * g));
         const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(prow + 2 * PLANE + 32 * g));
-        const bf16x8 wh = __builtin_bit_cast(bf16x8, w[rb].v[3 * g]), wm = __builtin_bit_cast(bf16x8, w[rb].v[3 * g + 1]),
-                     wl = __builtin_bit_cast(bf16x8, w[rb].v[3 * g + 2]);
+        const bf16x8 wh = __builtin_bit_cast(bf16x8, w[u].v[3 * g]), wm = __builtin_bit_cast(bf16x8, w[u].v[3 * g + 1]),
+                     wl = __builtin_bit_cast(bf16x8, w[u].v[3 * g + 2]);
         // six products, small terms first
-        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah, acc[rb], 0, 0, 0);
-        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, al, acc[rb], 0, 0, 0);
-        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, am, acc[rb], 0, 0, 0);
-        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, ah, acc[rb], 0, 0, 0);
-        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, am, acc[rb], 0, 0, 0);
-        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah, acc[rb], 0, 0, 0);
+        acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah, acc[u], 0, 0, 0);
+        acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, al, acc[u], 0, 0, 0);
+        acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, am, acc[u], 0, 0, 0);
+        acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, ah, acc[u], 0, 0, 0);
+        acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, am, acc[u], 0, 0, 0);
+        acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah, acc[u], 0, 0, 0);
       }
     }
   };
   if (NQ > 0) {
     gather(0);
 #pragma unroll
-    for (int rb = 0; rb < GP; ++rb) wstep(rb, w[rb]);
+    for (int u = 0; u < GW; ++u) wstep(0, u, w[u]);
     land(0);
     gather(NQ > 1 ? 1 : 0);
   }
@@ -308,35 +329,35 @@ __global__ void __launch_bounds__(CS * 4) sparse_conv_os(ConvOsArgs a) {
     gather(min(q + 2, NQ - 1));          // a whole phase to arrive
     if (PPT == 1 || h == 0) {
 #pragma unroll
-      for (int rb = 0; rb < GP; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int u = 0; u < GW; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const int live = min(GP, NG - GP * t);   // groups of this tile (wave-uniform)
     // a group's weights were requested a whole phase ago (right after their previous use): the other groups'
     // MFMAs, the barrier and the next landing cover the L2 latency
 #pragma unroll
-    for (int rb = 0; rb < GP; ++rb) {
+    for (int u = 0; u < GW; ++u) {
+      const int n_rows = __builtin_amdgcn_readfirstlane(grp[GP * t + rb0 + u]) >> 16;   // wave-uniform
       __builtin_amdgcn_sched_barrier(0);
-      if (rb == 0 || live > rb) mfma_group(rb, q & 1);
-      wstep(GP * (q + 1) + rb, w[rb]);
+      if (u == 0 || n_rows > 0) mfma_group(u, q & 1);
+      wstep(q + 1, u, w[u]);
     }
     if (PPT == 1 || h == PPT - 1) {
-      // tile done: lane = pair (lane & 15) of group rb, channels 16 wave + 4 (lane >> 4) .. +3 of the slice
+      // tile done: lane = pair (lane & 15) of its group, channels 16 cw + 4 (lane >> 4) .. +3 of the slice
 #pragma unroll
-      for (int rb = 0; rb < GP; ++rb) {
-        const int info = grp[GP * t + rb];
+      for (int u = 0; u < GW; ++u) {
+        const int info = grp[GP * t + rb0 + u];
 #ifdef DGR_OS_ABL_NORMW
-        if ((lane & 15) < (info >> 16) && acc[rb].x == 123.456f) {
+        if ((lane & 15) < (info >> 16) && acc[u].x == 123.456f) {
 #else
         if ((lane & 15) < (info >> 16)) {
 #endif
           const int e = ((info >> 8) & 255) + (lane & 15);
-          float *p = &acc_s[out_loc[info & 255][e]][16 * wave + 4 * (lane >> 4)];
+          float *p = &acc_s[out_loc[info & 255][e]][16 * cw + 4 * (lane >> 4)];
           f32x4 v = *reinterpret_cast<f32x4 *>(p);
           if constexpr (PM == 2) {
             const float f = __builtin_bit_cast(float, 0x7f000000u - __builtin_bit_cast(uint32_t, in_scale[info & 255][e])) * a.w_unscale;
-            v += acc[rb] * f;
+            v += acc[u] * f;
           } else {
-            v += acc[rb];
+            v += acc[u];
           }
           *reinterpret_cast<f32x4 *>(p) = v;
         }
@@ -359,15 +380,20 @@ __global__ void __launch_bounds__(CS * 4) sparse_conv_os(ConvOsArgs a) {
 
 template <int CP, int CS, int MB, int CK, int TM>
 static int launch_os(const ConvOsArgs &ka, int64_t n_out_cap, hipStream_t stream) {
+  // one group per wave where it measured faster (8 clouds of 27 k voxels: 32 -> 32 at level 0 147 -> 124 us,
+  // 64 -> 64 at levels 0 / 1 108 -> 99 us); with Cin >= 128 (several phases per tile) or fewer rows per block the
+  // extra phases of the padded group list cost more than the added waves hide (136 -> 178 us at 256 -> 64)
+  constexpr int GW = (MB >= 64 && CP <= 64) ? 1 : TM / 16;
   int64_t blocks = dgr_ceil_div(n_out_cap, MB);
   blocks = (blocks + 7) / 8 * 8;
   dim3 grid((unsigned)blocks, (unsigned)(ka.cout / CS));
+  constexpr int threads = CS * 4 * (TM / 16 / GW);
   if (ka.wb3 && ka.row_scale)
-    sparse_conv_os<CP, CS, MB, CK, TM, 2><<<grid, CS * 4, 0, stream>>>(ka);
+    sparse_conv_os<CP, CS, MB, CK, TM, 2, GW><<<grid, threads, 0, stream>>>(ka);
   else if (ka.wb3)
-    sparse_conv_os<CP, CS, MB, CK, TM, 3><<<grid, CS * 4, 0, stream>>>(ka);
+    sparse_conv_os<CP, CS, MB, CK, TM, 3, GW><<<grid, threads, 0, stream>>>(ka);
   else
-    sparse_conv_os<CP, CS, MB, CK, TM, 0><<<grid, CS * 4, 0, stream>>>(ka);
+    sparse_conv_os<CP, CS, MB, CK, TM, 0, GW><<<grid, threads, 0, stream>>>(ka);
   DGR_LAUNCH_CHECK();
   return DGR_OK;
 }
