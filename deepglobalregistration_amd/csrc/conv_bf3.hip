@@ -618,26 +618,34 @@ static int launch_bf3(const ConvBf3Args &ka, int64_t tile_bound, int num_cus, hi
   return DGR_OK;
 }
 
-// one wave per row: largest |x| (after the pending ReLU) -> the power of two that moves it into [2^14, 2^15)
+// LPR = lanes per row (16 bytes each; wider rows loop): largest |x| (after the pending ReLU) -> the power of two that
+// moves it into [2^14, 2^15).  A wave covers 64 / LPR rows at a time.
+template <int LPR>
 __global__ void __launch_bounds__(256) row_scale_kernel(const float *__restrict__ in, int in_ld, int cin, int relu,
                                                         const int32_t *__restrict__ n_dev, float *__restrict__ out) {
+  constexpr int RPW = 64 / LPR;   // rows per wave
   const int lane = threadIdx.x & 63;
+  const int sub = lane / LPR, l = lane % LPR;
   const int n = *n_dev;
   const int relu_lo = relu ? 0 : (int)0x80000000;
-  for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += (int64_t)gridDim.x * 4) {
-    const float *row = in + r * in_ld;
+  const int64_t stride = (int64_t)gridDim.x * 4 * RPW;
+  for (int64_t r0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW; r0 < n; r0 += stride) {
+    const int64_t r = r0 + sub;
     uint32_t mx = 0;
-    for (int c = lane * 4; c < cin; c += 256) {
-      const i32x4 v = __builtin_bit_cast(i32x4, *reinterpret_cast<const f32x4 *>(row + c));
+    if (r < n) {
+      const float *row = in + r * in_ld;
+      for (int c = l * 4; c < cin; c += LPR * 4) {
+        const i32x4 v = __builtin_bit_cast(i32x4, *reinterpret_cast<const f32x4 *>(row + c));
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int vi = v[u];
-        mx = max(mx, (uint32_t)max(vi, relu_lo) & 0x7fffffffu);   // |x| as an integer: monotone in the magnitude
+        for (int u = 0; u < 4; ++u) {
+          const int vi = v[u];
+          mx = max(mx, (uint32_t)max(vi, relu_lo) & 0x7fffffffu);   // |x| as an integer: monotone in the magnitude
+        }
       }
     }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
-    if (lane == 0) {
+    for (int d = LPR / 2; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+    if (l == 0 && r < n) {
       // biased exponent clamped to [20, 240]: scale = 2^(14 - (e - 127)); zero / denormal rows get a finite scale
       const uint32_t e = min(max(mx >> 23, 20u), 240u);
       out[r] = mx == 0 ? 1.f : __builtin_bit_cast(float, (268u - e) << 23);
@@ -647,11 +655,18 @@ __global__ void __launch_bounds__(256) row_scale_kernel(const float *__restrict_
 
 int dgr_row_scale(const float *in, int in_ld, int cin, int relu, const int32_t *n_dev, int64_t n_cap, float *out,
                   hipStream_t stream) {
-  DGR_REQUIRE((cin & 3) == 0 && (in_ld & 3) == 0, "row scale: channel count and row stride must be multiples of 4");
-  int64_t grid = dgr_ceil_div(n_cap, 4);
-  if (grid > 8192) grid = 8192;
+  DGR_REQUIRE((cin & 3) == 0 && (in_ld & 3) == 0 && cin >= 4, "row scale: channel count and row stride must be multiples of 4");
+  const int lpr = cin >= 256 ? 64 : cin >= 128 ? 32 : cin >= 64 ? 16 : cin >= 32 ? 8 : 4;   // power of two: shuffle tree
+  int64_t grid = dgr_ceil_div(n_cap, 4 * (64 / lpr));
+  if (grid > 4096) grid = 4096;
   if (grid < 1) grid = 1;
-  row_scale_kernel<<<(int)grid, 256, 0, stream>>>(in, in_ld, cin, relu, n_dev, out);
+  switch (lpr) {
+    case 64: row_scale_kernel<64><<<(int)grid, 256, 0, stream>>>(in, in_ld, cin, relu, n_dev, out); break;
+    case 32: row_scale_kernel<32><<<(int)grid, 256, 0, stream>>>(in, in_ld, cin, relu, n_dev, out); break;
+    case 16: row_scale_kernel<16><<<(int)grid, 256, 0, stream>>>(in, in_ld, cin, relu, n_dev, out); break;
+    case 8: row_scale_kernel<8><<<(int)grid, 256, 0, stream>>>(in, in_ld, cin, relu, n_dev, out); break;
+    default: row_scale_kernel<4><<<(int)grid, 256, 0, stream>>>(in, in_ld, cin, relu, n_dev, out); break;
+  }
   DGR_LAUNCH_CHECK();
   return DGR_OK;
 }
