@@ -337,7 +337,7 @@ __global__ void __launch_bounds__(256, 2) sparse_conv_bf16x3(ConvBf3Args a) {
 // the product-row stores; waiting for a weight fragment therefore also waits for every OLDER operation: for gathers
 // issued only ~4 k-steps earlier (their long prefetch distance never materialises) and, after a tile's epilogue,
 // for its 16 stores.  With the matrix work halved by the two-piece split the kernel ran at the speed of those
-// latencies (ablations on the 256 -> 256 block3 layer: all MFMAs removed 2.19 -> 2.02 ms, stores removed -> 1.46 ms).
+// latencies (ablations on the 256 -> 256 block4 layers: all MFMAs removed 2.19 -> 2.02 ms, stores removed -> 1.46 ms).
 // Here each latency domain lives in waves of its own, with their own counters:
 //   * waves 0..3 (compute): weight ring (L2) -> MFMAs on the landed f16 planes -> raw accumulators into an LDS
 //     stage.  Their only memory operations are the weight loads, four per k-step, so every wait count is static.
