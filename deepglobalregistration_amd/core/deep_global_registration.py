@@ -245,7 +245,8 @@ class DeepGlobalRegistration:
         gate (status 1) are re-estimated by the RANSAC safeguard over their putative correspondences and get
         status 3 -- like `register()` and the reference, a pair whose SVD failed (status 2) keeps T = identity
         (:295-300 never reaches the safeguard branch); with `icp`, every pair is finally refined by
-        point-to-point ICP -- the two Open3D steps of `register()` (:302-322), run per pair after the batched call."""
+        point-to-point ICP -- the two Open3D steps of `register()` (:302-322), both inside the same library call
+        (dgr_params.safeguard / use_icp)."""
         T, status, stats = ops.register_batch(
             self.fcgf_model._handle(), self.inlier_model._handle(), coords0, xyz0, off0, coords1, xyz1, off1,
             self.voxel_size, clip_weight_thresh=self.clip_weight_thresh,

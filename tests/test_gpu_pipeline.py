@@ -173,6 +173,30 @@ def test_collated_batch_and_batched_knn(setup):
     assert T.shape == (len(pairs), 4, 4) and status.tolist() == [1] * len(pairs)
     with pytest.raises(ValueError):
         dgr.register_collated(dict(batch, len_batch=[[1, 1]]))
+    # non-degenerate: a third of the rows carry ground-truth matches, logits +-4 from the ground truth -> every pair registers, the
+    # collated call returns what the per-pair calls return (rows of different pairs never interact) and the pose
+    from deepglobalregistration_amd import synth
+    ov, fl, off1 = [], [], 0
+    for p, (a, b, T_gt) in enumerate(pairs):
+        gt = synth.gt_correspondences(x0[p], x1[p], T_gt, VOXEL)
+        keep = np.random.default_rng(p).random(len(gt)) < 0.7
+        ov.append(np.where((gt >= 0) & keep, gt + off1, -1))
+        fl.append(np.where((gt >= 0) & keep, 4.0, -4.0).astype(np.float32))
+        off1 += len(x1[p])
+    ov_d, fl_d = torch.from_numpy(np.concatenate(ov)).cuda(), torch.from_numpy(np.concatenate(fl)).cuda()
+    T, status, stats = dgr.register_collated(batch, forced_logits=fl_d, override_idx1=ov_d)
+    assert status.tolist() == [0] * len(pairs)
+    o1 = 0
+    for p, (a, b, T_gt) in enumerate(pairs):
+        assert rot_angle_deg(T[p, :3, :3], T_gt[:3, :3]) < 1.0 and np.linalg.norm(T[p, :3, 3] - T_gt[:3, 3]) < 0.05
+        ca = c0[p].clone(); ca[:, 0] = 0
+        cb = c1[p].clone(); cb[:, 0] = 0
+        ovp = torch.from_numpy(np.where(ov[p] >= 0, ov[p] - o1, -1)).cuda()
+        T1, s1, st1 = dgr.register_voxelized(ca, torch.from_numpy(x0[p]).cuda(), [0, len(x0[p])], cb,
+                                             torch.from_numpy(x1[p]).cuda(), [0, len(x1[p])],
+                                             forced_logits=torch.from_numpy(fl[p]).cuda(), override_idx1=ovp)
+        assert s1.tolist() == [0] and np.array_equal(T1[0], T[p]) and int(st1[0, 0]) == int(stats[p, 0])
+        o1 += len(x1[p])
     # batched 1-NN = per-pair 1-NN, shifted by the pair's first row when concatenated
     rng = np.random.default_rng(0)
     lens = [[700, 900], [1300, 1100]]
