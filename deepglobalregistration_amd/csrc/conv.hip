@@ -3,7 +3,12 @@
 // Replaces the ME.MinkowskiConvolution / MinkowskiConvolutionTranspose forward invoked by every
 // conv of ResUNetBN2C (model/resunet.py:598-649, model/residual_block.py:15-80).
 //
-// Phase 1 (sparse_conv_mfma): the kernel map lists pairs (in, out) per kernel offset k ("rule").  A
+// Since round 2 this file holds the exact-f32 MFMA kernel of the layers the split-operand kernels do not cover
+// (k = 1 convs, C_out = 64 in the 6-D net, odd widths; all wide layers with DGR_CONV_F32=1), the reduction pass
+// shared with conv_bf3.hip, and the FCGF conv1 kernels; the wide 6-D layers run in conv_bf3.hip and every K = 27
+// conv of the 3-D net in conv_os.hip.
+//
+// Phase 1 (sparse_conv_mfma_v2): the kernel map lists pairs (in, out) per kernel offset k ("rule").  A
 // tile is <= 64 pairs of ONE rule: the 64 gathered input rows [64 x Cin] are staged in LDS once and
 // multiplied with the rule's dense [Cin x Cout] slice on the matrix cores
 // (v_mfma_f32_32x32x2_f32: exact f32, bitwise an fma chain); the product rows go to Y[pair, Cout]

@@ -1,27 +1,31 @@
 // Output-stationary fused sparse convolution for the 3-D (FCGF) net on gfx950.
 // Replaces, for D = 3, the ME.MinkowskiConvolution / MinkowskiConvolutionTranspose forward of every
 // K = 27 conv of ResUNetBN2C (model/resunet.py:598-649, model/residual_block.py:15-80) -- same
-// arithmetic as the rule-major path in conv.hip (per pair an exact-f32 MFMA product row, summed per
-// output row in ascending offset order on top of the folded batch-norm shift and the residual), but
-// with NO product rows in HBM and NO reduction pass:
+// arithmetic as the rule-major path (per pair a product row, summed per output row in ascending offset
+// order on top of the folded batch-norm shift and the residual), but with NO product rows in HBM and NO
+// reduction pass:
 //
-//   * a workgroup owns DGR_OS_ROWS = 64 consecutive output rows and a slice of CS output channels; the
-//     rows' accumulators [64 x CS] live in LDS for the whole layer and are written once at the end;
+//   * a workgroup owns MB (64 | 32 | 16 by level) consecutive output rows and a slice of CS output channels;
+//     the rows' accumulators [MB x CS] live in LDS for the whole layer and are written once at the end;
 //   * the only kernel-map structure is the dense neighbour table nbr[27][n_pad] (kmap.hip): per offset k
-//     the 64 entries of the block are ballot-compacted into a list of (input row, local output row);
-//   * per offset one tile: the <= 64 gathered input rows go through a double-buffered LDS tile
-//     (requested one phase ahead, landed one phase later: one barrier per phase) and are multiplied
-//     with W[k] by v_mfma_f32_16x16x4_f32 (exact f32).  A wave owns 16 output channels and walks the
-//     tile's 16-row groups, so a tile costs ceil(count / 16) row groups instead of a full 64-row MFMA
-//     tile -- the map's fill (47 % of a 64-row block per offset on 3DMatch-shaped clouds) does not turn
-//     into idle matrix cycles; operands are swapped (D = W^T In^T) so that a lane ends up with one pair
-//     and 4 consecutive channels and the accumulation into the LDS row is one 16-byte read-modify-write;
-//   * channel ranges are exclusive per wave, so the LDS accumulation needs no atomics and no extra
+//     the block's entries are ballot-compacted into a list of (input row, local output row);
+//   * 16-row groups -- an offset with c pairs yields ceil(c / 16) -- are packed into tiles of TM / 16 groups;
+//     the gathered input rows go through a double-buffered LDS tile (requested one phase ahead, landed
+//     one phase later: one barrier per phase) and are multiplied with W[k]; the map's fill (47 % of a
+//     64-row block per offset on 3DMatch-shaped clouds) does not turn into idle matrix cycles; operands
+//     are swapped (D = W^T In^T) so that a lane ends up with one pair and 4 consecutive channels and the
+//     accumulation into the LDS row is one 16-byte read-modify-write;
+//   * channel ranges are exclusive per wave (and the waves that share a channel range work on groups of
+//     ONE offset, whose output rows are distinct), so the LDS accumulation needs no atomics and no extra
 //     barrier, and the sum order is ascending k: results do not depend on scheduling (bit-reproducible).
 //
-// Weight layout (net.hip, per layer): W16[k][g][jb][lane][c] = W_folded[k][16 g + 4 (lane >> 4) + c][16 jb + (lane & 15)]
-// (g = Cin_pad/16 groups, jb = Cout/16 channel blocks): one coalesced 16-byte load per lane = the A
-// operands of 4 consecutive MFMAs.
+// Arithmetic (PM): 2 = every f32 operand as two f16 pieces under exact power-of-two row / layer scales, three
+// v_mfma_f32_16x16x32_f16 per 32 input channels (default; error analysis in conv_bf3.hip); 3 = three exact
+// bf16 pieces, six products (DGR_CONV_BF3=1); 0 = v_mfma_f32_16x16x4_f32 on the f32 operands (DGR_OS_F32=1).
+//
+// Weight layouts (net.hip, per layer): split pieces WB[piece][k][s][jb][lane] = 8 halves =
+// W_folded[k][32 s + 8 (lane >> 4) + e][16 jb + (lane & 15)]; f32: W16[k][g][jb][lane][c] =
+// W_folded[k][16 g + 4 (lane >> 4) + c][16 jb + (lane & 15)] -- one coalesced 16-byte load per lane either way.
 #include <stdlib.h>
 
 #include <type_traits>
