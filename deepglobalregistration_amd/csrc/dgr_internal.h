@@ -184,8 +184,8 @@ struct DgrConvLaunch {
   int64_t tile_bound;                                        // host upper bound on the tile count (0 = unknown)
 };
 int dgr_conv_launch(const DgrConvLaunch &a, int num_cus, hipStream_t stream, const char **kernel_name = nullptr);
-// wide layers (Cout >= 128): the same phase 1 on the bf16 matrix pipe with every f32 operand split exactly into
-// three bf16 pieces (conv_bf3.hip); wb = the layer's pre-split weights, piece_stride in 16-byte units
+// wide layers (Cout >= 128): the same phase 1 on the f16 / bf16 matrix pipe with every f32 operand split into
+// pieces (conv_bf3.hip); wb = the layer's pre-split weights, piece_stride in 16-byte units
 bool dgr_conv_bf3_supported(int cin_pad, int cin, int cout);
 // pieces = 3: bf16 x 3 (six products); pieces = 2: f16 x 2 (three products) with the input's power-of-two row
 // scales (dgr_row_scale) and the inverse of the layer's weight scale
