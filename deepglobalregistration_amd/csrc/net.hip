@@ -391,7 +391,8 @@ struct Fwd {
       o.w16 = L.w16; o.shift = L.shift;
       o.wb3 = L.w16b; o.piece_stride = L.w16b_piece;
       o.pieces = L.pieces; o.w_unscale = L.w_unscale;
-      if (L.w16b && L.pieces == 2 && !getenv("DGR_OS_F32")) {
+      static const bool os_f32 = getenv("DGR_OS_F32") != nullptr;   // (conv_os.hip reads the same switch)
+      if (L.w16b && L.pieces == 2 && !os_f32) {
         float *rs;
         DGR_ALLOC(rs, ctx->arena, float, cin_map.n_cap);
         DGR_CHECK(dgr_row_scale(in.ptr, in.ld, L.cin, in.relu, cin_map.n_dev, cin_map.n_cap, rs, stream));
