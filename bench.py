@@ -202,8 +202,8 @@ def launch_check(args, rank, world, backend):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--pairs-per-step', type=int, default=4, help='pairs per batch (one dgr_register_batch)')
     ap.add_argument('--total-pairs', type=int, default=0, help='strong-scaling mode: this many pairs in total, dealt '
                     'over the ranks by cost; a step = one pass over all of them (BASELINE configs[3]: 512)')
