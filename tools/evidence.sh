@@ -5,7 +5,7 @@
 R=$PWD; O=$R/gpurun_out/final; mkdir -p $O; rm -rf $O/*
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py"
-timeout 900 $B > $O/bench_c1_default.json 2> $O/bench_c1_default.err
+timeout 900 $B --steps 20 --warmup 3 > $O/bench_c1_default.json 2> $O/bench_c1_default.err
 timeout 300 $B --streams 1 --pairs-per-step 4 --no-parity > $O/bench_c1_s1_b4.json 2> $O/bench_c1_s1_b4.err
 timeout 300 $B --streams 1 --pairs-per-step 1 --no-parity > $O/bench_c1_s1_b1.json 2> $O/bench_c1_s1_b1.err
 timeout 600 $B --kind outdoor --n-raw 120000 --voxel 0.3 --conv1-ks 5 > $O/bench_c3.json 2> $O/bench_c3.err
