@@ -242,3 +242,34 @@ def test_ragged_and_tiny_batches(setup):
     T1, s1, st1 = dgr.register_voxelized(ca, xa, [0, len(xa)], cb, xb, [0, len(xb)])
     assert s1[0] == status[2]
     np.testing.assert_allclose(T1[0], T[2], atol=1e-4)
+
+
+def test_checkpoint_file_legacy_keys_and_kernel_shapes(tmp_path):
+    """`__init__` (:88-131): a checkpoint FILE (torch.save), the legacy un-prefixed config keys (:104-112) and
+    kernel-volume-1 kernels stored as [1, Cin, Cout] (MinkowskiEngine 0.4) give the same networks as the in-memory
+    dict with [Cin, Cout] kernels: identical registration of one pair, bit for bit."""
+    from deepglobalregistration_amd import synth
+    from deepglobalregistration_amd.core.deep_global_registration import DeepGlobalRegistration
+    ck = synth.synth_checkpoint(seed=3, voxel_size=VOXEL, feat_conv1_kernel_size=5)
+    legacy = {'config': dict(ck['config']), 'state_dict': {}, 'state_dict_inlier': {}}
+    cfg = legacy['config']
+    cfg['model'], cfg['model_n_out'], cfg['conv1_kernel_size'] = (cfg.pop('feat_model'), cfg.pop('feat_model_n_out'),
+                                                                  cfg.pop('feat_conv1_kernel_size'))
+    reshaped = 0
+    for part in ('state_dict', 'state_dict_inlier'):
+        for k, v in ck[part].items():
+            t = torch.as_tensor(v)
+            if k.endswith('.kernel') and t.dim() == 2:
+                t = t[None]                       # [Cin, Cout] -> [1, Cin, Cout]
+                reshaped += 1
+            legacy[part][k] = t
+    assert reshaped >= 2                          # conv1_tr / final of both nets
+    path = tmp_path / 'ckpt.pth'
+    torch.save(legacy, str(path))
+    a = DeepGlobalRegistration({'weights': ck, 'use_icp': False}, torch.device('cuda'))
+    b = DeepGlobalRegistration({'weights': str(path), 'use_icp': False}, torch.device('cuda'))
+    x0, x1, _ = synth.synth_pair(5, n_raw=6000)
+    Ta, Tb = a.register(x0, x1), b.register(x0, x1)
+    assert a.last_status == b.last_status and np.array_equal(Ta, Tb)
+    with pytest.raises(ValueError):
+        DeepGlobalRegistration({'weights': 3}, torch.device('cuda'))
