@@ -158,3 +158,21 @@ def test_batched_call_with_safeguard_and_icp():
                                             forced_logits=forced,
                                             override_idx1=torch.from_numpy(np.concatenate(ov)).cuda())
     assert status0.tolist() == [1, 1] and np.array_equal(T0[0], np.eye(4))
+
+
+def test_register_equals_the_fused_call():
+    """`register()` (stage by stage, the reference's own control flow, :238-324) and ONE `dgr_register_batch` with
+    the safeguard / ICP flags return the same transformation for the same pair -- gate, safeguard RANSAC (same
+    counter-based sampler and seed) and ICP included."""
+    from deepglobalregistration_amd import synth
+    from deepglobalregistration_amd.core.deep_global_registration import DeepGlobalRegistration
+    dgr = DeepGlobalRegistration({'weights': synth.synth_checkpoint(0)}, torch.device('cuda'))
+    x0, x1, _ = synth.synth_pair(2, 20000)
+    dgr.last_status = None
+    T = dgr.register(x0, x1)
+    assert dgr.last_status in ('ok', 'safeguard')  # untrained weights: whichever branch the gate takes, both calls take it
+    xa, ca, _ = dgr.preprocess(x0)
+    xb, cb, _ = dgr.preprocess(x1)
+    Tf, status, _ = dgr.register_voxelized(ca, xa, [0, len(xa)], cb, xb, [0, len(xb)], safeguard=True, icp=True)
+    assert status.tolist() == [3 if dgr.last_status == 'safeguard' else 0]
+    assert np.abs(Tf[0] - T).max() < 1e-6          # the batched call returns float32 at the ABI
