@@ -42,6 +42,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 struct ConvBf3Args {
   const float *in;
   float *y;               // [pairs, cout] per-pair product rows
+  float *y_scratch;       // a few rows nobody reads (fixed-count stores of the wave-specialised kernel)
   const uint4 *wb;        // three pieces, each [K][CP/16][cout/32][64] uint4
   const int32_t *pair_in, *tile_ptr;
   const int4 *tile_desc;
@@ -393,8 +394,20 @@ __global__ void __launch_bounds__(512, 1) sparse_conv_f16x2_ws(ConvBf3Args a, co
     const int ptid = tid - 64 * WN;
     const bool pub = wave == WN;   // wave 4, lane = tile row: keeps the rings filled
     int idx_reg = -1;
+    bool idx_ok = false;
     float sc_reg = 1.f;
     int4 d_reg = make_int4(0, 0, 0, 0);
+#ifdef DGR_WS_STATIC_STORES
+    {
+      const int4 d8 = desc(AHEAD);
+      idx_reg = a.pair_in[d8.y + min(lane, max(d8.z - 1, 0))];
+      idx_ok = AHEAD < n_my && lane < d8.z;
+      d_reg = desc(AHEAD + 1);
+      const int4 d7 = desc(AHEAD - 1);
+      const int v7 = (AHEAD - 1 < n_my && lane < d7.z) ? a.pair_in[d7.y + lane] : -1;
+      sc_reg = a.row_scale[max(v7, 0)];
+    }
+#endif
     if (pub) {
       int last = -1;
       for (int j = 0; j < AHEAD; ++j) {
@@ -474,6 +487,27 @@ __global__ void __launch_bounds__(512, 1) sparse_conv_f16x2_ws(ConvBf3Args a, co
       }
 #endif
     };
+    // the same for rows [h ROWS_SP, (h + 1) ROWS_SP) with a FIXED number of store instructions (rows past the tile's
+    // end go to a scratch row): the compiler's vmcnt bookkeeping stays exact across the phase instead of falling back
+    // to the conservative count that a loop of unknown trip count forces on every later wait of this wave
+    auto store_rows_static = [&](int t, int h) {
+      const int4 d = desc(max(t, 0));
+      const float *sc = scalebuf[t & (RING - 1)];
+      const float(*st)[LDS_ST] = stage[NSTG == 2 ? (t & 1) : 0];
+      const int c4 = (ptid % CPR) * 4;
+      const int r1 = t < 0 ? 0 : min((h + 1) * ROWS_SP, d.z);
+      constexpr int NPASS = (ROWS_SP + RPP - 1) / RPP;
+#pragma unroll
+      for (int i = 0; i < NPASS; ++i) {
+        const int r = h * ROWS_SP + ptid / CPR + i * RPP;
+        const bool ok = r < r1;
+        const int rr = min(r, TM - 1);
+        f32x4 v = *reinterpret_cast<const f32x4 *>(&st[rr][c4]);
+        v *= dgr_inv_pow2(sc[rr]) * a.w_unscale;
+        float *dst = ok ? a.y + (int64_t)(d.y + r) * a.cout + c4 : a.y_scratch + (ptid / CPR) * a.cout + c4;
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(dst));
+      }
+    };
 #pragma unroll
     for (int j = 0; j < NSET; ++j) gather(j, G[j], okm[j]);
     land(0, G[0], okm[0]); gather(NSET, G[0], okm[0]);
@@ -482,6 +516,19 @@ __global__ void __launch_bounds__(512, 1) sparse_conv_f16x2_ws(ConvBf3Args a, co
     // phase q: land phase q + 2 (requested four phases ago), request phase q + LEAD into the freed set
     auto pphase = [&](int q, f32x4 *Gs, uint32_t &ok) {
       const int t = q / PPT, h = q % PPT;
+#ifdef DGR_WS_STATIC_STORES
+      if (h == 0) {   // every producer wave loads (static op counts); only the publishing wave writes the rings
+        const int idx_pub = idx_ok ? idx_reg : -1;   // (the select happens here, a tile after the load)
+        if (pub) {
+          idxbuf[(t + AHEAD) & (RING - 1)][lane] = idx_pub;
+          scalebuf[(t + AHEAD - 1) & (RING - 1)][lane] = sc_reg;
+        }
+        sc_reg = a.row_scale[max(idx_pub, 0)];
+        idx_reg = a.pair_in[d_reg.y + min(lane, max(d_reg.z - 1, 0))];
+        idx_ok = t + AHEAD + 1 < n_my && lane < d_reg.z;
+        d_reg = desc(t + AHEAD + 2);
+      }
+#else
       if (pub && h == 0) {   // values loaded at the previous event have had at least a phase
         idxbuf[(t + AHEAD) & (RING - 1)][lane] = idx_reg;
         scalebuf[(t + AHEAD - 1) & (RING - 1)][lane] = sc_reg;
@@ -489,9 +536,14 @@ __global__ void __launch_bounds__(512, 1) sparse_conv_f16x2_ws(ConvBf3Args a, co
         idx_reg = (t + AHEAD + 1 < n_my && lane < d_reg.z) ? a.pair_in[d_reg.y + lane] : -1;
         d_reg = desc(t + AHEAD + 2);
       }
+#endif
       land(q + 2, Gs, ok);
       gather(q + LEAD, Gs, ok);
+#ifdef DGR_WS_STATIC_STORES
+      if (h < NSP) store_rows_static(t - 1, h);   // t = 0: every row goes to the scratch row
+#else
       if (t > 0 && h < NSP) store_rows(t - 1, h * ROWS_SP, (h + 1) * ROWS_SP);
+#endif
       __syncthreads();
     };
     for (int q = 0; q < NQ; q += NSET) {   // set of phase p = p % 4: static register indexing
@@ -684,7 +736,7 @@ int dgr_conv_bf3_launch(const DgrConvLaunch &a, const void *wb, int64_t piece_st
   DGR_REQUIRE(pieces == 3 || (pieces == 2 && row_scale), "split-operand conv: 2 pieces need the input's row scales");
   DGR_REQUIRE((a.in_ld & 3) == 0, "bf16x3 conv: input row stride must be a multiple of 4");
   ConvBf3Args ka;
-  ka.in = a.in; ka.y = a.y; ka.wb = static_cast<const uint4 *>(wb); ka.piece_stride = piece_stride;
+  ka.in = a.in; ka.y = a.y; ka.y_scratch = a.y_scratch; ka.wb = static_cast<const uint4 *>(wb); ka.piece_stride = piece_stride;
   ka.pair_in = a.pair_in; ka.tile_ptr = a.tile_ptr; ka.tile_desc = a.tile_desc;
   ka.in_ld = a.in_ld; ka.in_relu = a.in_relu; ka.cin = a.cin; ka.cout = a.cout; ka.K = a.K;
   ka.row_scale = row_scale; ka.w_unscale = w_unscale;

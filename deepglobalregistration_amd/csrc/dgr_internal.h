@@ -175,6 +175,7 @@ struct DgrConvLaunch {
   float *out;   // identity maps only: [n_out, out_ld] written directly (product + shift)
   int out_ld;
   float *y;            // non-identity maps: per-pair product rows [pairs, cout]
+  float *y_scratch = nullptr;   // >= 64 rows nobody reads (fixed-count stores of the wave-specialised kernel)
   const float *shift;  // identity maps: per-channel shift (may be null)
   const float *w;  // MFMA-B-fragment tiled weights of this layer
   int cin, cin_pad, cout, cout_pad, K;

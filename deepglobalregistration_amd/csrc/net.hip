@@ -340,6 +340,7 @@ struct Fwd {
   bool prof;
 
   float *ybuf = nullptr;  // per-pair product rows, sized for the largest layer of this forward
+  float *yscratch = nullptr;   // 64 rows nobody reads
 
   // one conv: Y[pair] = in[pair_in] W[k] (MFMA), then out[o] = shift (+res) + sum of the row's Y rows
   int conv(int li, const Tensor &in, const DgrKernelMap *km, bool swapped, int lvl_in, int lvl_out,
@@ -349,7 +350,7 @@ struct Fwd {
     DgrConvLaunch a;
     a.in = in.ptr; a.in_ld = in.ld; a.in_relu = in.relu;
     a.out = out.ptr; a.out_ld = out.ld;
-    a.y = ybuf; a.shift = L.shift;
+    a.y = ybuf; a.y_scratch = yscratch; a.shift = L.shift;
     a.w = L.w;
     a.cin = L.cin; a.cin_pad = L.cin_pad; a.cout = L.cout; a.cout_pad = L.cout_pad; a.K = L.K;
     if (km && ms.use_nbr) {
@@ -496,6 +497,7 @@ int dgr_resunet_forward_impl(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, 
     for (int l = 0; l < 4; ++l) need = std::max(need, m.same[l].pair_cap * same_c[l]);
     for (int l = 0; l < 3; ++l) need = std::max(need, m.down[l].pair_cap * down_c[l]);
     DGR_ALLOC(f.ybuf, A, float, need);
+    DGR_ALLOC(f.yscratch, A, float, 64 * 256);
   }
   const DgrMapSet &ms = f.ms;
   const int64_t n1 = ms.cm[0].n_cap, n2 = ms.cm[1].n_cap, n4 = ms.cm[2].n_cap, n8 = ms.cm[3].n_cap;
