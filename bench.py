@@ -36,11 +36,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
-PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md, dense (f16 = bf16 rate)
-# The conv kernels compute f32 results on the f16 matrix pipe: every f32 operand is split into two f16 pieces under
-# an exact power-of-two scale and a MAC costs three v_mfma_*_f16 products (conv_bf3.hip).  `roofline.peak` stays the
-# f32 MFMA peak (the dtype the path computes in), so `frac` can exceed 1; `roofline.pipe` prices the same launches
-# against the pipe they actually run on (3 x the algorithmic FLOP over the dense f16 peak).
+PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md, dense v_mfma_f32_32x32x16_f16 / _bf16
+# The conv kernels compute f32-level results on the f16 matrix pipe: every f32 operand is split into two f16 pieces
+# under an exact power-of-two scale and a MAC costs THREE v_mfma_*_f16 products (conv_bf3.hip, conv_os.hip).  The
+# headline `roofline` therefore prices the dominant kernel against the pipe it issues on: achieved = 3 x the
+# algorithmic FLOP/s, peak = the dense f16 MFMA peak.  `roofline.f32_view` is the same launches counted as plain f32
+# MACs against the f32 MFMA peak (what an exact-f32 kernel would be priced against); it can exceed 1 and is NOT the
+# roofline fraction.  With DGR_EXACT_F32=1 the kernels issue v_mfma_f32_*_f32 and the f32 peak is the headline.
 PRODUCTS_PER_MAC = 3
 PEAK_HBM_GBPS = 8000.0          # spec
 
@@ -110,10 +112,12 @@ def roofline_time_s(s):
 # oracle timed as the reported CPU baseline.  The oracle is the checker, never the measured product.
 # ----------------------------------------------------------------------------------------------
 def oracle_parity_and_baseline(ck, args, pair0, do_baseline):
-    """pair0 = dict(xyz0, coords0, xyz1, coords1 [numpy, batch column 0], idx1 [local], F0, F1, logit, forced).
+    """pair0 = dict(xyz0, coords0, xyz1, coords1 [numpy, batch column 0], idx1 [local], F0, F1, logit, forced, device).
     Returns (parity dict, cpu_baseline dict | None)."""
-    from oracle import knn as oknn, pipeline as opipe, registration as oreg, resunet as oresunet
-    threads = max(1, min(16, os.cpu_count() or 1))
+    from oracle import knn as oknn, parity as oparity, pipeline as opipe, registration as oreg, resunet as oresunet
+    from deepglobalregistration_amd import ops
+    found = os.cpu_count() or 1
+    threads = max(1, min(16, found))   # the oracle is many small CPU ops: beyond ~16 threads fork/join overhead wins
     torch.set_num_threads(threads)
     ks = ck['config']['feat_conv1_kernel_size']
     p0, c0, p1, c1 = pair0['xyz0'], pair0['coords0'], pair0['xyz1'], pair0['coords1']
@@ -132,21 +136,40 @@ def oracle_parity_and_baseline(ck, args, pair0, do_baseline):
               'dlogit_rel': float(np.abs(pair0['logit'] - ologit).max() / max(1e-12, np.abs(ologit).max())),
               'tolerance': 1e-4,
               'what': 'F0/F1 and the 6-D logits of pair 0 of the timed batch (HIP, dgr_register_batch) vs '
-                      'oracle.resunet.resunet_forward on identical voxels / correspondences; computed outside '
-                      'the timed region'}
-    parity['ok'] = bool(parity['dF'] < 1e-4 and parity['dlogit_rel'] < 1e-4)
+                      'oracle.resunet.resunet_forward on identical voxels / correspondences; R/t: the HIP refinement '
+                      '(dgr_se3_refine) vs oracle.registration.global_registration on the same correspondences and '
+                      'weights, both forced to the oracle\'s free-running iteration count (oracle/parity.py); computed '
+                      'outside the timed region'}
+    # R / t (parity TE / RE): iteration-matched, plus how far the reference moves from itself at that
+    # iteration count under a row permutation / a few-ulp change of its inputs (the band)
+    w, wsum, thr = opipe.confidence_gate(pair0['forced'])
+    X, Y = p0, p1[pair0['idx1']]
+    q = 2 * args.voxel
+    dev = pair0['device']
+
+    def hip_refine(Xa, Ya, wa, max_iter, max_break):
+        return ops.se3_refine(torch.from_numpy(Xa).to(dev), torch.from_numpy(Ya).to(dev), torch.from_numpy(wa).to(dev),
+                              q, max_iter, max_break, 1e-4)
+    if wsum >= thr and not args.no_refine:
+        rp = oparity.iteration_matched(X, Y, w, hip_refine, always_band=True, band_counts='short', band_ulps=4,
+                                       break_threshold_ratio=1e-4, quantization_size=q)
+        Ro, to = rp.pop('R_oracle'), rp.pop('t_oracle')
+        R = np.asarray(hip_refine(np.asarray(X, np.float32), np.asarray(Y, np.float32),
+                                  np.asarray(w, np.float32).reshape(-1, 1), rp['iterations'], 10 ** 9)[0], np.float64)
+        c = (np.trace(R.T @ Ro.astype(np.float64)) - 1) / 2
+        parity.update({'dR': rp['dR'], 'dt': rp['dt'], 'refinement_iterations': rp['iterations'],
+                       'reference_band': rp['band'], 'parity_RE_deg': float(np.degrees(np.arccos(np.clip(c, -1, 1)))),
+                       'parity_TE_m': rp['dt'] * rp['t_scale'],
+                       'band_what': 'largest |dR|, |dt| of the oracle against ITSELF at the same iteration counts '
+                                    '(k, k-15) on a row permutation and 4 few-ulp perturbations of its input'})
+        parity['rt_ok'] = bool(max(rp['dR'], rp['dt']) <= max(1e-4, 3 * (rp['band'] or 0.0)))
+    parity['ok'] = bool(parity['dF'] < 1e-4 and parity['dlogit_rel'] < 1e-4 and parity.get('rt_ok', True))
     if not do_baseline:
         return parity, None
-    # 1-NN: a bounded sample -- the first `nq` query rows against ALL reference rows, chunked like the
-    # reference (nn_max_n = 250); the search is row-independent, so the full time is the sample x N0 / nq
-    nq = min(n0, 1500)
-    runs = []
-    for _ in range(3):
-        t0 = time.time()
-        oknn.find_knn(oF0[:nq], oF1, nn_max_n=250)
-        runs.append(time.time() - t0)
-    t['knn'] = float(np.median(runs)) * n0 / nq
-    w, wsum, thr = opipe.confidence_gate(pair0['forced'])
+    # 1-NN: the whole search, chunked like the reference (nn_max_n = 250), one run
+    t0 = time.time()
+    oknn.find_knn(oF0, oF1, nn_max_n=250)
+    t['knn'] = time.time() - t0
     runs = []
     for _ in range(3):
         t0 = time.time()
@@ -155,10 +178,10 @@ def oracle_parity_and_baseline(ck, args, pair0, do_baseline):
         runs.append(time.time() - t0)
     t['registration'] = float(np.median(runs))
     total = sum(t.values())
-    base = {'value': 1.0 / total, 'unit': 'pairs/s', 'cores': threads, 'kind': 'port',
-            'sample': f'pair 0 of the timed batch at FULL size ({n0}/{n1} voxels): FCGF x2 and 6-D net one run each, '
-                      f'registration median of 3, 1-NN on the first {nq} of {n0} query rows vs all {n1} reference rows '
-                      f'(median of 3, scaled by N0/{nq}); voxelisation excluded',
+    base = {'value': 1.0 / total, 'unit': 'pairs/s', 'cores': threads, 'host_cores_found': found, 'kind': 'port',
+            'sample': f'pair 0 of the timed batch at FULL size ({n0}/{n1} voxels): FCGF x2, 6-D net and the whole 1-NN '
+                      f'search ({n0} x {n1} rows, chunks of 250 like the reference) one run each, registration median '
+                      f'of 3; voxelisation excluded; {threads} torch threads on a host that reports {found} cores',
             'stage_s': {k: round(v, 3) for k, v in t.items()},
             'reference_modules_in_container': {
                 'note': 'the reference\'s own core/knn.py / core/registration.py timed on CPU tensors in the build '

@@ -31,9 +31,11 @@
 #include "dgr_internal.h"
 #include <algorithm>
 #include "hash.h"
+#include "split.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 struct ConvKArgs {
   const float *in;
@@ -385,11 +387,12 @@ int dgr_conv_launch(const DgrConvLaunch &a, int num_cus, hipStream_t stream, con
 // phase 2: out[o, :] = shift (+ residual[o, :]) + sum over the row's pairs (ascending k) of Y[pos, :]
 // LPR lanes cooperate on one output row (one float4 column group each); rows are independent.
 // ------------------------------------------------------------------------------------------
-template <int LPR>
+template <int LPR, bool SPLIT>
 __global__ void __launch_bounds__(256)
     reduce_rows_kernel(const float *__restrict__ y, int y_ld, const int32_t *__restrict__ ptr,
                        const int32_t *__restrict__ pos, const int32_t *n_dev, float *__restrict__ out, int out_ld,
-                       const float *__restrict__ shift, const float *__restrict__ res, int res_ld, int res_relu) {
+                       const float *__restrict__ shift, const float *__restrict__ res, int res_ld, int res_relu,
+                       unsigned char *__restrict__ planes, float *__restrict__ scale_out, int out_relu) {
   constexpr int ROWS = 256 / LPR;
   const int n = *n_dev;
   const int sub = threadIdx.x / LPR, c = (threadIdx.x % LPR) * 4;
@@ -424,32 +427,66 @@ __global__ void __launch_bounds__(256)
     }
     for (; j < end; ++j) acc += dgr_y_load<LPR == 64>(y + (int64_t)pos[j] * y_ld + c);
     *reinterpret_cast<f32x4 *>(out + row * out_ld + c) = acc;
+    if constexpr (SPLIT) {
+      // the row as the wide-layer kernel gathers it (conv_wide.hip): scale from the row's largest |x| after the
+      // consumers' pending ReLU (the LPR lanes of a row are consecutive lanes of one wave), two f16 planes
+      const int lo = out_relu ? 0 : (int)0x80000000;
+      int xb[4];
+      uint32_t mx = 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        xb[u] = max(__builtin_bit_cast(int, acc[u]), lo);   // pending ReLU as one integer max
+        mx = max(mx, (uint32_t)xb[u] & 0x7fffffffu);
+      }
+#pragma unroll
+      for (int d = LPR / 2; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+      const float sx = dgr_row_scale_of(mx);
+      f16x4 h, m;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        _Float16 hh, mm;
+        dgr_split2(__builtin_bit_cast(float, xb[u]), sx, hh, mm);
+        h[u] = hh; m[u] = mm;
+      }
+      unsigned char *dst = planes + row * (LPR * 16);
+      *reinterpret_cast<f16x4 *>(dst + dgr_split_row_offset(c, 0)) = h;
+      *reinterpret_cast<f16x4 *>(dst + dgr_split_row_offset(c, 1)) = m;
+      if (c == 0) scale_out[row] = sx;
+    }
   }
 }
 
 int dgr_reduce_rows(const float *y, int cout, const int32_t *ptr, const int32_t *pos, const int32_t *n_dev,
                     int64_t n_cap, float *out, int out_ld, const float *shift, const float *res, int res_ld,
-                    int res_relu, hipStream_t stream) {
+                    int res_relu, hipStream_t stream, const DgrSplitRows *split, int out_relu) {
   DGR_REQUIRE((out_ld & 3) == 0 && (res == nullptr || (res_ld & 3) == 0), "reduce_rows: row strides must be x4");
+  DGR_REQUIRE(!split || (split->planes && split->scale && split->channels == cout && cout % 64 == 0),
+              "reduce_rows: split rows need planes, scales and the layer's width (a multiple of 64)");
   const int lpr = cout / 4;
   const int64_t want = std::max<int64_t>(1, dgr_ceil_div(n_cap, 256 / lpr));
   // grid-stride kernels: at most four resident rounds, and a whole number of them
-#define DGR_RR(L)                                                                                              \
+#define DGR_RR1(L, SP)                                                                                         \
   do {                                                                                                         \
     static int resident = 0;                                                                                   \
     if (resident == 0) {                                                                                       \
       int per_cu = 0, dev = 0, cus = 0;                                                                        \
-      DGR_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reduce_rows_kernel<L>, 256, 0));     \
+      DGR_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reduce_rows_kernel<L, SP>, 256, 0)); \
       DGR_HIP_CHECK(hipGetDevice(&dev));                                                                       \
       DGR_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));                  \
       resident = (per_cu < 1 ? 1 : per_cu) * (cus < 1 ? 1 : cus);                                              \
     }                                                                                                          \
     const int64_t blocks = want > resident ? (int64_t)resident * std::min<int64_t>(4, want / resident) : want; \
-    reduce_rows_kernel<L><<<(int)blocks, 256, 0, stream>>>(y, cout, ptr, pos, n_dev, out, out_ld, shift, res,  \
-                                                           res_ld, res_relu);                                  \
+    reduce_rows_kernel<L, SP><<<(int)blocks, 256, 0, stream>>>(y, cout, ptr, pos, n_dev, out, out_ld, shift,   \
+                                                               res, res_ld, res_relu, split ? split->planes : nullptr, \
+                                                               split ? split->scale : nullptr, out_relu);      \
+  } while (0)
+#define DGR_RR(L)                       \
+  do {                                  \
+    if (split) DGR_RR1(L, true);        \
+    else DGR_RR1(L, false);             \
   } while (0)
   switch (cout) {
-    case 32: DGR_RR(8); break;
+    case 32: DGR_RR1(8, false); break;
     case 64: DGR_RR(16); break;
     case 128: DGR_RR(32); break;
     case 256: DGR_RR(64); break;
@@ -457,6 +494,7 @@ int dgr_reduce_rows(const float *y, int cout, const int32_t *ptr, const int32_t 
       dgr_set_error("reduce_rows: unsupported width %d", cout);
       return DGR_EINVAL;
   }
+#undef DGR_RR1
 #undef DGR_RR
   DGR_LAUNCH_CHECK();
   return DGR_OK;

@@ -21,7 +21,7 @@
 //
 // Arithmetic (PM): 2 = every f32 operand as two f16 pieces under exact power-of-two row / layer scales, three
 // v_mfma_f32_16x16x32_f16 per 32 input channels (default; error analysis in conv_bf3.hip); 3 = three exact
-// bf16 pieces, six products (DGR_CONV_BF3=1); 0 = v_mfma_f32_16x16x4_f32 on the f32 operands (DGR_OS_F32=1).
+// bf16 pieces, six products (DGR_CONV_BF3=1); 0 = v_mfma_f32_16x16x4_f32 on the f32 operands (DGR_EXACT_F32=1).
 //
 // Weight layouts (net.hip, per layer): split pieces WB[piece][k][s][jb][lane] = 8 halves =
 // W_folded[k][32 s + 8 (lane >> 4) + e][16 jb + (lane & 15)]; f32: W16[k][g][jb][lane][c] =
@@ -57,7 +57,7 @@ struct ConvOsArgs {
 // per workgroup (16 | 32 | 64), CK = input channels per pipeline phase (32 | 64), TM = pair slots per tile (32 | 64)
 // BF3: the products run on the bf16 matrix pipe with every f32 operand split exactly into three bf16 pieces (six
 // v_mfma_f32_16x16x32_bf16 per 32 input channels instead of eight v_mfma_f32_16x16x4_f32: 2.67x fewer matrix
-// cycles, f32-level error -- see conv_bf3.hip); false = exact-f32 MFMA (DGR_OS_F32=1, A/B measurements)
+// cycles, f32-level error -- see conv_bf3.hip); false = exact-f32 MFMA (DGR_EXACT_F32=1, A/B measurements)
 // PM = pieces per operand: 0 = exact-f32 MFMA, 3 = bf16 x 3 (six products), 2 = f16 x 2 with exact power-of-two
 // row / layer scales (three v_mfma_f32_16x16x32_f16 per 32 input channels; conv_bf3.hip has the error analysis)
 // GW = groups of a tile per wave: GW = TM / 16 -> CS / 16 waves, each walks all groups of the tile (the coarse levels,
@@ -410,7 +410,7 @@ int dgr_conv_os_launch(const DgrConvOsLaunch &a, hipStream_t stream, const char 
               a.cin, a.cout);
   DGR_REQUIRE(a.n_out_cap * (int64_t)a.in_ld < (1ll << 32) / 4 * 4, "output-stationary conv: input tensor beyond 32-bit element offsets");
   ConvOsArgs ka;
-  static const bool os_f32 = getenv("DGR_OS_F32") != nullptr;
+  static const bool os_f32 = getenv("DGR_EXACT_F32") != nullptr;
   ka.in = a.in; ka.out = a.out; ka.w16 = a.w16; ka.shift = a.shift; ka.res = a.res;
   ka.wb3 = os_f32 ? nullptr : static_cast<const uint4 *>(a.wb3);
   ka.piece_stride = a.piece_stride;

@@ -175,7 +175,6 @@ struct DgrConvLaunch {
   float *out;   // identity maps only: [n_out, out_ld] written directly (product + shift)
   int out_ld;
   float *y;            // non-identity maps: per-pair product rows [pairs, cout]
-  float *y_scratch = nullptr;   // >= 64 rows nobody reads (fixed-count stores of the wave-specialised kernel)
   const float *shift;  // identity maps: per-channel shift (may be null)
   const float *w;  // MFMA-B-fragment tiled weights of this layer
   int cin, cin_pad, cout, cout_pad, K;
@@ -185,21 +184,31 @@ struct DgrConvLaunch {
   int64_t tile_bound;                                        // host upper bound on the tile count (0 = unknown)
 };
 int dgr_conv_launch(const DgrConvLaunch &a, int num_cus, hipStream_t stream, const char **kernel_name = nullptr);
-// wide layers (Cout >= 128): the same phase 1 on the f16 / bf16 matrix pipe with every f32 operand split into
-// pieces (conv_bf3.hip); wb = the layer's pre-split weights, piece_stride in 16-byte units
-bool dgr_conv_bf3_supported(int cin_pad, int cin, int cout);
-// pieces = 3: bf16 x 3 (six products); pieces = 2: f16 x 2 (three products) with the input's power-of-two row
-// scales (dgr_row_scale) and the inverse of the layer's weight scale
-int dgr_conv_bf3_launch(const DgrConvLaunch &a, const void *wb, int64_t piece_stride, int pieces, float w_unscale,
-                        const float *row_scale, int num_cus, hipStream_t stream, const char **kernel_name = nullptr);
+// A tensor in the form the wide-layer kernel gathers (conv_wide.hip): per row channels / 64 blocks of 256 bytes
+// [h of 64 channels][m of the same] (two f16 pieces of scale * x, the consumer's pending ReLU applied) + the row's
+// power-of-two scale.  Written by the tensor's producer (dgr_reduce_rows) next to the f32 rows.
+struct DgrSplitRows {
+  unsigned char *planes = nullptr;   // [n_cap][4 * channels] bytes
+  float *scale = nullptr;            // [n_cap]
+  int channels = 0;
+};
+// wide layers of the 6-D net (Cout >= 128): phase 1 on the f16 matrix pipe with every f32 operand as two f16 pieces
+// (conv_wide.hip); wb = the layer's pre-split weights, piece_stride in 16-byte units, `in` = the input as split rows
+bool dgr_conv_wide_supported(int cin_pad, int cin, int cout);
+int dgr_conv_wide_launch(const DgrConvLaunch &a, const DgrSplitRows &in, const void *wb, int64_t piece_stride,
+                         float w_unscale, int num_cus, hipStream_t stream, const char **kernel_name = nullptr);
 // out[r] = 2^(14 - floor(log2 max_c |in[r][c]|)) (after the pending ReLU): the row's largest entry lands in
 // [2^14, 2^15) when multiplied by it; 1 for rows of zeros
 int dgr_row_scale(const float *in, int in_ld, int cin, int relu, const int32_t *n_dev, int64_t n_cap, float *out,
                   hipStream_t stream);
-// out[o,:] = shift (+res[o,:]) + sum_{j in [ptr[o], ptr[o+1])} y[pos[j],:]   (ascending-k order)
+// the same + the rows' two f16 planes (a tensor that did not come out of dgr_reduce_rows)
+int dgr_split_rows(const float *in, int in_ld, int relu, const int32_t *n_dev, int64_t n_cap, const DgrSplitRows &out,
+                   hipStream_t stream);
+// out[o,:] = shift (+res[o,:]) + sum_{j in [ptr[o], ptr[o+1])} y[pos[j],:]   (ascending-k order); `split` (nullable):
+// also the row as split rows with max(x, 0) applied when out_relu (= the consumers' pending ReLU)
 int dgr_reduce_rows(const float *y, int cout, const int32_t *ptr, const int32_t *pos, const int32_t *n_dev,
                     int64_t n_cap, float *out, int out_ld, const float *shift, const float *res, int res_ld,
-                    int res_relu, hipStream_t stream);
+                    int res_relu, hipStream_t stream, const DgrSplitRows *split = nullptr, int out_relu = 0);
 // output-stationary conv for Cin <= 8, Cout == 32 (conv1): no product rows, no reduction pass
 int dgr_conv_small_cin(const float *in, int in_ld, int in_relu, int cin, const float *w_tiled, const float *shift,
                        const DgrKernelMap &km, const int32_t *n_out_dev, int64_t n_out_cap, float *out, int out_ld,

@@ -5,10 +5,11 @@
 //
 // Load time: eval-mode batch norm is folded into the kernels (scale) and a per-channel shift; the
 // kernels are re-tiled into the MFMA B-operand order documented in conv.hip.
-// Forward: every conv is [init rows with shift (+ residual)] + [sparse_conv_mfma accumulating
-// with atomics].  ReLU is never a separate pass: a tensor carries a "ReLU pending" flag and the
-// consumer applies max(x,0) while gathering.  ME.cat is free: producers write into column ranges
-// of a pre-concatenated buffer (row stride = total channels).
+// Forward: every conv is one of the kernel families of conv.hip / conv_os.hip / conv_wide.hip (chosen per layer in
+// Fwd::conv); rule-major layers write per-pair product rows that a deterministic reduction sums on top of the folded
+// shift (+ residual).  ReLU is never a separate pass: a tensor carries a "ReLU pending" flag and the consumer applies
+// max(x,0) while gathering (or the producer bakes it into the split rows it writes for a wide-layer consumer).
+// ME.cat is free: producers write into column ranges of a pre-concatenated buffer (row stride = total channels).
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -28,12 +29,12 @@ struct DgrLayer {
   int K, cin, cout, cin_pad, cout_pad;
   float *w = nullptr;      // device, tiled
   float *w16 = nullptr;    // device, 16x16x4 fragment order (3-D K = 27 layers: output-stationary conv, conv_os.hip)
-  void *w16b = nullptr;    // device, the same as three exact bf16 pieces in 16x16x32 fragment order (conv_os.hip, BF3)
+  void *w16b = nullptr;    // device, the same as two f16 pieces in 16x16x32 fragment order (conv_os.hip)
   int64_t w16b_piece = 0;
   float *wc = nullptr;     // device, compact [K][32] (3-D conv1 with one input channel: conv1_grid_mfma, conv.hip)
-  void *wb = nullptr;      // device, three exact bf16 pieces in 32x32x16 fragment order (wide layers, conv_bf3.hip)
+  void *wb = nullptr;      // device, two f16 pieces in 32x32x16 fragment order (wide layers, conv_wide.hip)
   int64_t wb_piece = 0;    // 16-byte units per piece
-  int pieces = 3;          // wb / w16b: 3 = bf16 x 3 (exact), 2 = f16 x 2 scaled by 1 / w_unscale (a power of two)
+  int pieces = 2;          // wb / w16b: two f16 pieces of 2^e W; w_unscale = 2^-e
   float w_unscale = 1.f;
   float *shift = nullptr;  // device [cout] or nullptr
 };
@@ -43,7 +44,8 @@ struct LayerRun {  // bookkeeping of the last forward, for dgr_net_layer_stats /
   const int32_t *n_in = nullptr, *n_out = nullptr;
   int K = 1;
   DgrConvLaunch launch;   // the exact launch of phase 1
-  const float *row_scale = nullptr;   // f16 x 2 wide-layer kernel: the input's row scales
+  DgrSplitRows split_in, split_out;   // wide-layer kernel: the input as split rows; what the reduction also writes
+  int out_relu = 0;
   bool small_cin = false;  // conv1 ran through the output-stationary kernel instead
   const int32_t *fused_pairs = nullptr;  // conv1 fused with its neighbour search: device pair counter
   bool os = false;                       // ran through the output-stationary kernel
@@ -117,15 +119,14 @@ static int make_layer(dgr_net *net, const dgr_weight_desc *descs, int nd, const 
     for (int c = 0; c < cout; ++c) shift[c] += bd->data[c];
     has_shift = true;
   }
-  // DGR_CONV_F32=1 keeps the exact-f32 MFMA kernel for the wide layers (A/B measurements); by default they run
-  // on the bf16 pipe with exactly split operands (conv_bf3.hip) and only that weight copy is made
-  static const bool f32_wide = getenv("DGR_CONV_F32") != nullptr;
-  // split-operand kernels: two f16 pieces under power-of-two scales (default) or three exact bf16 pieces
-  // (DGR_CONV_BF3=1; twice the matrix work, kept for A/B measurements)
-  static const bool three_pieces = getenv("DGR_CONV_BF3") != nullptr;
-  L.pieces = three_pieces ? 3 : 2;
+  // DGR_EXACT_F32=1: every conv on v_mfma_f32_*_f32 with the f32 operands themselves (the reference's arithmetic,
+  // conv.hip / conv_os.hip) -- the mode the split-operand kernels are measured against.  Default: two f16 pieces per
+  // operand under power-of-two scales, three products per MAC (conv_wide.hip, conv_os.hip).
+  static const bool exact_f32 = getenv("DGR_EXACT_F32") != nullptr;
+  L.pieces = 2;
+  // the layer's weight scale: the largest |w| (batch norm folded in) lands in [2^14, 2^15)
   float w_scale = 1.f;
-  if (L.pieces == 2) {
+  {
     float mx = 0.f;
     for (int k = 0; k < K; ++k)
       for (int r = 0; r < cin; ++r)
@@ -133,18 +134,16 @@ static int make_layer(dgr_net *net, const dgr_weight_desc *descs, int nd, const 
     int e = 0;
     if (mx > 0.f && std::isfinite(mx)) (void)frexpf(mx, &e);   // mx in [2^(e-1), 2^e)
     e = std::min(std::max(e, -100), 100);
-    w_scale = ldexpf(1.f, 15 - e);                              // largest |w| lands in [2^14, 2^15)
+    w_scale = ldexpf(1.f, 15 - e);
     L.w_unscale = ldexpf(1.f, e - 15);
   }
   auto f16_bits = [](float x) { _Float16 h = (_Float16)x; uint16_t b; memcpy(&b, &h, 2); return b; };
   auto f16_val = [](float x) { return (float)(_Float16)x; };
-  const bool use_bf3 = K > 1 && !f32_wide && dgr_conv_bf3_supported(L.cin_pad, cin, cout) && !(net->D == 3 && K == 27);
-  if (use_bf3) {
+  const bool use_wide = K > 1 && !exact_f32 && dgr_conv_wide_supported(L.cin_pad, cin, cout) && !(net->D == 3 && K == 27);
+  if (use_wide) {
     const int S16 = cin / 16, NB32 = cout / 32;
     L.wb_piece = (int64_t)K * S16 * NB32 * 64;
-    std::vector<uint16_t> pieces((size_t)L.pieces * L.wb_piece * 8);
-    auto top16 = [](float x) { uint32_t b; memcpy(&b, &x, 4); return b & 0xffff0000u; };
-    auto asf = [](uint32_t b) { float x; memcpy(&x, &b, 4); return x; };
+    std::vector<uint16_t> pieces((size_t)2 * L.wb_piece * 8);
     for (int k = 0; k < K; ++k) {
       const float *src = kd->data + (size_t)k * cin * cout;
       for (int s = 0; s < S16; ++s)
@@ -153,20 +152,9 @@ static int make_layer(dgr_net *net, const dgr_weight_desc *descs, int nd, const 
             const int col = 32 * nb + (lane & 31);
             const size_t o = ((((size_t)k * S16 + s) * NB32 + nb) * 64 + lane) * 8;
             for (int e = 0; e < 8; ++e) {
-              const float x = src[(size_t)(16 * s + 8 * (lane >> 5) + e) * cout + col] * scale[col];
-              if (L.pieces == 2) {
-                const float xs = x * w_scale;
-                pieces[o + e] = f16_bits(xs);
-                pieces[(size_t)L.wb_piece * 8 + o + e] = f16_bits(xs - f16_val(xs));
-                continue;
-              }
-              const uint32_t h = top16(x);
-              const float r1 = x - asf(h);
-              const uint32_t m = top16(r1);
-              const float r2 = r1 - asf(m);          // <= 8 significant bits: exact in bf16
-              pieces[o + e] = (uint16_t)(h >> 16);
-              pieces[(size_t)L.wb_piece * 8 + o + e] = (uint16_t)(m >> 16);
-              pieces[(size_t)2 * L.wb_piece * 8 + o + e] = (uint16_t)(top16(r2) >> 16);
+              const float xs = src[(size_t)(16 * s + 8 * (lane >> 5) + e) * cout + col] * scale[col] * w_scale;
+              pieces[o + e] = f16_bits(xs);
+              pieces[(size_t)L.wb_piece * 8 + o + e] = f16_bits(xs - f16_val(xs));
             }
           }
     }
@@ -219,9 +207,7 @@ static int make_layer(dgr_net *net, const dgr_weight_desc *descs, int nd, const 
       // WB[piece][k][s][jb][lane] = 8 bf16 = piece of W[k][32 s + 8 (lane >> 4) + e][16 jb + (lane & 15)]
       const int S32 = cin / 32;
       L.w16b_piece = (int64_t)K * S32 * NB * 64;
-      std::vector<uint16_t> pcs((size_t)L.pieces * L.w16b_piece * 8);
-      auto top16 = [](float x) { uint32_t b; memcpy(&b, &x, 4); return b & 0xffff0000u; };
-      auto asf = [](uint32_t b) { float x; memcpy(&x, &b, 4); return x; };
+      std::vector<uint16_t> pcs((size_t)2 * L.w16b_piece * 8);
       for (int k = 0; k < K; ++k) {
         const float *src = kd->data + (size_t)k * cin * cout;
         for (int sI = 0; sI < S32; ++sI)
@@ -230,19 +216,9 @@ static int make_layer(dgr_net *net, const dgr_weight_desc *descs, int nd, const 
               const int col = 16 * jb + (lane & 15);
               const size_t o = ((((size_t)k * S32 + sI) * NB + jb) * 64 + lane) * 8;
               for (int e = 0; e < 8; ++e) {
-                const float x = src[(size_t)(32 * sI + 8 * (lane >> 4) + e) * cout + col] * scale[col];
-                if (L.pieces == 2) {
-                  const float xs = x * w_scale;
-                  pcs[o + e] = f16_bits(xs);
-                  pcs[(size_t)L.w16b_piece * 8 + o + e] = f16_bits(xs - f16_val(xs));
-                  continue;
-                }
-                const uint32_t h = top16(x);
-                const float r1 = x - asf(h);
-                const uint32_t m = top16(r1);
-                pcs[o + e] = (uint16_t)(h >> 16);
-                pcs[(size_t)L.w16b_piece * 8 + o + e] = (uint16_t)(m >> 16);
-                pcs[(size_t)2 * L.w16b_piece * 8 + o + e] = (uint16_t)(top16(r1 - asf(m)) >> 16);
+                const float xs = src[(size_t)(32 * sI + 8 * (lane >> 4) + e) * cout + col] * scale[col] * w_scale;
+                pcs[o + e] = f16_bits(xs);
+                pcs[(size_t)L.w16b_piece * 8 + o + e] = f16_bits(xs - f16_val(xs));
               }
             }
       }
@@ -330,6 +306,7 @@ struct Tensor {
   float *ptr;
   int ld;
   int relu;  // consumers must apply ReLU when reading
+  DgrSplitRows split;   // set for tensors a wide layer gathers: written by the tensor's producer (ReLU applied)
 };
 
 struct Fwd {
@@ -340,7 +317,6 @@ struct Fwd {
   bool prof;
 
   float *ybuf = nullptr;  // per-pair product rows, sized for the largest layer of this forward
-  float *yscratch = nullptr;   // 64 rows nobody reads
 
   // one conv: Y[pair] = in[pair_in] W[k] (MFMA), then out[o] = shift (+res) + sum of the row's Y rows
   int conv(int li, const Tensor &in, const DgrKernelMap *km, bool swapped, int lvl_in, int lvl_out,
@@ -350,7 +326,7 @@ struct Fwd {
     DgrConvLaunch a;
     a.in = in.ptr; a.in_ld = in.ld; a.in_relu = in.relu;
     a.out = out.ptr; a.out_ld = out.ld;
-    a.y = ybuf; a.y_scratch = yscratch; a.shift = L.shift;
+    a.y = ybuf; a.shift = L.shift;
     a.w = L.w;
     a.cin = L.cin; a.cin_pad = L.cin_pad; a.cout = L.cout; a.cout_pad = L.cout_pad; a.K = L.K;
     if (km && ms.use_nbr) {
@@ -391,9 +367,9 @@ struct Fwd {
       o.rows_per_block = lvl_out <= 1 ? 64 : lvl_out == 2 ? 32 : 16;
       o.w16 = L.w16; o.shift = L.shift;
       o.wb3 = L.w16b; o.piece_stride = L.w16b_piece;
-      o.pieces = L.pieces; o.w_unscale = L.w_unscale;
-      static const bool os_f32 = getenv("DGR_OS_F32") != nullptr;   // (conv_os.hip reads the same switch)
-      if (L.w16b && L.pieces == 2 && !os_f32) {
+      o.pieces = 2; o.w_unscale = L.w_unscale;
+      static const bool os_f32 = getenv("DGR_EXACT_F32") != nullptr;   // (conv_os.hip reads the same switch)
+      if (L.w16b && !os_f32) {
         float *rs;
         DGR_ALLOC(rs, ctx->arena, float, cin_map.n_cap);
         DGR_CHECK(dgr_row_scale(in.ptr, in.ld, L.cin, in.relu, cin_map.n_dev, cin_map.n_cap, rs, stream));
@@ -422,26 +398,22 @@ struct Fwd {
     }
     const bool small_cin = km && !swapped && !res && L.cin <= 8 && L.cout == 32 && L.cin_pad == 8;
     const char *kname = "conv_small_cin_kernel";
-    const float *row_scale = nullptr;
+    const bool wide = L.wb && km;
     if (small_cin)
       DGR_CHECK(dgr_conv_small_cin(in.ptr, in.ld, in.relu, L.cin, L.w, L.shift, *km, cout_map.n_dev, cout_map.n_cap,
                                    out.ptr, out.ld, stream));
-    else if (L.wb && km) {
-      if (L.pieces == 2) {
-        float *rs;
-        DGR_ALLOC(rs, ctx->arena, float, cin_map.n_cap);
-        DGR_CHECK(dgr_row_scale(in.ptr, in.ld, L.cin, in.relu, cin_map.n_dev, cin_map.n_cap, rs, stream));
-        row_scale = rs;
-      }
-      DGR_CHECK(dgr_conv_bf3_launch(a, L.wb, L.wb_piece, L.pieces, L.w_unscale, row_scale, ctx->num_cus, stream, &kname));
-    }
-    else
+    else if (wide) {
+      DGR_REQUIRE(in.split.planes, "layer %s: the wide-layer kernel needs its input as split rows", L.name.c_str());
+      DGR_CHECK(dgr_conv_wide_launch(a, in.split, L.wb, L.wb_piece, L.w_unscale, ctx->num_cus, stream, &kname));
+    } else
       DGR_CHECK(dgr_conv_launch(a, ctx->num_cus, stream, &kname));
     if (prof) DGR_HIP_CHECK(hipEventRecord(em, stream));   // end of the MFMA phase
+    DGR_REQUIRE(!out.split.planes || (km && !small_cin), "layer %s: only a reduction can write split rows", L.name.c_str());
     if (km && !small_cin)
       DGR_CHECK(dgr_reduce_rows(ybuf, L.cout, swapped ? km->in_ptr : km->out_ptr, swapped ? km->in_pos : km->out_pos,
                                 cout_map.n_dev, cout_map.n_cap, out.ptr, out.ld, L.shift, res ? res->ptr : nullptr,
-                                res ? res->ld : 0, res ? res->relu : 0, stream));
+                                res ? res->ld : 0, res ? res->relu : 0, stream, out.split.planes ? &out.split : nullptr,
+                                out.relu));
     if (prof) {
       DGR_HIP_CHECK(hipEventRecord(e1, stream));
       ctx->conv_spans.push_back({e0, e1});
@@ -450,7 +422,9 @@ struct Fwd {
     }
     LayerRun &r = net->runs[li];
     r.launch = a;
-    r.row_scale = row_scale;
+    r.split_in = wide ? in.split : DgrSplitRows();
+    r.split_out = out.split;
+    r.out_relu = out.relu;
     r.has_reduce = km != nullptr;
     r.small_cin = small_cin;
     if (km) r.km = *km;
@@ -497,7 +471,6 @@ int dgr_resunet_forward_impl(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, 
     for (int l = 0; l < 4; ++l) need = std::max(need, m.same[l].pair_cap * same_c[l]);
     for (int l = 0; l < 3; ++l) need = std::max(need, m.down[l].pair_cap * down_c[l]);
     DGR_ALLOC(f.ybuf, A, float, need);
-    DGR_ALLOC(f.yscratch, A, float, 64 * 256);
   }
   const DgrMapSet &ms = f.ms;
   const int64_t n1 = ms.cm[0].n_cap, n2 = ms.cm[1].n_cap, n4 = ms.cm[2].n_cap, n8 = ms.cm[3].n_cap;
@@ -518,10 +491,24 @@ int dgr_resunet_forward_impl(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, 
 
   const Tensor X{const_cast<float *>(feats), net->cin, 0};
   const Tensor T1{t1, 32, 0}, Y1{y1, 32, 1}, S1{cat1 + 64, 96, 1};
-  const Tensor T2{t2, 64, 0}, Y2{y2, 64, 1}, S2{cat2 + 64, 128, 1};
-  const Tensor T4{t4, 128, 0}, Y4{y4, 128, 1}, S4{cat4 + 128, 256, 1};
-  const Tensor T8{t8, 256, 0}, Y8{y8, 256, 1}, S8{s8, 256, 1};
-  const Tensor U4{u4, 128, 0}, V4{v4, 128, 1}, S4T{cat4, 256, 1};
+  const Tensor T2{t2, 64, 0}, Y2{y2, 64, 1};
+  Tensor S2{cat2 + 64, 128, 1};
+  Tensor T4{t4, 128, 0}, Y4{y4, 128, 1}, S4{cat4 + 128, 256, 1};
+  Tensor T8{t8, 256, 0}, Y8{y8, 256, 1}, S8{s8, 256, 1};
+  Tensor U4{u4, 128, 0}, V4{v4, 128, 1};
+  const Tensor S4T{cat4, 256, 1};
+  // tensors that a wide layer (conv_wide.hip) gathers are also written as split rows by their producer
+  {
+    struct { Tensor *t; int consumer, channels; int64_t rows; } sp[] = {
+        {&S2, 6, 64, n2}, {&T4, 7, 128, n4}, {&Y4, 8, 128, n4}, {&S4, 9, 128, n4}, {&T8, 10, 256, n8},
+        {&Y8, 11, 256, n8}, {&S8, 12, 256, n8}, {&U4, 13, 128, n4}, {&V4, 14, 128, n4}};
+    for (auto &e : sp) {
+      if (!net->layers[e.consumer].wb) continue;
+      e.t->split.channels = e.channels;
+      DGR_ALLOC(e.t->split.planes, A, unsigned char, (size_t)e.rows * 4 * e.channels);
+      DGR_ALLOC(e.t->split.scale, A, float, e.rows);
+    }
+  }
   const Tensor U2{u2, 64, 0}, V2{v2, 64, 1}, S2T{cat2, 128, 1};
   const Tensor U1{u1, 64, 0}, V1{v1, 64, 1}, S1T{cat1, 96, 1};
   const Tensor H{h, 64, 1}, FIN{fin, net->cout, 0};
@@ -768,13 +755,14 @@ extern "C" int dgr_net_rerun_layer(dgr_ctx *ctx, dgr_net *net, int layer, int re
       DGR_CHECK(dgr_conv_small_cin(r.launch.in, r.launch.in_ld, r.launch.in_relu, L.cin, L.w, L.shift, r.km, r.n_out,
                                    r.n_out_cap, r.launch.out, r.launch.out_ld, nullptr));
     else if (L.wb && r.has_reduce)
-      DGR_CHECK(dgr_conv_bf3_launch(r.launch, L.wb, L.wb_piece, L.pieces, L.w_unscale, r.row_scale, ctx->num_cus, nullptr));
+      DGR_CHECK(dgr_conv_wide_launch(r.launch, r.split_in, L.wb, L.wb_piece, L.w_unscale, ctx->num_cus, nullptr));
     else
       DGR_CHECK(dgr_conv_launch(r.launch, ctx->num_cus, nullptr));
     DGR_HIP_CHECK(hipEventRecord(e1, nullptr));
     if (r.has_reduce && !r.small_cin && !r.os)
       DGR_CHECK(dgr_reduce_rows(r.launch.y, L.cout, r.red_ptr, r.red_pos, r.n_out, r.n_out_cap, r.launch.out,
-                                r.launch.out_ld, L.shift, r.res, r.res_ld, r.res_relu, nullptr));
+                                r.launch.out_ld, L.shift, r.res, r.res_ld, r.res_relu, nullptr,
+                                r.split_out.planes ? &r.split_out : nullptr, r.out_relu));
     DGR_HIP_CHECK(hipEventRecord(e2, nullptr));
     DGR_HIP_CHECK(hipEventSynchronize(e2));
     float a = 0.f, b = 0.f;

@@ -1,10 +1,10 @@
-"""The conv kernels' three arithmetic modes against each other and against the oracle.
+"""The conv kernels' two arithmetic modes against each other and against the oracle.
 
 Default: every f32 operand as two f16 pieces under exact power-of-two row / layer scales, three MFMA products per
-MAC (conv_bf3.hip, conv_os.hip).  DGR_CONV_BF3=1: three exact bf16 pieces, six products.  DGR_CONV_F32=1 +
-DGR_OS_F32=1: v_mfma_f32_* on the f32 operands themselves.  All three are held to the oracle (CPU f32) at the
-1e-4 parity tolerance and to EACH OTHER at 2e-5 -- the split-operand arithmetic must not be distinguishable from
-an f32 MFMA chain at the level the parity tests can see."""
+MAC (conv_wide.hip, conv_os.hip).  DGR_EXACT_F32=1: v_mfma_f32_* on the f32 operands themselves (the reference's
+arithmetic).  Both are held to the oracle (CPU f32) at the 1e-4 parity tolerance and to EACH OTHER at 2e-5 -- the
+split-operand arithmetic must not be distinguishable from an f32 MFMA chain at the level the parity tests can see
+(tests/test_gpu_split_f64.py measures both against f64)."""
 import os
 import subprocess
 import sys
@@ -17,7 +17,7 @@ from oracle import resunet as oresunet
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-MODES = {'f16x2': {}, 'bf16x3': {'DGR_CONV_BF3': '1'}, 'f32': {'DGR_CONV_F32': '1', 'DGR_OS_F32': '1'}}
+MODES = {'f16x2': {}, 'f32': {'DGR_EXACT_F32': '1'}}
 
 
 @pytest.fixture(scope='module')
@@ -25,7 +25,7 @@ def dumps(tmp_path_factory):
     d = tmp_path_factory.mktemp('modes')
     out = {}
     for name, env in MODES.items():
-        e = {k: v for k, v in os.environ.items() if k not in ('DGR_CONV_BF3', 'DGR_CONV_F32', 'DGR_OS_F32')}
+        e = {k: v for k, v in os.environ.items() if k != 'DGR_EXACT_F32'}
         e.update(env)
         path = str(d / f'{name}.npz')
         subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'aux', 'net_modes_dump.py'), path], env=e,
@@ -36,13 +36,9 @@ def dumps(tmp_path_factory):
 
 def test_every_mode_ran_its_own_kernels(dumps):
     k = {m: dumps[m]['kinds'].tolist() for m in MODES}
-    three = lambda n: n.endswith('bf16x3>') or (n.startswith('sparse_conv_bf16x3<') and n.endswith(', 3>'))
-    two = lambda n: 'f16x2' in n or (n.startswith('sparse_conv_bf16x3<') and n.endswith(', 2>'))
-    assert any(n.startswith('sparse_conv_f16x2_ws') for n in k['f16x2']) and any(n.endswith('f16x2>') for n in k['f16x2'])
-    assert not any(three(n) for n in k['f16x2'])
-    assert any(three(n) and n.startswith('sparse_conv_bf16x3') for n in k['bf16x3']) and any(n.endswith('bf16x3>') for n in k['bf16x3'])
-    assert not any(two(n) for n in k['bf16x3'])
-    assert not any(two(n) or three(n) for n in k['f32']) and any(n.endswith('f32>') for n in k['f32'])
+    split = lambda n: 'f16x2' in n
+    assert any(n.startswith('sparse_conv_wide_f16x2') for n in k['f16x2']) and any(n.endswith('f16x2>') for n in k['f16x2'])
+    assert not any(split(n) for n in k['f32']) and any(n.endswith('f32>') for n in k['f32'])
 
 
 def test_modes_agree_with_each_other_and_the_oracle(dumps):
