@@ -559,10 +559,10 @@ def main():
                                              'roofline_ms': sum(roofline_time_s(s) for s in per_layer) * 1e3,
                                              'frac_of_roofline': sum(roofline_time_s(s) for s in per_layer) * 1e3 / conv_ms},
                          'pipe': {'dtype': 'f16 x 2 pieces per f32 operand, f32 accumulate',
-                                  'products_per_mac': PRODUCTS_PER_MAC, 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                                  'products_per_mac': PRODUCTS_PER_MAC, 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                                   'achieved': PRODUCTS_PER_MAC * (dominant['achieved_tflops'] if dominant else achieved),
                                   'frac': PRODUCTS_PER_MAC * (dominant['achieved_tflops'] if dominant else achieved)
-                                          / PEAK_BF16_MFMA_TFLOPS,
+                                          / PEAK_F16_MFMA_TFLOPS,
                                   'note': 'frac > 1 against the f32 MFMA peak is the split-operand arithmetic, not a '
                                           'measurement error; this object is the same kernel against the f16 pipe it issues on'}
                                  if (dominant and 'f16x2' in dominant['name']) else None,

@@ -36,6 +36,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvKArgs {
   const float *in;
@@ -431,11 +432,12 @@ __global__ void __launch_bounds__(256)
       // the row as the wide-layer kernel gathers it (conv_wide.hip): scale from the row's largest |x| after the
       // consumers' pending ReLU (the LPR lanes of a row are consecutive lanes of one wave), two f16 planes
       const int lo = out_relu ? 0 : (int)0x80000000;
+      const i32x4 ab = __builtin_bit_cast(i32x4, acc);   // (bit_cast of a single vector ELEMENT reads element 0)
       int xb[4];
       uint32_t mx = 0;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        xb[u] = max(__builtin_bit_cast(int, acc[u]), lo);   // pending ReLU as one integer max
+        xb[u] = max(ab[u], lo);   // pending ReLU as one integer max
         mx = max(mx, (uint32_t)xb[u] & 0x7fffffffu);
       }
 #pragma unroll

@@ -112,6 +112,7 @@ __global__ void __launch_bounds__(512, 1) sparse_conv_wide_f16x2(ConvWideArgs a,
   constexpr int BUFB = TM * 256;         // bytes per phase buffer
   constexpr int RING = 16;               // tiles in the index / scale rings
   constexpr int AH_I = 8, AH_S = 4;      // tile t + AH_I's indices and tile t + AH_S's scales are requested at tile t
+  static_assert(RING >= 2 * AH_I && AH_I > LEAD && AH_S >= 3 && AH_S < AH_I, "ring distances");
 #ifndef DGR_WIDE_WD
 #define DGR_WIDE_WD 2   // (4: same speed in tools/microbench/wide_check, 5 spilled registers at Cout = 256)
 #endif
@@ -172,11 +173,6 @@ __global__ void __launch_bounds__(512, 1) sparse_conv_wide_f16x2(ConvWideArgs a,
 #ifdef DGR_WIDE_PRIO_MOVERS
     __builtin_amdgcn_s_setprio(DGR_WIDE_PRIO_MOVERS);
 #endif
-    auto idx_dma = [&](int i) {   // input rows of tile i (rows past its end: the last pair again) -> index ring
-      const int4 d = desc(i);
-      __builtin_amdgcn_global_load_lds(DGR_GLOBAL_PTR(a.pair_in + d.y + min(lane, d.z - 1)),
-                                       DGR_LDS_PTR(OFF_IDX + (i & (RING - 1)) * TM * 4), 4, 0, 0);
-    };
     if (pw < PD) {
       // ------------------------------------------------------------ requesters
       // Plain loads into registers (NSET phases in flight), then 16-byte LDS writes: the lane-linear destination of a
@@ -209,7 +205,29 @@ __global__ void __launch_bounds__(512, 1) sparse_conv_wide_f16x2(ConvWideArgs a,
 #pragma unroll
         for (int jj = 0; jj < NI; ++jj) *reinterpret_cast<f32x4 *>(dst + jj * 1024) = Gs[jj];
       };
-      dgr_phase_barrier();   // P0: the storing waves have filled the index ring for the first tiles
+      // index / scale rings: tile u's input rows are loaded at tile u - AH_I and published at tile u - AH_I + 1, its row
+      // scales (through the published indices) loaded at tile u - AH_S and published at u - AH_S + 1 -- a load has a
+      // whole tile to land.  Both requesting waves keep the (identical) rings, so each reads what it wrote itself; the
+      // storing waves see the scales through the phase barriers.
+      int *ring_i = reinterpret_cast<int *>(lds + OFF_IDX);
+      float *ring_s = reinterpret_cast<float *>(lds + OFF_SC);
+      auto load_idx = [&](int i) -> int {   // rows past the tile's end: its last pair again (a valid row)
+        const int4 d = desc(i);
+        return a.pair_in[d.y + min(lane, d.z - 1)];
+      };
+#pragma unroll
+      for (int i = 0; i < AH_I - 1; ++i) ring_i[i * TM + lane] = load_idx(i);
+#pragma unroll
+      for (int i = 0; i < AH_S - 1; ++i) ring_s[i * TM + lane] = a.row_scale[ring_i[i * TM + lane]];
+      int idx_reg = load_idx(AH_I - 1);
+      float sc_reg = a.row_scale[ring_i[(AH_S - 1) * TM + lane]];
+      auto rings = [&](int t) {   // first phase of tile t: publish tile t + AH - 1, request tile t + AH
+        ring_i[((t + AH_I - 1) & (RING - 1)) * TM + lane] = idx_reg;
+        ring_s[((t + AH_S - 1) & (RING - 1)) * TM + lane] = sc_reg;
+        idx_reg = load_idx(t + AH_I);
+        sc_reg = a.row_scale[ring_i[((t + AH_S) & (RING - 1)) * TM + lane]];
+      };
+      dgr_phase_barrier();   // P0
 #pragma unroll
       for (int j = 0; j < NSET; ++j) request(j, G[j]);
       land(0, G[0]); request(NSET, G[0]);
@@ -217,6 +235,7 @@ __global__ void __launch_bounds__(512, 1) sparse_conv_wide_f16x2(ConvWideArgs a,
       dgr_phase_barrier();   // P1: phases 0 and 1 are in LDS
       // ---- phase q: land phase q + 2 (requested four phases ago), request phase q + LEAD into the freed set
       auto phase = [&](int q, f32x4 *Gs) {
+        if (q % PPT == 0) rings(q / PPT);
         DGR_T(ta);
         land(q + 2, Gs);
         DGR_T(tb);
@@ -237,11 +256,6 @@ __global__ void __launch_bounds__(512, 1) sparse_conv_wide_f16x2(ConvWideArgs a,
     }
     // -------------------------------------------------------------- storers
     const int ptid = tid - 64 * (WN + PD);
-    auto scale_dma = [&](int i) {   // row scales of tile i (its indices have landed) -> scale ring
-      const int row = *reinterpret_cast<const int *>(lds + OFF_IDX + (i & (RING - 1)) * TM * 4 + lane * 4);
-      __builtin_amdgcn_global_load_lds(DGR_GLOBAL_PTR(a.row_scale + row),
-                                       DGR_LDS_PTR(OFF_SC + (i & (RING - 1)) * TM * 4), 4, 0, 0);
-    };
     // rows [r0, r0 + RPH) of finished tile u: LDS stage -> HBM, whole rows, scaled back.  Streaming stores: a product
     // row is read exactly once, by reduce_rows.
     auto store_rows = [&](int u, int r0) {
@@ -266,23 +280,10 @@ __global__ void __launch_bounds__(512, 1) sparse_conv_wide_f16x2(ConvWideArgs a,
         if (r < d.z) __builtin_nontemporal_store(v[i], reinterpret_cast<f32x4 *>(a.y + (int64_t)(d.y + r) * COUT + c4));
       }
     };
-#pragma unroll
-    for (int i = 0; i < AH_I; ++i) idx_dma(i);
-    dgr_wait_vmcnt<0>();
     dgr_phase_barrier();   // P0
-#pragma unroll
-    for (int i = 0; i < AH_S; ++i) scale_dma(i);
-    dgr_wait_vmcnt<0>();
     dgr_phase_barrier();   // P1
     auto sphase = [&](int t, auto hc) {
       constexpr int h = decltype(hc)::value;
-      if constexpr (h == 0) {
-        // everything but the newest operations has completed -- in particular the indices of tile t + AH_S and the
-        // scales of tiles t - 1, t - 2, requested several tiles ago -- and the 6-bit counter stays clear of its limit
-        dgr_wait_vmcnt<(NPS * PPT < 40 ? NPS * PPT : 40)>();   // (fewer than one tile's operations of this wave)
-        idx_dma(t + AH_I);
-        scale_dma(t + AH_S);
-      }
       DGR_T(ta);
       if constexpr (h == 0) store_rows(t - 2, (PPT - 1) * RPH);
       else store_rows(t - 1, (h - 1) * RPH);
@@ -299,7 +300,6 @@ __global__ void __launch_bounds__(512, 1) sparse_conv_wide_f16x2(ConvWideArgs a,
         sphase(t, std::integral_constant<int, 3>());
       }
     }
-    dgr_wait_vmcnt<0>();
     DGR_TOUT();
     return;
   }

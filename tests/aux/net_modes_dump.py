@@ -23,6 +23,7 @@ def main(out):
     feats6 = np.cos(rng.uniform(-3, 3, (len(coords6), 6))).astype(np.float32)
     net6 = ops.NetHandle(synth.synth_state_dict(6, 6, 1, 3, 11), 6, 6, 1, 3, False)
     logit = net6.forward(torch.from_numpy(coords6).cuda(), torch.from_numpy(feats6).cuda()).cpu().numpy()
+    inter6 = {'i6_' + n: net6.intermediate(n) for n in ('s1', 's2', 's4', 's8', 's4_tr', 's2_tr', 's1_tr')}
     kinds6 = list(dict.fromkeys(_kinds(net6, coords6, feats6)))
     # 3-D FCGF net (output-stationary kernel), features of very different magnitude per row
     c3 = random_cloud_coords(rng, 3000, 24, 3)
@@ -30,7 +31,7 @@ def main(out):
     net3 = ops.NetHandle(synth.synth_state_dict(3, 1, 32, 7, 0), 3, 1, 32, 7, True)
     F = net3.forward(torch.from_numpy(c3).cuda(), torch.from_numpy(feats3).cuda()).cpu().numpy()
     kinds3 = list(dict.fromkeys(_kinds(net3, c3, feats3)))
-    np.savez(out, logit=logit, F=F, coords6=coords6, feats6=feats6, c3=c3, kinds=np.array(kinds6 + kinds3))
+    np.savez(out, logit=logit, F=F, coords6=coords6, feats6=feats6, c3=c3, kinds=np.array(kinds6 + kinds3), **inter6)
 
 
 def _kinds(net, coords, feats):
