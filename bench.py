@@ -241,6 +241,12 @@ def main():
                     'starts from the raw float64 host points (H2D copy + GPU voxelisation inside the timed region)')
     ap.add_argument('--streams', type=int, default=3, help='HIP streams per GPU, each driven by its own host '
                     'thread with its own library context and its own batches of pairs (independent units)')
+    ap.add_argument('--full-register', action='store_true', help='register() as the reference ships it: final ICP on '
+                    '(use_icp = True, core/deep_global_registration.py:78,317-322); NOT the headline configuration')
+    ap.add_argument('--force-safeguard', action='store_true', help='every pair takes the safeguard branch (RANSAC over its '
+                    'correspondences, :302-315): the confidence gate threshold is put out of reach')
+    ap.add_argument('--dump-results', default=None, help='rank 0 writes the gathered per-pair results (pair ids, T, status, stats) '
+                    'of the last timed step to this .npz (tests)')
     ap.add_argument('--launch-check', action='store_true', help='CPU-only check of the multi-rank plumbing')
     args = ap.parse_args()
 
@@ -288,19 +294,29 @@ def main():
     # ---- which pairs does this rank register? --------------------------------------------------
     vox_cache = {}
 
-    def voxelised(seed):
-        """Pair `seed`: raw points, voxelised tensors on the device, ground-truth pose (cached)."""
-        if seed not in vox_cache:
-            a, b, Tg = synth.synth_pair(seed, n_raw=args.n_raw, kind=args.kind)
-            xa, ca, _ = ops.voxelize(a, args.voxel, 0, device)
-            xb, cb, _ = ops.voxelize(b, args.voxel, 0, device)
-            vox_cache[seed] = (a, b, Tg, xa, ca, xb, cb)
-        return vox_cache[seed]
+    def voxelised(seed, keep=True):
+        """Pair `seed`: raw points (kept only for --from-host), voxelised tensors on the device, ground-truth pose.
+        `keep=False`: not cached (the cost pass of the strong-scaling mode looks at pairs this rank may not get)."""
+        if seed in vox_cache:
+            return vox_cache[seed]
+        a, b, Tg = synth.synth_pair(seed, n_raw=args.n_raw, kind=args.kind)
+        xa, ca, _ = ops.voxelize(a, args.voxel, 0, device)
+        xb, cb, _ = ops.voxelize(b, args.voxel, 0, device)
+        rec = (a if args.from_host else None, b if args.from_host else None, Tg, xa, ca, xb, cb)
+        if keep:
+            vox_cache[seed] = rec
+        return rec
 
     if args.total_pairs:
         P = args.total_pairs
         lo, hi = ddist.shard_range(P, rank, world)          # provisional contiguous block: measure its costs
-        costs = [float(len(voxelised(s)[3])) * float(len(voxelised(s)[5])) for s in range(lo, hi)]
+        if P < world:
+            raise SystemExit(f'bench.py: --total-pairs {P} is fewer than the {world} ranks')
+        costs = []
+        for s_ in range(lo, hi):
+            rec = voxelised(s_, keep=False)
+            costs.append(float(len(rec[3])) * float(len(rec[5])))
+            del rec
         cost = ddist.all_gather_vector(costs, P, lo, device=coll_dev)
         my_pairs = ddist.deal_by_cost(cost, world)[rank]    # sorted by N0 * N1, dealt snake round-robin
         log(f'strong scaling: {P} pairs dealt by cost, this rank {len(my_pairs)} (cost share '
@@ -375,9 +391,13 @@ def main():
                     xb, cb, _ = self.dgr.preprocess(b, batch_index=q)
                     x0.append(xa); c0.append(ca); x1.append(xb); c1.append(cb)
                 bt['C0'], bt['X0'], bt['C1'], bt['X1'] = torch.cat(c0), torch.cat(x0), torch.cat(c1), torch.cat(x1)
+            forced = bt['forced']
+            if args.force_safeguard and forced is not None:
+                forced = bt.setdefault('forced_low', torch.full_like(forced, -20.0))   # no pair passes the confidence gate
             return self.dgr.register_voxelized(bt['C0'], bt['X0'], bt['off0'], bt['C1'], bt['X1'], bt['off1'],
-                                               forced_logits=bt['forced'], skip_refinement=args.no_refine,
-                                               override_idx1=bt['ovr'])
+                                               forced_logits=forced, skip_refinement=args.no_refine,
+                                               override_idx1=bt['ovr'], safeguard=args.force_safeguard,
+                                               icp=args.full_register)
 
         def step(self):
             self.results = [self.run_batch(bt) for bt in self.batches]
@@ -401,6 +421,7 @@ def main():
         torch.cuda.synchronize()
 
     barrier()
+    cpu0 = time.process_time()
     t0 = time.perf_counter()
     if len(workers) == 1:
         workers[0].run(args.steps)
@@ -412,6 +433,8 @@ def main():
             th.join()
     barrier()
     elapsed = time.perf_counter() - t0
+    # host CPU seconds (all threads of this rank) per step: the budget of N ranks x S driver threads on one node
+    cpu_s_per_step = (time.process_time() - cpu0) / args.steps
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -503,30 +526,41 @@ def main():
         achieved = flop / (conv_ms * 1e-3) / 1e12
         T_all, status_all, stats_all = gathered
         ids_all = [int(round(v)) for v in gathered_ids[0][:, 0, 0]]
+        if args.dump_results:
+            np.savez(args.dump_results, ids=np.asarray(ids_all), T=T_all, status=status_all, stats=stats_all)
         te, re = [], []
         for p, seed in enumerate(ids_all):
-            if status_all[p] == 0:
+            if status_all[p] in (0, 3):   # estimated by the network path or by the safeguard RANSAC
                 Tg = vox_cache[seed][2] if seed in vox_cache else synth.synth_pair(seed, n_raw=args.n_raw, kind=args.kind)[2]
                 te.append(float(np.linalg.norm(T_all[p][:3, 3] - Tg[:3, 3])))
                 c = (np.trace(T_all[p][:3, :3].T @ Tg[:3, :3]) - 1) / 2
                 re.append(float(np.degrees(np.arccos(np.clip(c, -1, 1)))))
         # HBM traffic / MFMA-busy of the dominant kernel from PMC counters: separate rocprofv3 --pmc passes on
         # the same per-stream workload (tools/evidence.sh), committed under profiles/ -- not measurable from inside
-        # this process, hence the field name
-        pmc = None
-        ppath = os.path.join(ROOT, 'profiles', 'r02_dominant_pmc.json')
-        if os.path.exists(ppath):
-            pj = json.load(open(ppath))
-            if dominant and pj.get('kernel') and pj['kernel'] in dominant['name'] and pj.get('workload') == cfg_label(args):
-                pmc = pj
-        peak = PEAK_FP32_MFMA_TFLOPS
+        # this process; quoted only when kernel name and workload label match this run
+        pmc, pmc_file = None, None
+        for cand in ('r03_dominant_pmc.json', 'r02_dominant_pmc.json'):
+            ppath = os.path.join(ROOT, 'profiles', cand)
+            if os.path.exists(ppath):
+                pj = json.load(open(ppath))
+                if dominant and pj.get('kernel') and pj['kernel'] in dominant['name'] and pj.get('workload') == cfg_label(args):
+                    pmc, pmc_file = pj, cand
+                    break
+        split = bool(dominant and 'f16x2' in dominant['name'])     # the dominant kernel issues on the f16 pipe
+        products = PRODUCTS_PER_MAC if split else 1
+        peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
+        alg = dominant['achieved_tflops'] if dominant else achieved
         pairs_per_step = (args.total_pairs or world * n_local)
         ms_per_step = elapsed / args.steps * 1e3
         out = {
-            'metric': 'pair registrations/sec (FCGF x2 + 1-NN + 6-D inlier net + gate + weighted Procrustes + SE(3) refinement)',
+            'metric': 'pair registrations/sec (FCGF x2 + 1-NN + 6-D inlier net + gate + weighted Procrustes + SE(3) refinement'
+                      + (' + ICP' if args.full_register else '') + (', safeguard RANSAC forced' if args.force_safeguard else '') + ')',
             'value': pairs_per_step * args.steps / elapsed, 'unit': 'pairs/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
-            'higher_is_better': True, 'scaling': 'strong' if args.total_pairs else 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'higher_is_better': True, 'scaling': 'strong' if args.total_pairs else 'weak', 'vs_baseline': None,
+            'dtype': ('f32 results via 2 x f16 split operands (3 f16 MFMA products per MAC, f32 accumulate); k = 1 convs, '
+                      'kNN re-evaluation and registration in exact f32, SVD in f64') if split else
+                     'f32 (v_mfma_f32_*_f32 on the f32 operands: DGR_EXACT_F32=1); SVD in f64',
             'data': 'synthetic 3DMatch-shaped pairs, seeded synthetic weights, teacher-forced matches (20% GT) and inlier logits'
                     + ('; PCIe-inclusive: raw host points -> H2D -> voxelisation inside the timed region' if args.from_host else ''),
             'config': {'workload': f'{pairs_per_step} pairs/step ({world} GPU(s) x {len(workers)} stream(s) x batches of {B}), '
@@ -535,16 +569,22 @@ def main():
                        'streams_per_gpu': len(workers),
                        'voxels_per_pair': [int(off0[-1] / nb), int(off1[-1] / nb)],
                        'pairs_per_step': pairs_per_step, 'refinement': not args.no_refine,
+                       'use_icp': bool(args.full_register), 'forced_safeguard': bool(args.force_safeguard),
                        'parallelism': f'pair-sharded x{world}, no data-path collective'},
-            # roofline of the DOMINANT conv kernel variant: algorithmic FLOP per launch / its average launch
-            # duration (HIP events on the launch stream); `all_conv_layers` is the same over every layer launch
-            'roofline': {'bound': 'mfma', 'achieved': dominant['achieved_tflops'] if dominant else achieved,
-                         'peak': peak, 'unit': 'TFLOP/s',
-                         'frac': (dominant['achieved_tflops'] if dominant else achieved) / peak,
-                         'traffic': None,
-                         'traffic_from_profiles': pmc.get('hbm_bytes_per_launch') if pmc else None,
+            # roofline of the DOMINANT conv kernel variant against the pipe it issues on: achieved = products per MAC x
+            # the algorithmic FLOP of its launches / their durations (HIP events on the launch stream around the MFMA
+            # phase of every layer during a profiled re-run of the same steps by one stream)
+            'roofline': {'bound': 'mfma', 'achieved': products * alg, 'peak': peak, 'unit': 'TFLOP/s',
+                         'frac': products * alg / peak,
+                         'pipe': 'dense f16 MFMA (v_mfma_f32_32x32x16_f16)' if split else 'f32 MFMA (v_mfma_f32_32x32x2_f32)',
+                         'products_per_mac': products, 'algorithmic_tflops': alg,
+                         'limited_by': 'not the matrix pipe: per-CU vector-memory throughput (4 bytes of weights per MAC-column '
+                                       'at 64 pairs per tile) and the HBM write stream of the product rows (DESIGN.md 4.2)'
+                                       if split else None,
+                         'traffic': pmc.get('hbm_bytes_per_launch') if pmc else None,
+                         'traffic_source': (f'profiles/{pmc_file}: separate rocprofv3 --pmc passes of the one-stream command, '
+                                            '2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, per launch') if pmc else None,
                          'mfma_busy_from_profiles': pmc.get('mfma_busy') if pmc else None,
-                         'pmc_source': 'profiles/r02_dominant_pmc.json (separate rocprofv3 --pmc passes, 2 x FETCH_SIZE + WRITE_SIZE)' if pmc else None,
                          'kernel': dominant['name'] if dominant else 'sparse conv (all variants)',
                          'launches_per_batch': dominant['launches_per_batch'] if dominant else n_launch,
                          'avg_launch_us': dominant['avg_launch_us'] if dominant else conv_ms * 1e3 / n_launch,
@@ -552,23 +592,19 @@ def main():
                          'share_of_conv_flop': dominant['share_of_conv_flop'] if dominant else 1.0,
                          'share_of_conv_time': dominant['share_of_conv_time'] if dominant else 1.0,
                          'algorithmic_bytes_per_launch': dominant['algorithmic_bytes_per_launch'] if dominant else byts / n_launch,
-                         'all_conv_layers': {'achieved': achieved, 'frac': achieved / peak,
+                         # the same launches counted as plain f32 MACs against the f32 MFMA peak (what an exact-f32
+                         # kernel is priced against); NOT a roofline fraction of this kernel -- it can exceed 1
+                         'f32_view': {'achieved': alg, 'peak': PEAK_FP32_MFMA_TFLOPS, 'ratio': alg / PEAK_FP32_MFMA_TFLOPS},
+                         'all_conv_layers': {'achieved_algorithmic_tflops': achieved,
                                              'launches_per_batch': n_launch, 'avg_launch_us': conv_ms * 1e3 / n_launch,
                                              'gflop_per_batch': flop / 1e9, 'compulsory_gbytes_per_batch': byts / 1e9,
                                              'hbm_gbps_compulsory': byts / (conv_ms * 1e-3) / 1e9,
-                                             'roofline_ms': sum(roofline_time_s(s) for s in per_layer) * 1e3,
-                                             'frac_of_roofline': sum(roofline_time_s(s) for s in per_layer) * 1e3 / conv_ms},
-                         'pipe': {'dtype': 'f16 x 2 pieces per f32 operand, f32 accumulate',
-                                  'products_per_mac': PRODUCTS_PER_MAC, 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                                  'achieved': PRODUCTS_PER_MAC * (dominant['achieved_tflops'] if dominant else achieved),
-                                  'frac': PRODUCTS_PER_MAC * (dominant['achieved_tflops'] if dominant else achieved)
-                                          / PEAK_F16_MFMA_TFLOPS,
-                                  'note': 'frac > 1 against the f32 MFMA peak is the split-operand arithmetic, not a '
-                                          'measurement error; this object is the same kernel against the f16 pipe it issues on'}
-                                 if (dominant and 'f16x2' in dominant['name']) else None,
+                                             'roofline_ms_f32_model': sum(roofline_time_s(s) for s in per_layer) * 1e3,
+                                             'frac_of_roofline_f32_model': sum(roofline_time_s(s) for s in per_layer) * 1e3 / conv_ms},
                          'c_le_64_layers': c64,
                          'by_kernel': {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in g.items()}
                                        for k, g in groups.items()}},
+            'host_cpu_s_per_step_per_rank': cpu_s_per_step,
             'stage_ms_per_batch': {k: round(v, 3) for k, v in prof.items() if k != 'conv_launches'},
             'te_m_mean': float(np.mean(te)) if te else None, 're_deg_mean': float(np.mean(re)) if re else None,
             'status_counts': {str(k): int((status_all == k).sum()) for k in np.unique(status_all)},

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DGR_HIP_LIB') or os.path.join(_HERE, 'lib', 'libdgr_hip.so')  # override: experiments only
 
 DGR_OK, DGR_EINVAL, DGR_EHIP, DGR_ENOMEM, DGR_ESVD, DGR_EINTERNAL = 0, -1, -2, -3, -4, -5
-STATUS_OK, STATUS_LOW_CONFIDENCE, STATUS_SVD_FAILED, STATUS_SAFEGUARD = 0, 1, 2, 3
+STATUS_OK, STATUS_LOW_CONFIDENCE, STATUS_SVD_FAILED, STATUS_SAFEGUARD, STATUS_ICP_SKIPPED = 0, 1, 2, 3, 4
 
 c_i32p, c_i64p, c_f32p, c_f64p = (C.POINTER(C.c_int32), C.POINTER(C.c_int64),
                                   C.POINTER(C.c_float), C.POINTER(C.c_double))
@@ -76,6 +76,7 @@ SIGNATURES = {
     'dgr_ctx_conv_launch_kinds': (C.c_int, [vp, C.c_char_p, C.c_int64, C.POINTER(C.c_int64)]),
     'dgr_debug_ortho2rotation': (C.c_int, [vp, vp, C.c_int64, vp, vp, vp, vp]),
     'dgr_debug_smooth_l1': (C.c_int, [vp, vp, vp, C.c_int64, C.c_float, vp, vp]),
+    'dgr_debug_conv_layer': (C.c_int, [vp, vp, C.c_int, vp, vp, C.c_int, C.c_int64, vp, vp]),
 }
 
 _lib = None

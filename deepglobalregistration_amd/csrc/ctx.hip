@@ -143,7 +143,7 @@ extern "C" int dgr_ctx_set_profiling(dgr_ctx *ctx, int enable) {
   return DGR_OK;
 }
 
-extern "C" int dgr_ctx_stage_times(dgr_ctx *ctx, float times_ms[8]) {
+extern "C" int dgr_ctx_stage_times(dgr_ctx *ctx, float times_ms[9]) {
   DGR_REQUIRE(ctx != nullptr && times_ms != nullptr, "bad argument");
   memcpy(times_ms, ctx->stage_ms, sizeof(ctx->stage_ms));
   return DGR_OK;

@@ -254,7 +254,7 @@ struct dgr_ctx {
   int num_cus = 256;
   DgrArena arena;
   bool profiling = false;
-  float stage_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float stage_ms[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // [8] = the Open3D-equivalent steps of dgr_register_batch
   int64_t conv_launches = 0;  // conv kernel launches covered by stage_ms[7]
   DgrBatchOutputs last;
   DgrEventPool events;
@@ -284,6 +284,24 @@ int dgr_icp_impl(dgr_ctx *ctx, const float *src, int64_t N0, const float *dst, i
                  double *stats_out, hipStream_t stream);
 int dgr_ransac_impl(dgr_ctx *ctx, const float *X, const float *Y, int64_t N, double max_dist, int64_t num_hypotheses,
                     uint32_t seed, double *T_out, double *stats_out, hipStream_t stream);
+// the same in host phases (o3d.hip): enqueue-only pieces, so that a batch synchronises the stream twice, not per pair
+struct DgrIcpJob {
+  const float *src = nullptr, *dst = nullptr;
+  int64_t N0 = 0, N1 = 0;
+  double max_dist = 0;
+  int nblocks = 0;
+  void *st = nullptr;            // device IcpState
+  double *P = nullptr, *sorted = nullptr, *partial = nullptr;
+  int32_t ncell = 0;             // host copy of the grid size, valid after the sync behind dgr_icp_begin
+  double host_state[64];         // host copy of the IcpState, valid after the sync behind dgr_icp_run
+};
+int dgr_icp_begin(dgr_ctx *ctx, const float *src, int64_t N0, const float *dst, int64_t N1, double max_dist,
+                  const double *T_init_dev /* device, nullable = identity */, DgrIcpJob *job, hipStream_t stream);
+int dgr_icp_run(dgr_ctx *ctx, DgrIcpJob *job, int max_iter, double rel_fitness, double rel_rmse, hipStream_t stream);
+void dgr_icp_finish(const DgrIcpJob *job, double *T_out, double *stats_out);
+constexpr int DGR_RANSAC_RESULT_DOUBLES = 19;   // device record: T[16], winning hypothesis, inlier count, rmse
+int dgr_ransac_begin(dgr_ctx *ctx, const float *X, const float *Y, int64_t N, double max_dist, int64_t num_hypotheses,
+                     uint32_t seed, double **result_dev, hipStream_t stream);
 struct DgrRegResult {  // device-side result record of the registration kernel
   float R[9];
   float t[3];

@@ -674,6 +674,43 @@ extern "C" int dgr_resunet_forward(dgr_ctx *ctx, dgr_net *net, const int32_t *co
   return DGR_OK;
 }
 
+// One conv layer of a network on a caller-supplied feature matrix, through exactly the kernels the forward uses for it
+// (split rows + the wide-layer kernel + the reduction in the 6-D net, the output-stationary kernel in the 3-D net) over
+// the same-stride 3^D kernel map of `coords`.  For layers with a 3^D kernel and Cin >= 32.  Test instrument: it lets the
+// parity tests feed the split-operand kernels rows of any magnitude pattern (tests/test_gpu_split_f64.py).
+extern "C" int dgr_debug_conv_layer(dgr_ctx *ctx, dgr_net *net, int layer, const int32_t *coords, const float *in,
+                                    int in_relu, int64_t N, float *out, dgr_stream stream_) {
+  DGR_REQUIRE(ctx && net && coords && in && out && N > 0, "dgr_debug_conv_layer: bad argument");
+  DGR_REQUIRE(layer >= 0 && layer < (int)net->layers.size(), "layer %d out of range", layer);
+  const DgrLayer &L = net->layers[layer];
+  int k3 = 1;
+  for (int d = 0; d < net->D; ++d) k3 *= 3;
+  DGR_REQUIRE(L.K == k3 && L.cin >= 32, "dgr_debug_conv_layer: layer %s is not a 3^D conv with >= 32 input channels", L.name.c_str());
+  hipStream_t stream = (hipStream_t)stream_;
+  DGR_HIP_CHECK(hipSetDevice(ctx->device));
+  DGR_CHECK(ctx->arena.reset());
+  DGR_CHECK(dgr_ctx_new_flag(ctx, stream));
+  dgr_ctx_begin_profile(ctx);
+  DgrArena &A = ctx->arena;
+  Fwd f;
+  f.ctx = ctx; f.net = net; f.stream = stream; f.prof = false;
+  f.ms.overflow = ctx->flag_dev;
+  DGR_CHECK(dgr_build_maps(A, coords, N, net->D, 3, &f.ms, stream, false, /*lean=*/true, /*nbr_tables=*/net->D == 3));
+  const int64_t n_cap = f.ms.cm[0].n_cap;
+  if (!f.ms.use_nbr) DGR_ALLOC(f.ybuf, A, float, f.ms.same[0].pair_cap * L.cout);
+  Tensor tin{const_cast<float *>(in), L.cin, in_relu}, tout{out, L.cout, 0};
+  if (L.wb) {
+    tin.split.channels = L.cin;
+    DGR_ALLOC(tin.split.planes, A, unsigned char, (size_t)n_cap * 4 * L.cin);
+    DGR_ALLOC(tin.split.scale, A, float, n_cap);
+    DGR_CHECK(dgr_split_rows(in, L.cin, in_relu, f.ms.cm[0].n_dev, n_cap, tin.split, stream));
+  }
+  DGR_CHECK(f.conv(layer, tin, &f.ms.same[0], false, 0, 0, tout, nullptr));
+  DGR_CHECK(dgr_ctx_check_flag(ctx, stream));   // synchronises the stream
+  dgr_net_invalidate_runs(net);
+  return DGR_OK;
+}
+
 extern "C" int dgr_net_get_intermediate(dgr_ctx *ctx, dgr_net *net, const char *name, float *host_out,
                                         int64_t capacity, int64_t *rows, int64_t *cols) {
   DGR_REQUIRE(ctx && net && name && rows && cols, "NULL argument");

@@ -13,6 +13,7 @@ int dgr_icp_impl(dgr_ctx *ctx, const float *src, int64_t N0, const float *dst, i
                  double *stats_out, hipStream_t stream);
 int dgr_ransac_impl(dgr_ctx *ctx, const float *X, const float *Y, int64_t N, double max_dist, int64_t num_hypotheses,
                     uint32_t seed, double *T_out, double *stats_out, hipStream_t stream);
+#include <cstddef>
 #include <cstring>
 
 // ------------------------------------------------------------------------------------------------
@@ -266,61 +267,100 @@ extern "C" int dgr_icp_point_to_point(dgr_ctx *ctx, const float *src, int64_t N0
                       (hipStream_t)stream_);
 }
 
-// the same without resetting the context's arena (scratch is taken behind the caller's allocations and given back):
-// the fused batched pipeline calls it per pair
-int dgr_icp_impl(dgr_ctx *ctx, const float *src, int64_t N0, const float *dst, int64_t N1, double max_dist,
-                 const double *T_init, int max_iter, double rel_fitness, double rel_rmse, double *T_out,
-                 double *stats_out, hipStream_t stream) {
+// ICP in three host phases, so that a batch of pairs needs two stream synchronisations in total instead of two per pair
+// (pipeline.hip): begin = scratch + target bounding box / grid layout (the cell count comes back to the host), run = grid
+// build + all iterations + the state's way back, finish = results out of the job.  All scratch is taken behind the
+// caller's arena allocations; the caller rewinds once the stream has been synchronised.
+constexpr int32_t ICP_CELL_CAP = 4 << 20;
+
+__global__ void icp_tinit_kernel(const double *T_init, double *Tdev) {
+  if (threadIdx.x < 16) Tdev[threadIdx.x] = T_init ? T_init[threadIdx.x] : ((threadIdx.x % 5 == 0) ? 1.0 : 0.0);
+}
+
+int dgr_icp_begin(dgr_ctx *ctx, const float *src, int64_t N0, const float *dst, int64_t N1, double max_dist,
+                  const double *T_init_dev, DgrIcpJob *job, hipStream_t stream) {
   DGR_REQUIRE(N0 > 0 && N1 > 0, "ICP: empty point cloud (N0=%lld, N1=%lld)", (long long)N0, (long long)N1);
-  DGR_REQUIRE(max_dist > 0.0 && max_iter >= 0 && max_iter <= 10000, "ICP: bad max_dist / max_iter");
+  DGR_REQUIRE(max_dist > 0.0, "ICP: bad max_dist");
   DgrArena &A = ctx->arena;
-  const DgrArena::Mark icp_mark = A.mark();
-  constexpr int32_t CELL_CAP = 4 << 20;
   IcpState *st;
-  double *Tdev, *P, *sorted, *partial;
-  int32_t *counts, *starts, *cursor;
-  const int nblocks = (int)dgr_ceil_div(N0, ICP_THREADS);
+  double *Tdev;
+  job->src = src; job->dst = dst; job->N0 = N0; job->N1 = N1; job->max_dist = max_dist;
+  job->nblocks = (int)dgr_ceil_div(N0, ICP_THREADS);
   DGR_ALLOC(st, A, IcpState, 1);
   DGR_ALLOC(Tdev, A, double, 16);
-  DGR_ALLOC(P, A, double, N0 * 3);
-  DGR_ALLOC(sorted, A, double, N1 * 3);
-  DGR_ALLOC(partial, A, double, (int64_t)nblocks * ICP_NSUM);
-  DGR_ALLOC(counts, A, int32_t, CELL_CAP + 1);
-  DGR_ALLOC(starts, A, int32_t, CELL_CAP + 1);
-  DGR_ALLOC(cursor, A, int32_t, CELL_CAP + 1);
-  double Ti[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-  if (T_init) memcpy(Ti, T_init, sizeof(Ti));
-  DGR_HIP_CHECK(hipMemcpyAsync(Tdev, Ti, sizeof(Ti), hipMemcpyHostToDevice, stream));
+  DGR_ALLOC(job->P, A, double, N0 * 3);
+  DGR_ALLOC(job->sorted, A, double, N1 * 3);
+  DGR_ALLOC(job->partial, A, double, (int64_t)job->nblocks * ICP_NSUM);
+  job->st = st;
+  icp_tinit_kernel<<<1, 64, 0, stream>>>(T_init_dev, Tdev);
   icp_init_kernel<<<1, 64, 0, stream>>>(st, Tdev);
   icp_bbox_kernel<<<(int)dgr_ceil_div(N1, ICP_THREADS), ICP_THREADS, 0, stream>>>(dst, N1, st);
-  icp_layout_kernel<<<1, 64, 0, stream>>>(st, max_dist, CELL_CAP);
-  // one host round trip (the stack buffer Ti needs one anyway): the actual cell count bounds the clears and the scan
-  // below -- a 3DMatch fragment at 10 cm cells has ~10^5 cells, not the 4 M of the budget
-  int32_t ncell = 0;
-  DGR_HIP_CHECK(hipMemcpyAsync(&ncell, &st->ncell, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-  DGR_HIP_CHECK(hipStreamSynchronize(stream));
-  DGR_REQUIRE(ncell >= 1 && ncell <= CELL_CAP, "ICP: target grid of %d cells (non-finite or empty target cloud?)", ncell);
-  DGR_HIP_CHECK(hipMemsetAsync(counts, 0, (size_t)(ncell + 1) * sizeof(int32_t), stream));
-  DGR_HIP_CHECK(hipMemsetAsync(cursor, 0, (size_t)(ncell + 1) * sizeof(int32_t), stream));
-  icp_count_kernel<<<(int)dgr_ceil_div(N1, 256), 256, 0, stream>>>(dst, N1, st, counts);
-  DGR_CHECK(dgr_exclusive_scan_i32(A, counts, starts, (int64_t)ncell + 1, nullptr, stream));
-  icp_fill_kernel<<<(int)dgr_ceil_div(N1, 256), 256, 0, stream>>>(dst, N1, st, starts, cursor, sorted);
-  icp_transform_init_kernel<<<(int)dgr_ceil_div(N0, 256), 256, 0, stream>>>(src, N0, st, P);
+  icp_layout_kernel<<<1, 64, 0, stream>>>(st, max_dist, ICP_CELL_CAP);
+  DGR_LAUNCH_CHECK();
+  // the actual cell count bounds the clears and the scan of the grid build -- a 3DMatch fragment at 10 cm cells has
+  // ~10^5 cells, not the 4 M of the budget
+  job->ncell = 0;
+  DGR_HIP_CHECK(hipMemcpyAsync(&job->ncell, &st->ncell, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  return DGR_OK;
+}
+
+// after the stream has been synchronised behind dgr_icp_begin
+int dgr_icp_run(dgr_ctx *ctx, DgrIcpJob *job, int max_iter, double rel_fitness, double rel_rmse, hipStream_t stream) {
+  DGR_REQUIRE(max_iter >= 0 && max_iter <= 10000, "ICP: bad max_iter");
+  DGR_REQUIRE(job->ncell >= 1 && job->ncell <= ICP_CELL_CAP, "ICP: target grid of %d cells (non-finite or empty target cloud?)",
+              job->ncell);
+  DgrArena &A = ctx->arena;
+  IcpState *st = static_cast<IcpState *>(job->st);
+  int32_t *counts, *starts, *cursor;
+  DGR_ALLOC(counts, A, int32_t, job->ncell + 1);
+  DGR_ALLOC(starts, A, int32_t, job->ncell + 1);
+  DGR_ALLOC(cursor, A, int32_t, job->ncell + 1);
+  DGR_HIP_CHECK(hipMemsetAsync(counts, 0, (size_t)(job->ncell + 1) * sizeof(int32_t), stream));
+  DGR_HIP_CHECK(hipMemsetAsync(cursor, 0, (size_t)(job->ncell + 1) * sizeof(int32_t), stream));
+  icp_count_kernel<<<(int)dgr_ceil_div(job->N1, 256), 256, 0, stream>>>(job->dst, job->N1, st, counts);
+  DGR_CHECK(dgr_exclusive_scan_i32(A, counts, starts, (int64_t)job->ncell + 1, nullptr, stream));
+  icp_fill_kernel<<<(int)dgr_ceil_div(job->N1, 256), 256, 0, stream>>>(job->dst, job->N1, st, starts, cursor, job->sorted);
+  icp_transform_init_kernel<<<(int)dgr_ceil_div(job->N0, 256), 256, 0, stream>>>(job->src, job->N0, st, job->P);
   DGR_LAUNCH_CHECK();
   for (int it = 0; it <= max_iter; ++it) {
-    icp_step_kernel<<<nblocks, ICP_THREADS, 0, stream>>>(P, N0, st, starts, sorted, max_dist, partial);
-    icp_solve_kernel<<<1, ICP_THREADS, 0, stream>>>(st, partial, nblocks, N0, max_iter, rel_fitness, rel_rmse);
+    icp_step_kernel<<<job->nblocks, ICP_THREADS, 0, stream>>>(job->P, job->N0, st, starts, job->sorted, job->max_dist, job->partial);
+    icp_solve_kernel<<<1, ICP_THREADS, 0, stream>>>(st, job->partial, job->nblocks, job->N0, max_iter, rel_fitness, rel_rmse);
   }
   DGR_LAUNCH_CHECK();
+  static_assert(sizeof(job->host_state) >= sizeof(IcpState), "host copy of the ICP state");
+  DGR_HIP_CHECK(hipMemcpyAsync(job->host_state, st, sizeof(IcpState), hipMemcpyDeviceToHost, stream));
+  return DGR_OK;
+}
+
+// after the stream has been synchronised behind dgr_icp_run
+void dgr_icp_finish(const DgrIcpJob *job, double *T_out, double *stats_out) {
   IcpState host;
-  DGR_HIP_CHECK(hipMemcpyAsync(&host, st, sizeof(IcpState), hipMemcpyDeviceToHost, stream));
-  DGR_HIP_CHECK(hipStreamSynchronize(stream));
+  memcpy(&host, job->host_state, sizeof(IcpState));
   memcpy(T_out, host.T, sizeof(double) * 16);
   if (stats_out) {
     stats_out[0] = host.fitness;
     stats_out[1] = host.rmse;
     stats_out[2] = (double)host.iters;
   }
+}
+
+// one ICP (the stand-alone entry point): T_init is a host matrix
+int dgr_icp_impl(dgr_ctx *ctx, const float *src, int64_t N0, const float *dst, int64_t N1, double max_dist,
+                 const double *T_init, int max_iter, double rel_fitness, double rel_rmse, double *T_out,
+                 double *stats_out, hipStream_t stream) {
+  DgrArena &A = ctx->arena;
+  const DgrArena::Mark icp_mark = A.mark();
+  double *Ti_dev = nullptr;
+  if (T_init) {
+    DGR_ALLOC(Ti_dev, A, double, 16);
+    DGR_HIP_CHECK(hipMemcpyAsync(Ti_dev, T_init, 16 * sizeof(double), hipMemcpyHostToDevice, stream));
+  }
+  DgrIcpJob job;
+  DGR_CHECK(dgr_icp_begin(ctx, src, N0, dst, N1, max_dist, Ti_dev, &job, stream));
+  DGR_HIP_CHECK(hipStreamSynchronize(stream));
+  DGR_CHECK(dgr_icp_run(ctx, &job, max_iter, rel_fitness, rel_rmse, stream));
+  DGR_HIP_CHECK(hipStreamSynchronize(stream));
+  dgr_icp_finish(&job, T_out, stats_out);
   A.rewind(icp_mark);   // the stream was synchronised above: nothing is in flight on the scratch
   return DGR_OK;
 }
@@ -469,12 +509,12 @@ extern "C" int dgr_ransac_correspondence(dgr_ctx *ctx, const float *X, const flo
   return dgr_ransac_impl(ctx, X, Y, N, max_dist, num_hypotheses, seed, T_out, stats_out, (hipStream_t)stream_);
 }
 
-int dgr_ransac_impl(dgr_ctx *ctx, const float *X, const float *Y, int64_t N, double max_dist, int64_t num_hypotheses,
-                    uint32_t seed, double *T_out, double *stats_out, hipStream_t stream) {
+// enqueue only: the result record (T first: a device-side T_init for dgr_icp_begin) stays in the arena
+int dgr_ransac_begin(dgr_ctx *ctx, const float *X, const float *Y, int64_t N, double max_dist, int64_t num_hypotheses,
+                     uint32_t seed, double **result_dev, hipStream_t stream) {
   DGR_REQUIRE(N > 0 && N < (1ll << 31), "RANSAC: bad correspondence count %lld", (long long)N);
   DGR_REQUIRE(num_hypotheses > 0 && num_hypotheses <= (1ll << 30), "RANSAC: bad hypothesis count");
   DGR_REQUIRE(max_dist > 0.0, "RANSAC: bad distance threshold");
-  const DgrArena::Mark rs_mark = ctx->arena.mark();
   const int nblocks = (int)dgr_ceil_div(num_hypotheses, RS_THREADS);
   RsBest *bb;
   RsResult *res;
@@ -484,14 +524,24 @@ int dgr_ransac_impl(dgr_ctx *ctx, const float *X, const float *Y, int64_t N, dou
   ransac_eval_kernel<<<nblocks, RS_THREADS, 0, stream>>>(X, Y, N, seed, num_hypotheses, md * md, bb);
   ransac_final_kernel<<<1, 256, 0, stream>>>(X, Y, N, seed, bb, nblocks, res);
   DGR_LAUNCH_CHECK();
-  RsResult host;
-  DGR_HIP_CHECK(hipMemcpyAsync(&host, res, sizeof(RsResult), hipMemcpyDeviceToHost, stream));
+  static_assert(offsetof(RsResult, T) == 0 && sizeof(RsResult) == DGR_RANSAC_RESULT_DOUBLES * sizeof(double), "result record layout");
+  *result_dev = reinterpret_cast<double *>(res);
+  return DGR_OK;
+}
+
+int dgr_ransac_impl(dgr_ctx *ctx, const float *X, const float *Y, int64_t N, double max_dist, int64_t num_hypotheses,
+                    uint32_t seed, double *T_out, double *stats_out, hipStream_t stream) {
+  const DgrArena::Mark rs_mark = ctx->arena.mark();
+  double *res;
+  DGR_CHECK(dgr_ransac_begin(ctx, X, Y, N, max_dist, num_hypotheses, seed, &res, stream));
+  double host[DGR_RANSAC_RESULT_DOUBLES];
+  DGR_HIP_CHECK(hipMemcpyAsync(host, res, sizeof(host), hipMemcpyDeviceToHost, stream));
   DGR_HIP_CHECK(hipStreamSynchronize(stream));
-  memcpy(T_out, host.T, sizeof(double) * 16);
+  memcpy(T_out, host, sizeof(double) * 16);
   if (stats_out) {
-    stats_out[0] = host.best_h;
-    stats_out[1] = host.count;
-    stats_out[2] = host.rmse;
+    stats_out[0] = host[16];
+    stats_out[1] = host[17];
+    stats_out[2] = host[18];
   }
   ctx->arena.rewind(rs_mark);   // the stream was synchronised above
   return DGR_OK;

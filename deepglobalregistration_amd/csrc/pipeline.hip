@@ -149,7 +149,7 @@ __global__ void add_offset_kernel(int64_t *idx, int64_t n, int64_t off) {
 struct StageTimer {
   dgr_ctx *ctx;
   hipStream_t stream;
-  hipEvent_t e[8][2];
+  hipEvent_t e[9][2];
   bool on;
   int rec(int stage, int which) {
     if (!on) return DGR_OK;
@@ -267,28 +267,6 @@ extern "C" int dgr_register_batch(dgr_ctx *ctx, dgr_net *fcgf, dgr_net *inlier, 
       }
     }
     status_out[p] = r.status;
-    // the two Open3D steps that end register() (:302-322), per pair, without leaving the library
-    if ((prm->safeguard && r.status == DGR_STATUS_LOW_CONFIDENCE) || prm->use_icp) {
-      const int64_t m0 = off0[p + 1] - off0[p], m1 = off1[p + 1] - off1[p];
-      double Td[16];
-      for (int i = 0; i < 16; ++i) Td[i] = T[i];
-      if (prm->safeguard && r.status == DGR_STATUS_LOW_CONFIDENCE) {
-        // Case 1 (:302-315): RANSAC over the putative correspondences xyz0[i] <-> xyz1[idx1[i]]
-        const DgrArena::Mark mk = A.mark();
-        float *Y;
-        DGR_ALLOC(Y, A, float, m0 * 3);
-        gather_rows3_kernel<<<(int)dgr_ceil_div(m0, 256), 256, 0, stream>>>(xyz1, idx1 + off0[p], m0, Y);
-        DGR_CHECK(dgr_ransac_impl(ctx, xyz0 + off0[p] * 3, Y, m0, 2.0 * prm->voxel_size,
-                                  prm->ransac_hypotheses > 0 ? prm->ransac_hypotheses : 4000000, prm->ransac_seed, Td,
-                                  nullptr, stream));
-        A.rewind(mk);
-        status_out[p] = DGR_STATUS_SAFEGUARD;
-      }
-      if (prm->use_icp)   // :317-322: max correspondence distance 2 voxel, Open3D defaults (1e-6, 1e-6, 30)
-        DGR_CHECK(dgr_icp_impl(ctx, xyz0 + off0[p] * 3, m0, xyz1 + off1[p] * 3, m1, 2.0 * prm->voxel_size, Td, 30, 1e-6,
-                               1e-6, Td, nullptr, stream));
-      for (int i = 0; i < 16; ++i) T[i] = (float)Td[i];
-    }
     if (stats_out) {
       stats_out[p * 4 + 0] = (float)r.iterations;
       stats_out[p * 4 + 1] = r.loss;
@@ -302,9 +280,70 @@ extern "C" int dgr_register_batch(dgr_ctx *ctx, dgr_net *fcgf, dgr_net *inlier, 
   ctx->last.ptr[3] = F0;      ctx->last.numel[3] = n0 * C;
   ctx->last.ptr[4] = F1;      ctx->last.numel[4] = n1 * C;
   ctx->last.generation = ctx->arena.generation;
+  // The two Open3D steps that end register() (:302-322) for the whole batch, without leaving the library and with two
+  // stream synchronisations in total: every failing pair's RANSAC and every pair's ICP set-up are enqueued back to
+  // back; the ICP takes its initial T on the device (a RANSAC result record, or the uploaded estimate).  The batch
+  // outputs above are complete at this point: a pair whose ICP cannot run keeps its estimate and gets its own status.
+  DGR_CHECK(tm.rec(8, 0));
+  if (prm->safeguard || prm->use_icp) {
+    const DgrArena::Mark mk = A.mark();
+    std::vector<double *> rs(npairs, nullptr);
+    std::vector<double> Th((size_t)npairs * 16), rsh((size_t)npairs * DGR_RANSAC_RESULT_DOUBLES);
+    if (prm->safeguard)
+      for (int p = 0; p < npairs; ++p) {
+        if (res[p].status != DGR_STATUS_LOW_CONFIDENCE) continue;
+        // Case 1 (:302-315): RANSAC over the putative correspondences xyz0[i] <-> xyz1[idx1[i]]
+        const int64_t m0 = off0[p + 1] - off0[p];
+        float *Y;
+        DGR_ALLOC(Y, A, float, m0 * 3);
+        gather_rows3_kernel<<<(int)dgr_ceil_div(m0, 256), 256, 0, stream>>>(xyz1, idx1 + off0[p], m0, Y);
+        DGR_CHECK(dgr_ransac_begin(ctx, xyz0 + off0[p] * 3, Y, m0, 2.0 * prm->voxel_size,
+                                   prm->ransac_hypotheses > 0 ? prm->ransac_hypotheses : 4000000, prm->ransac_seed, &rs[p],
+                                   stream));
+        DGR_HIP_CHECK(hipMemcpyAsync(&rsh[(size_t)p * DGR_RANSAC_RESULT_DOUBLES], rs[p],
+                                     DGR_RANSAC_RESULT_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, stream));
+        status_out[p] = DGR_STATUS_SAFEGUARD;
+      }
+    std::vector<DgrIcpJob> jobs(prm->use_icp ? npairs : 0);
+    if (prm->use_icp) {   // :317-322: max correspondence distance 2 voxel, Open3D defaults (1e-6, 1e-6, 30)
+      double *Tinit;
+      DGR_ALLOC(Tinit, A, double, (int64_t)npairs * 16);
+      for (int i = 0; i < npairs * 16; ++i) Th[i] = T_out[i];
+      DGR_HIP_CHECK(hipMemcpyAsync(Tinit, Th.data(), Th.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+      for (int p = 0; p < npairs; ++p)
+        DGR_CHECK(dgr_icp_begin(ctx, xyz0 + off0[p] * 3, off0[p + 1] - off0[p], xyz1 + off1[p] * 3, off1[p + 1] - off1[p],
+                                2.0 * prm->voxel_size, rs[p] ? rs[p] : Tinit + (int64_t)p * 16, &jobs[p], stream));
+    }
+    DGR_HIP_CHECK(hipStreamSynchronize(stream));
+    for (int p = 0; p < npairs; ++p)
+      if (rs[p])
+        for (int i = 0; i < 16; ++i) T_out[p * 16 + i] = (float)rsh[(size_t)p * DGR_RANSAC_RESULT_DOUBLES + i];
+    if (prm->use_icp) {
+      std::vector<char> ran(npairs, 0);
+      for (int p = 0; p < npairs; ++p) {
+        if (jobs[p].ncell < 1 || jobs[p].ncell > (4 << 20)) {   // no finite target point: the estimate stands
+          status_out[p] = DGR_STATUS_ICP_SKIPPED;
+          continue;
+        }
+        DGR_CHECK(dgr_icp_run(ctx, &jobs[p], 30, 1e-6, 1e-6, stream));
+        ran[p] = 1;
+      }
+      DGR_HIP_CHECK(hipStreamSynchronize(stream));
+      for (int p = 0; p < npairs; ++p) {
+        if (!ran[p]) continue;
+        double Td[16];
+        dgr_icp_finish(&jobs[p], Td, nullptr);
+        for (int i = 0; i < 16; ++i) T_out[p * 16 + i] = (float)Td[i];
+      }
+    }
+    A.rewind(mk);   // the stream was synchronised above
+  }
+  DGR_CHECK(tm.rec(8, 1));
   if (ctx->profiling) {
     memset(ctx->stage_ms, 0, sizeof(ctx->stage_ms));
     for (int s = 0; s < 5; ++s) DGR_HIP_CHECK(hipEventElapsedTime(&ctx->stage_ms[s], tm.e[s][0], tm.e[s][1]));
+    DGR_HIP_CHECK(hipStreamSynchronize(stream));
+    DGR_HIP_CHECK(hipEventElapsedTime(&ctx->stage_ms[8], tm.e[8][0], tm.e[8][1]));
     DGR_CHECK(dgr_ctx_collect_profile(ctx));
   }
   return DGR_OK;

@@ -116,6 +116,23 @@ class NetHandle:
                                            C.byref(rows), C.byref(cols)))
         return buf
 
+    def debug_conv_layer(self, layer, coords, feats, relu=False):
+        """Conv layer `layer` (forward order) applied to `feats` [N, Cin] over the 3^D same-stride map of `coords`,
+        through the kernels the forward uses for it (dgr_debug_conv_layer; test instrument)."""
+        dev = self.device
+        coords = _as(coords, torch.int32, dev)
+        feats = _as(feats, torch.float32, dev)
+        lay = _lib.load()
+        st_cout = None
+        # the layer's output width: the channel tables of ResUNetBN2C (model/resunet.py:664-665)
+        ch, tr = [None, 32, 64, 128, 256], [None, 64, 64, 64, 128]
+        widths = [ch[1]] * 3 + [ch[2]] * 3 + [ch[3]] * 3 + [ch[4]] * 3 + [tr[4]] * 3 + [tr[3]] * 3 + [tr[2]] * 3 + [tr[1], self.cout]
+        st_cout = widths[layer]
+        out = torch.empty((coords.shape[0], st_cout), dtype=torch.float32, device=dev)
+        check(lay.dgr_debug_conv_layer(get_ctx(dev), self.handle, int(layer), ptr(coords), ptr(feats), int(bool(relu)),
+                                       coords.shape[0], ptr(out), stream_ptr(dev.index)))
+        return out
+
     def rerun_layer(self, layer, reps=5):
         """(gemm_ms, reduce_ms) of conv layer `layer` of the last forward (kernel-tuning instrument)."""
         lib = _lib.load()
@@ -381,9 +398,9 @@ def set_profiling(device, enable):
 
 
 def stage_times(device):
-    t = (C.c_float * 8)()
+    t = (C.c_float * 9)()
     check(_lib.load().dgr_ctx_stage_times(get_ctx(device), t))
-    names = ['fcgf', 'knn', 'inlier_inputs', 'inlier_net', 'registration', 'maps_3d', 'maps_6d', 'conv_kernels']
+    names = ['fcgf', 'knn', 'inlier_inputs', 'inlier_net', 'registration', 'maps_3d', 'maps_6d', 'conv_kernels', 'o3d_steps']
     out = dict(zip(names, [float(v) for v in t]))
     out['conv_launches'] = int(_lib.load().dgr_ctx_conv_launches(get_ctx(device)))
     return out

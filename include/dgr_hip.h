@@ -46,7 +46,9 @@ enum {
 
 /* per-pair status of the confidence gate, core/deep_global_registration.py:276-281 */
 enum { DGR_STATUS_OK = 0, DGR_STATUS_LOW_CONFIDENCE = 1, DGR_STATUS_SVD_FAILED = 2,
-       DGR_STATUS_SAFEGUARD = 3 /* gate failed, T from the safeguard RANSAC (dgr_params.safeguard) */ };
+       DGR_STATUS_SAFEGUARD = 3 /* gate failed, T from the safeguard RANSAC (dgr_params.safeguard) */,
+       DGR_STATUS_ICP_SKIPPED = 4 /* dgr_params.use_icp: the final ICP could not run on this pair (no finite target point);
+                                     T is the estimate before ICP */ };
 
 const char *dgr_last_error(void);
 const char *dgr_version(void);
@@ -225,9 +227,9 @@ int dgr_register_batch_output(dgr_ctx *ctx, int which, void *dst_dev, int64_t ca
 
 /* per-stage device time (ms, HIP events) of the last dgr_register_batch when profiling was
  * enabled with dgr_ctx_set_profiling(ctx, 1): [fcgf, knn, inlier_inputs, inlier_net, registration,
- * maps_3d, maps_6d, conv_kernels_total].  Synchronises. */
+ * maps_3d, maps_6d, conv_kernels_total, safeguard RANSAC + ICP steps (dgr_params.safeguard / use_icp)].  Synchronises. */
 int dgr_ctx_set_profiling(dgr_ctx *ctx, int enable);
-int dgr_ctx_stage_times(dgr_ctx *ctx, float times_ms[8]);
+int dgr_ctx_stage_times(dgr_ctx *ctx, float times_ms[9]);
 /* number of sparse-conv kernel launches covered by times_ms[7] */
 int64_t dgr_ctx_conv_launches(dgr_ctx *ctx);
 /* duration (ms) of every sparse-conv layer launch of the last profiled batch, in launch order (FCGF layers
@@ -248,6 +250,13 @@ int dgr_debug_ortho2rotation(dgr_ctx *ctx, const float *p6, int64_t n, const flo
 /* HighDimSmoothL1Loss (core/loss.py:51-61) per point of X, Y [n,3] (device) with quantization_size q -> per_point_out [n] */
 int dgr_debug_smooth_l1(dgr_ctx *ctx, const float *X, const float *Y, int64_t n, float quantization_size,
                         float *per_point_out, dgr_stream stream);
+
+/* One conv layer (index in forward order, 0..22; layers with a 3^D kernel and >= 32 input channels) of `net` applied to
+ * a caller-supplied feature matrix `in` [N, Cin] (device; max(x, 0) applied first when in_relu) over the same-stride
+ * 3^D kernel map of `coords` [N, 1+D]: out [N, Cout] (device) = folded batch-norm shift + sum over the map, through the
+ * very kernels the forward runs for that layer (model/residual_block.py:118-134; MinkowskiConvolution.forward). */
+int dgr_debug_conv_layer(dgr_ctx *ctx, dgr_net *net, int layer, const int32_t *coords, const float *in, int in_relu,
+                         int64_t N, float *out, dgr_stream stream);
 
 #ifdef __cplusplus
 }

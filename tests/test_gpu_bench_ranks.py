@@ -1,0 +1,42 @@
+"""`bench.py --gpus 2` end to end on ONE GPU: both ranks on device 0 (DGR_BENCH_ONE_GPU=1), the tiny collectives over
+gloo (DGR_BENCH_BACKEND=gloo; a 1-GPU box cannot run RCCL between two ranks) -- the launcher, the weight broadcast,
+the cost-balanced dealing, the per-rank registration and the result gather, with real GPU work.  Every pair must be
+covered exactly once and every pair's result must equal the 1-rank run bit for bit (pairs are independent units:
+SURVEY.md 8e, core/deep_global_registration.py:238-324 has no cross-pair state)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COMMON = ['--steps', '2', '--warmup', '1', '--total-pairs', '6', '--pairs-per-step', '2', '--streams', '1', '--n-raw', '12000',
+          '--conv1-ks', '5', '--no-parity']
+
+
+def _bench(tmp, gpus):
+    env = dict(os.environ, DGR_BENCH_BACKEND='gloo', DGR_BENCH_ONE_GPU='1')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    out = os.path.join(tmp, f'res{gpus}.npz')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(gpus), '--dump-results', out, *COMMON],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    return line, np.load(out)
+
+
+def test_two_ranks_cover_every_pair_once_and_match_one_rank(tmp_path):
+    one, r1 = _bench(str(tmp_path), 1)
+    two, r2 = _bench(str(tmp_path), 2)
+    assert one['n_gpus'] == 1 and two['n_gpus'] == 2 and two['scaling'] == 'strong'
+    assert two['config']['pairs_per_step'] == 6 and two['value'] > 0
+    assert sorted(r1['ids'].tolist()) == list(range(6)) and sorted(r2['ids'].tolist()) == list(range(6))
+    o1, o2 = np.argsort(r1['ids']), np.argsort(r2['ids'])
+    np.testing.assert_array_equal(r1['T'][o1], r2['T'][o2])
+    np.testing.assert_array_equal(r1['status'][o1], r2['status'][o2])
+    np.testing.assert_array_equal(r1['stats'][o1], r2['stats'][o2])
+    assert two['host_cpu_s_per_step_per_rank'] > 0
