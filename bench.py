@@ -622,7 +622,7 @@ def main():
             pair0 = {'xyz0': lb['X0'][s0:e0].cpu().numpy(), 'coords0': c0, 'xyz1': lb['X1'][s1:e1].cpu().numpy(), 'coords1': c1,
                      'idx1': hip_out['idx1'][s0:e0] - s1, 'F0': hip_out['F0'].reshape(-1, 32)[s0:e0],
                      'F1': hip_out['F1'].reshape(-1, 32)[s1:e1], 'logit': hip_out['logit'][s0:e0],
-                     'forced': lb['forced'].cpu().numpy()[s0:e0]}
+                     'forced': lb['forced'].cpu().numpy()[s0:e0], 'device': device}
             out['parity'], out['cpu_baseline'] = oracle_parity_and_baseline(ck, args, pair0, not args.no_cpu_baseline)
             log(f'parity: {out["parity"]}')
         print(json.dumps(out))
