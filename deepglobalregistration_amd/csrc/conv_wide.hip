@@ -392,7 +392,9 @@ __global__ void __launch_bounds__(512, 1) sparse_conv_wide_f16x2(ConvWideArgs a,
           // next k-step's operands; the next phase's buffer has been complete since the last barrier
           if (s + 1 < SK) oload(buf, s + 1, op[(s + 1) & 1]);
           else oload(nbuf, 0, op[0]);
-          __builtin_amdgcn_sched_barrier(0);   // pin the prefetches ahead of the MFMA block
+          // pin the prefetches ahead of the MFMA block (left to the compiler, or interleaved one per MFMA gap with
+          // sched_group_barrier, the loads are waited for early: 2.36 / 2.19 ms against 1.95 ms, tools/microbench/wide_check)
+          __builtin_amdgcn_sched_barrier(0);
           uint4 (*wc)[NP] = w[s % WD];
           uint4 (*oc)[NP] = op[s & 1];
 #ifdef DGR_WIDE_ABL_NOMFMA
