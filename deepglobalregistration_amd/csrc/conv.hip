@@ -957,8 +957,7 @@ int dgr_conv1_probe(DgrArena &arena, const DgrCoordMap &cm, int ks, const float 
   DGR_REQUIRE(cin >= 1 && cin <= 8 && ks % 2 == 1, "conv1 probe: cin=%d ks=%d", cin, ks);
   if (pair_count) DGR_HIP_CHECK(hipMemsetAsync(pair_count, 0, sizeof(int32_t), stream));
   const int32_t *grid_done = nullptr;
-  static const bool no_grid = getenv("DGR_CONV1_HASH") != nullptr;
-  if (ks <= 7 && !no_grid) {
+  if (ks <= 7) {
     // dense grid: up to 64 M cells (256 MB) of transient arena memory
     static const long long cap = 64ll << 20;
     DgrArena::Mark mk = arena.mark();
@@ -980,8 +979,7 @@ int dgr_conv1_probe(DgrArena &arena, const DgrCoordMap &cm, int ks, const float 
       DGR_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
       resident = (per_cu < 1 ? 1 : per_cu) * (cus < 1 ? 1 : cus);
     }
-    static const bool scalar_conv1 = getenv("DGR_CONV1_SCALAR") != nullptr;   // A/B switch
-    if (cin == 1 && w_compact && (out_ld & 3) == 0 && (ks == 3 || ks == 5 || ks == 7) && !scalar_conv1) {
+    if (cin == 1 && w_compact && (out_ld & 3) == 0 && (ks == 3 || ks == 5 || ks == 7)) {
       const int wgs = (int)dgr_ceil_div(cm.n_cap, 64);
       if (ks == 7) conv1_grid_mfma<7><<<wgs, 256, 0, stream>>>(cm.coords, cm.n_dev, meta, cells, in, in_ld, w_compact, shift, out, out_ld, pair_count);
       else if (ks == 5) conv1_grid_mfma<5><<<wgs, 256, 0, stream>>>(cm.coords, cm.n_dev, meta, cells, in, in_ld, w_compact, shift, out, out_ld, pair_count);

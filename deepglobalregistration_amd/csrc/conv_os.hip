@@ -20,8 +20,8 @@
 //     barrier, and the sum order is ascending k: results do not depend on scheduling (bit-reproducible).
 //
 // Arithmetic (PM): 2 = every f32 operand as two f16 pieces under exact power-of-two row / layer scales, three
-// v_mfma_f32_16x16x32_f16 per 32 input channels (default; error analysis in conv_bf3.hip); 3 = three exact
-// bf16 pieces, six products (DGR_CONV_BF3=1); 0 = v_mfma_f32_16x16x4_f32 on the f32 operands (DGR_EXACT_F32=1).
+// v_mfma_f32_16x16x32_f16 per 32 input channels (default; error analysis in conv_wide.hip, measured against f64 in
+// tests/test_gpu_split_f64.py); 0 = v_mfma_f32_16x16x4_f32 on the f32 operands (DGR_EXACT_F32=1).
 //
 // Weight layouts (net.hip, per layer): split pieces WB[piece][k][s][jb][lane] = 8 halves =
 // W_folded[k][32 s + 8 (lane >> 4) + e][16 jb + (lane & 15)]; f32: W16[k][g][jb][lane][c] =
@@ -43,7 +43,7 @@ struct ConvOsArgs {
   const float *in;
   float *out;
   const float *w16, *shift, *res;
-  const uint4 *wb3;        // BF3: three exact bf16 pieces, each [27][CP/32][cout/16][64] x 16 bytes
+  const uint4 *wb3;        // split weights: two f16 pieces, each [27][CP/32][cout/16][64] x 16 bytes
   int64_t piece_stride;    // 16-byte units per piece
   const int32_t *nbr, *n_out_dev;
   int64_t n_pad;
@@ -55,18 +55,16 @@ struct ConvOsArgs {
 
 // CP = input channels (multiple of 32), CS = output-channel slice of a workgroup (32 | 64), MB = output rows
 // per workgroup (16 | 32 | 64), CK = input channels per pipeline phase (32 | 64), TM = pair slots per tile (32 | 64)
-// BF3: the products run on the bf16 matrix pipe with every f32 operand split exactly into three bf16 pieces (six
-// v_mfma_f32_16x16x32_bf16 per 32 input channels instead of eight v_mfma_f32_16x16x4_f32: 2.67x fewer matrix
-// cycles, f32-level error -- see conv_bf3.hip); false = exact-f32 MFMA (DGR_EXACT_F32=1, A/B measurements)
-// PM = pieces per operand: 0 = exact-f32 MFMA, 3 = bf16 x 3 (six products), 2 = f16 x 2 with exact power-of-two
-// row / layer scales (three v_mfma_f32_16x16x32_f16 per 32 input channels; conv_bf3.hip has the error analysis)
+// PM = pieces per operand: 0 = exact-f32 MFMA, 2 = f16 x 2 with exact power-of-two row / layer scales (three
+// v_mfma_f32_16x16x32_f16 per 32 input channels)
 // GW = groups of a tile per wave: GW = TM / 16 -> CS / 16 waves, each walks all groups of the tile (the coarse levels,
 // where an offset rarely fills more than one group); GW = 1 -> (TM / 16) x (CS / 16) waves, one group each: twice
 // the waves on the same LDS for the two finest levels, whose phases are chains of dependent LDS round trips
 template <int CP, int CS, int MB, int CK, int TM, int PM, int GW>
 __global__ void __launch_bounds__(CS * 4 * (TM / 16 / GW)) sparse_conv_os(ConvOsArgs a) {
   constexpr bool BF3 = PM != 0;
-  constexpr int NP = PM == 0 ? 1 : PM;
+  static_assert(PM == 0 || PM == 2, "arithmetic mode");
+  constexpr int NP = PM == 0 ? 1 : 2;
   constexpr int GP = TM / 16;            // 16-row groups per tile
   constexpr int NCW = CS / 16;           // 16-channel blocks of the slice
   constexpr int NWR = GP / GW;           // wave rows: each owns GW consecutive groups of every tile
@@ -114,6 +112,9 @@ __global__ void __launch_bounds__(CS * 4 * (TM / 16 / GW)) sparse_conv_os(ConvOs
   const int slice = blockIdx.y;
   const int64_t row0 = (int64_t)blk * MB;
 
+  if constexpr (PM == 2)
+    for (int e = tid; e < KV * MB; e += THREADS) (&in_scale[0][0])[e] = 1.f;   // slots past a list's end: a finite scale
+  __syncthreads();
   // ---- 1. per offset: compact the block's neighbour-table column into (input row, local output row)
   {
     int v[KPW];
@@ -206,11 +207,12 @@ __global__ void __launch_bounds__(CS * 4 * (TM / 16 / GW)) sparse_conv_os(ConvOs
       v.x = max(v.x, relu_lo); v.y = max(v.y, relu_lo); v.z = max(v.z, relu_lo); v.w = max(v.w, relu_lo);
       if constexpr (!BF3) {
         *reinterpret_cast<i32x4 *>(&As[q & 1][0][0] + (ch / C4K) * LDA + (ch % C4K) * 4) = v;
-      } else if constexpr (PM == 2) {
+      } else {
         // s x = h + m (+ <= 2^-22): two f16 planes; slots past their group's entries carry row 0 under a
-        // finite foreign scale and are never accumulated
+        // finite foreign scale (in_scale is initialised to 1) and are never accumulated; the landing past the last
+        // phase (into the buffer nobody reads) looks the last tile's groups up again
         const int r = ch / C4K;
-        const int info = grp[GP * (q / PPT) + (r >> 4)];
+        const int info = grp[GP * (min(q, NQ - 1) / PPT) + (r >> 4)];
         const float sx = in_scale[info & 255][min(((info >> 8) & 255) + (r & 15), MB - 1)];
         _Float16 hh[4], mm[4];
 #pragma unroll
@@ -225,22 +227,6 @@ __global__ void __launch_bounds__(CS * 4 * (TM / 16 / GW)) sparse_conv_os(ConvOs
                                                 __builtin_bit_cast(uint32_t, f16x2{hh[2], hh[3]})};
         *reinterpret_cast<u32x2 *>(dst + PLANE) = u32x2{__builtin_bit_cast(uint32_t, f16x2{mm[0], mm[1]}),
                                                         __builtin_bit_cast(uint32_t, f16x2{mm[2], mm[3]})};
-      } else {
-        // x = h + m + l exactly (8 + 8 + 8 significant bits by truncation), three bf16 planes
-        uint32_t h[4], m[4], l[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int vi = v[u];   // (bit_cast straight from a vector ELEMENT reads element 0)
-          const float x = __builtin_bit_cast(float, vi);
-          h[u] = (uint32_t)vi & 0xffff0000u;
-          const float r1 = x - __builtin_bit_cast(float, h[u]);
-          m[u] = __builtin_bit_cast(uint32_t, r1) & 0xffff0000u;
-          l[u] = __builtin_bit_cast(uint32_t, r1 - __builtin_bit_cast(float, m[u]));
-        }
-        unsigned short *dst = Ps + (q & 1) * 3 * PLANE + (ch / C4K) * LDP + (ch % C4K) * 4;
-        *reinterpret_cast<u32x2 *>(dst) = u32x2{(h[0] >> 16) | h[1], (h[2] >> 16) | h[3]};
-        *reinterpret_cast<u32x2 *>(dst + PLANE) = u32x2{(m[0] >> 16) | m[1], (m[2] >> 16) | m[3]};
-        *reinterpret_cast<u32x2 *>(dst + 2 * PLANE) = u32x2{(l[0] >> 16) | (l[1] & 0xffff0000u), (l[2] >> 16) | (l[3] & 0xffff0000u)};
       }
     }
   };
@@ -286,7 +272,7 @@ __global__ void __launch_bounds__(CS * 4 * (TM / 16 / GW)) sparse_conv_os(ConvOs
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c], av[c], acc[u], 0, 0, 0);
       }
-    } else if constexpr (PM == 2) {
+    } else {
       const unsigned short *prow = Ps + buf * NP * PLANE + (rb * 16 + (lane & 15)) * LDP + 8 * (lane >> 4);
 #pragma unroll
       for (int g = 0; g < G32; ++g) {
@@ -296,23 +282,6 @@ __global__ void __launch_bounds__(CS * 4 * (TM / 16 / GW)) sparse_conv_os(ConvOs
         acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm, ah, acc[u], 0, 0, 0);
         acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, am, acc[u], 0, 0, 0);
         acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, ah, acc[u], 0, 0, 0);
-      }
-    } else {
-      const unsigned short *prow = Ps + buf * 3 * PLANE + (rb * 16 + (lane & 15)) * LDP + 8 * (lane >> 4);
-#pragma unroll
-      for (int g = 0; g < G32; ++g) {
-        const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(prow + 32 * g));
-        const bf16x8 am = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(prow + PLANE + 32 * g));
-        const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(prow + 2 * PLANE + 32 * g));
-        const bf16x8 wh = __builtin_bit_cast(bf16x8, w[u].v[3 * g]), wm = __builtin_bit_cast(bf16x8, w[u].v[3 * g + 1]),
-                     wl = __builtin_bit_cast(bf16x8, w[u].v[3 * g + 2]);
-        // six products, small terms first
-        acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah, acc[u], 0, 0, 0);
-        acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, al, acc[u], 0, 0, 0);
-        acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, am, acc[u], 0, 0, 0);
-        acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, ah, acc[u], 0, 0, 0);
-        acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, am, acc[u], 0, 0, 0);
-        acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah, acc[u], 0, 0, 0);
       }
     }
   };
@@ -394,8 +363,6 @@ static int launch_os(const ConvOsArgs &ka, int64_t n_out_cap, hipStream_t stream
   constexpr int threads = CS * 4 * (TM / 16 / GW);
   if (ka.wb3 && ka.row_scale)
     sparse_conv_os<CP, CS, MB, CK, TM, 2, GW><<<grid, threads, 0, stream>>>(ka);
-  else if (ka.wb3)
-    sparse_conv_os<CP, CS, MB, CK, TM, 3, GW><<<grid, threads, 0, stream>>>(ka);
   else
     sparse_conv_os<CP, CS, MB, CK, TM, 0, GW><<<grid, threads, 0, stream>>>(ka);
   DGR_LAUNCH_CHECK();
@@ -408,15 +375,16 @@ int dgr_conv_os_launch(const DgrConvOsLaunch &a, hipStream_t stream, const char 
               "output-stationary conv: channel counts and row strides must be multiples of 4");
   DGR_REQUIRE(a.cout % 32 == 0 && a.cin == a.cin_pad, "output-stationary conv: Cin = %d, Cout = %d must be multiples of 32",
               a.cin, a.cout);
-  DGR_REQUIRE(a.n_out_cap * (int64_t)a.in_ld < (1ll << 32) / 4 * 4, "output-stationary conv: input tensor beyond 32-bit element offsets");
+  DGR_REQUIRE(a.n_in_cap > 0 && a.n_in_cap * (int64_t)a.in_ld < (1ll << 32) / 4 * 4,
+              "output-stationary conv: input tensor beyond 32-bit element offsets");
   ConvOsArgs ka;
   static const bool os_f32 = getenv("DGR_EXACT_F32") != nullptr;
   ka.in = a.in; ka.out = a.out; ka.w16 = a.w16; ka.shift = a.shift; ka.res = a.res;
   ka.wb3 = os_f32 ? nullptr : static_cast<const uint4 *>(a.wb3);
   ka.piece_stride = a.piece_stride;
-  ka.row_scale = (ka.wb3 && a.pieces == 2) ? a.row_scale : nullptr;
+  ka.row_scale = ka.wb3 ? a.row_scale : nullptr;
   ka.w_unscale = a.w_unscale;
-  DGR_REQUIRE(!ka.wb3 || a.pieces == 3 || ka.row_scale, "output-stationary conv: 2-piece weights need the input's row scales");
+  DGR_REQUIRE(!ka.wb3 || ka.row_scale, "output-stationary conv: the split weights need the input's row scales");
   ka.nbr = a.nbr->nbr; ka.n_out_dev = a.n_out_dev; ka.n_pad = a.nbr->n_pad;
   ka.in_ld = a.in_ld; ka.in_relu = a.in_relu; ka.out_ld = a.out_ld; ka.out_relu = a.out_relu;
   ka.res_ld = a.res_ld; ka.res_relu = a.res_relu;
@@ -433,8 +401,7 @@ int dgr_conv_os_launch(const DgrConvOsLaunch &a, hipStream_t stream, const char 
   do {                                                                                                  \
     constexpr int tm = (MBV) < DGR_OS_TM ? ((MBV) < 32 ? 32 : (MBV)) : DGR_OS_TM;                       \
     if (kernel_name) *kernel_name = ka.row_scale ? "sparse_conv_os<" #CPV ", " #CSV ", " DGR_STR(MBV) ", " DGR_STR(CKV) ", f16x2>"  \
-                                    : ka.wb3 ? "sparse_conv_os<" #CPV ", " #CSV ", " DGR_STR(MBV) ", " DGR_STR(CKV) ", bf16x3>"  \
-                                           : "sparse_conv_os<" #CPV ", " #CSV ", " DGR_STR(MBV) ", " DGR_STR(CKV) ", f32>"; \
+                                                 : "sparse_conv_os<" #CPV ", " #CSV ", " DGR_STR(MBV) ", " DGR_STR(CKV) ", f32>"; \
     return launch_os<CPV, CSV, MBV, CKV, tm>(ka, a.n_out_cap, stream);                                  \
   } while (0)
   // rows per workgroup by level: the coarse levels have few rows (1/3, 1/12, 1/60 of the input on

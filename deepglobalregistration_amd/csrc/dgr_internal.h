@@ -219,9 +219,9 @@ struct DgrConvOsLaunch {
   const float *in; int in_ld, in_relu;
   float *out; int out_ld, out_relu;
   const float *w16, *shift;
-  const void *wb3; int64_t piece_stride;   // split weights (16-byte units per piece), or null
-  int pieces = 3;                          // 3 = bf16 x 3; 2 = f16 x 2 (needs row_scale, w_unscale)
-  const float *row_scale = nullptr; float w_unscale = 1.f;
+  const void *wb3; int64_t piece_stride;   // split weights: two f16 pieces (16-byte units per piece), or null
+  const float *row_scale = nullptr; float w_unscale = 1.f;   // ... with the input's row scales and the layer's inverse weight scale
+  int64_t n_in_cap = 0;                    // row capacity of the input tensor (32-bit gather offsets)
   const float *res; int res_ld, res_relu;
   int rows_per_block;   // 64 | 32 | 16 output rows per workgroup
   const DgrNbrTable *nbr;

@@ -430,23 +430,17 @@ static int build_kernel_map_t(DgrArena &arena, const DgrCoordMap &in, const DgrC
   DGR_ALLOC(counts, arena, int32_t, (int64_t)K * RB);
   DGR_ALLOC(base, arena, int32_t, (int64_t)K * RB);
   DGR_ALLOC(total, arena, int32_t, 1);
+  // the two bit matrices (out rows; in rows for maps used swapped) come out of ONE allocation: one clear
   uint32_t *mask_out, *mask_in = nullptr;
   int32_t *cnt_out, *cnt_in = nullptr;
-  DGR_ALLOC(mask_out, arena, uint32_t, (n_cap + 1) * KW);
-  if (need_in_csr) DGR_ALLOC(mask_in, arena, uint32_t, (n_in_cap + 1) * KW);
+  {
+    const size_t w_out = (size_t)(n_cap + 1) * KW, w_in = need_in_csr ? (size_t)(n_in_cap + 1) * KW : 0;
+    DGR_ALLOC(mask_out, arena, uint32_t, w_out + w_in);
+    if (need_in_csr) mask_in = mask_out + w_out;
+    DGR_HIP_CHECK(hipMemsetAsync(mask_out, 0, (w_out + w_in) * sizeof(uint32_t), stream));
+  }
   DGR_ALLOC(cnt_out, arena, int32_t, n_cap + 1);
   if (need_in_csr) DGR_ALLOC(cnt_in, arena, int32_t, n_in_cap + 1);
-  {
-    // the two bit matrices sit back to back in the arena (unless a chunk boundary fell between them): one clear
-    const size_t b_out = (size_t)(n_cap + 1) * KW * sizeof(uint32_t), b_in = (size_t)(n_in_cap + 1) * KW * sizeof(uint32_t);
-    char *lo = reinterpret_cast<char *>(mask_out), *hi = reinterpret_cast<char *>(mask_in);
-    if (need_in_csr && hi > lo && (size_t)(hi - lo) < b_out + 4096) {
-      DGR_HIP_CHECK(hipMemsetAsync(mask_out, 0, (size_t)(hi - lo) + b_in, stream));
-    } else {
-      DGR_HIP_CHECK(hipMemsetAsync(mask_out, 0, b_out, stream));
-      if (need_in_csr) DGR_HIP_CHECK(hipMemsetAsync(mask_in, 0, b_in, stream));
-    }
-  }
   int32_t *hits = nullptr;
   int4 *cell = nullptr;
   int64_t n_cells = 0;

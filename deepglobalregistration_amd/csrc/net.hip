@@ -367,7 +367,7 @@ struct Fwd {
       o.rows_per_block = lvl_out <= 1 ? 64 : lvl_out == 2 ? 32 : 16;
       o.w16 = L.w16; o.shift = L.shift;
       o.wb3 = L.w16b; o.piece_stride = L.w16b_piece;
-      o.pieces = 2; o.w_unscale = L.w_unscale;
+      o.w_unscale = L.w_unscale; o.n_in_cap = cin_map.n_cap;
       static const bool os_f32 = getenv("DGR_EXACT_F32") != nullptr;   // (conv_os.hip reads the same switch)
       if (L.w16b && !os_f32) {
         float *rs;
@@ -451,13 +451,11 @@ int dgr_resunet_forward_impl(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, 
     DGR_HIP_CHECK(hipEventRecord(m0, stream));
   }
   f.ms.overflow = ctx->flag_dev;
-  // FCGF conv1 (ks^3 offsets, <= 8 input channels) is fused with its neighbour search: no map for it
-  // (any odd kernel size <= 7, also 3); such a 3-D net then needs no rule-major map at all: the K = 27 layers
-  // run output-stationary over dense neighbour tables.  DGR_CONV3D_RULEMAJOR=1 keeps the rule-major two-phase
-  // path of conv.hip for A/B measurements.
-  static const bool rule_major_3d = getenv("DGR_CONV3D_RULEMAJOR") != nullptr;
-  const bool use_nbr = net->D == 3 && net->cin <= 8 && net->conv1_ks <= 7 && !rule_major_3d;
-  const bool conv1_fused = net->D == 3 && net->cin <= 8 && net->conv1_ks <= 7 && (net->conv1_ks != 3 || use_nbr);
+  // FCGF conv1 (ks^3 offsets, <= 8 input channels) is fused with its neighbour search: no map for it (any odd kernel
+  // size <= 7, also 3); such a 3-D net needs no rule-major map at all: the K = 27 layers run output-stationary over
+  // dense neighbour tables (conv_os.hip).  Any other 3-D shape takes the rule-major two-phase path of conv.hip.
+  const bool use_nbr = net->D == 3 && net->cin <= 8 && net->conv1_ks <= 7;
+  const bool conv1_fused = use_nbr;
   DGR_CHECK(dgr_build_maps(A, coords, N, net->D, net->conv1_ks, &f.ms, stream, conv1_fused, /*lean=*/true, use_nbr));
   if (f.prof) {
     DGR_HIP_CHECK(hipEventRecord(m1, stream));

@@ -163,6 +163,18 @@ __device__ __forceinline__ void ortho_backward(const Ortho &o, const float G[9],
   for (int i = 0; i < 3; ++i) gp[3 + i] = gb[i];
 }
 
+// `(X - Y) / quantization_size` (core/loss.py:54): ONE definition for the registration kernel and the debug entry point
+// that the golden-vector test of the loss calls.  The reference's CPU path divides (the default here: it is what the
+// oracle and the golden vectors do); on its CUDA device ATen multiplies by the f32 reciprocal -- compile with
+// -DDGR_REG_RECIP_MUL for that variant (a build-time choice, not a runtime switch).
+__device__ __forceinline__ float dgr_residual_scaled(float d, float q) {
+#ifdef DGR_REG_RECIP_MUL
+  return d * (1.f / q);
+#else
+  return d / q;
+#endif
+}
+
 // HighDimSmoothL1Loss per point (core/loss.py:51-61) of s = sum(((X - Y) / q)^2): value and d/ds;
 // discontinuous at s == 1 (0.5 vs 0.25) like the reference
 __device__ __forceinline__ void dgr_smooth_l1(float s, float eps, float &per, float &dps) {
@@ -332,11 +344,8 @@ __global__ void __launch_bounds__(REG_THREADS) registration_kernel(RegArgs a) {
       // differ by one ulp in s for q = 0.05, which moves points across the s = 1 discontinuity of the loss; after
       // 334 Adam iterations on a 113 k-point pair the result was 1.0e-3 away from the CPU reference with the
       // reciprocal and 3.4e-5 with the division (tests/test_gpu_configs.py, iteration-matched).
-#ifdef DGR_REG_RECIP_MUL
-      const float rx = (px - B.x) * inv_q, ry = (py - B.y) * inv_q, rz = (pz - B.z) * inv_q;
-#else
-      const float rx = (px - B.x) / q, ry = (py - B.y) / q, rz = (pz - B.z) / q;
-#endif
+      const float rx = dgr_residual_scaled(px - B.x, q), ry = dgr_residual_scaled(py - B.y, q),
+                  rz = dgr_residual_scaled(pz - B.z, q);
       const float s = rx * rx + ry * ry + rz * rz;
       float per, dps;
       dgr_smooth_l1(s, a.eps, per, dps);
@@ -538,12 +547,12 @@ __global__ void debug_ortho_kernel(const float *__restrict__ P, int64_t n, const
   }
 }
 
-__global__ void debug_loss_kernel(const float *__restrict__ X, const float *__restrict__ Y, int64_t n, float inv_q,
+__global__ void debug_loss_kernel(const float *__restrict__ X, const float *__restrict__ Y, int64_t n, float q,
                                   float eps, float *__restrict__ per_point) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const float rx = (X[i * 3] - Y[i * 3]) * inv_q, ry = (X[i * 3 + 1] - Y[i * 3 + 1]) * inv_q,
-              rz = (X[i * 3 + 2] - Y[i * 3 + 2]) * inv_q;
+  const float rx = dgr_residual_scaled(X[i * 3] - Y[i * 3], q), ry = dgr_residual_scaled(X[i * 3 + 1] - Y[i * 3 + 1], q),
+              rz = dgr_residual_scaled(X[i * 3 + 2] - Y[i * 3 + 2], q);
   float per, dps;
   dgr_smooth_l1(rx * rx + ry * ry + rz * rz, eps, per, dps);
   per_point[i] = per;
@@ -562,7 +571,7 @@ extern "C" int dgr_debug_smooth_l1(dgr_ctx *ctx, const float *X, const float *Y,
                                    float *per_point_out, dgr_stream stream) {
   DGR_REQUIRE(ctx && X && Y && per_point_out && n > 0 && quantization_size > 0, "dgr_debug_smooth_l1: bad argument");
   DGR_HIP_CHECK(hipSetDevice(ctx->device));
-  debug_loss_kernel<<<(int)dgr_ceil_div(n, 64), 64, 0, (hipStream_t)stream>>>(X, Y, n, 1.f / quantization_size,
+  debug_loss_kernel<<<(int)dgr_ceil_div(n, 64), 64, 0, (hipStream_t)stream>>>(X, Y, n, quantization_size,
                                                                               1.1920928955078125e-07f, per_point_out);
   DGR_LAUNCH_CHECK();
   return DGR_OK;

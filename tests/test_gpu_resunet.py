@@ -45,6 +45,23 @@ def test_fcgf_forward_general_input_features():
     _check(3, 3, 16, 3, False, coords, feats, seed=5)
 
 
+def test_3d_net_on_the_rule_major_path():
+    """A 3-D net with more than 8 input channels does not take the fused conv1 / output-stationary route: all its
+    layers run the rule-major two-phase kernels over kmap_search<3> / kmap_fill maps (conv.hip, kmap.hip)."""
+    from deepglobalregistration_amd import ops
+    rng = np.random.default_rng(43)
+    coords = np.concatenate([random_cloud_coords(rng, 2000, 16, 3, batch=b) for b in (0, 1)])
+    feats = rng.standard_normal((len(coords), 12)).astype(np.float32)
+    _check(3, 12, 16, 3, False, coords, feats, seed=6)
+    ops.set_profiling('cuda', True)
+    from deepglobalregistration_amd import synth
+    net = ops.NetHandle(synth.synth_state_dict(3, 12, 16, 3, 6), 3, 12, 16, 3, False)
+    net.forward(torch.from_numpy(coords).cuda(), torch.from_numpy(feats).cuda())
+    kinds = ops.conv_launch_kinds('cuda')
+    ops.set_profiling('cuda', False)
+    assert not any('sparse_conv_os' in k or 'conv1_grid' in k for k in kinds) and any('sparse_conv_mfma_v2' in k for k in kinds)
+
+
 def test_inlier_net_6d_forward_matches_oracle():
     rng = np.random.default_rng(7)
     # 6-D rows built like the pipeline does: unique 3-D voxel + a second 3-D voxel
