@@ -228,8 +228,11 @@ struct DgrConvOsLaunch {
   const int32_t *n_out_dev;
   int64_t n_out_cap;
   int cin, cin_pad, cout;
+  bool dense = false;   // same-stride layer with C <= 64: the dense-tile kernel (conv_dense.hip) instead of the list-based one
 };
 int dgr_conv_os_launch(const DgrConvOsLaunch &a, hipStream_t stream, const char **kernel_name = nullptr);
+bool dgr_conv_dense_supported(int cin, int cin_pad, int cout);
+int dgr_conv_dense_launch(const DgrConvOsLaunch &a, hipStream_t stream, const char **kernel_name = nullptr);
 int dgr_l2_normalize_rows(const float *in, int in_ld, float *out, int out_ld, int c, int relu,
                           const int32_t *n_dev, int64_t n_cap, hipStream_t stream);
 

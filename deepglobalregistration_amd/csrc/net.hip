@@ -90,6 +90,11 @@ static int make_layer(dgr_net *net, const dgr_weight_desc *descs, int nd, const 
   L.K = K; L.cin = cin; L.cout = cout;
   L.cin_pad = round_up(cin, 8);
   L.cout_pad = cout <= 32 ? 32 : cout <= 64 ? 64 : cout <= 128 ? 128 : 256;
+  // conv1 is the one layer whose Cin the caller chooses: zero-pad to the next width the rule-major kernel is built for
+  if (L.cout_pad == 32 && L.cin_pad > 8) {
+    DGR_REQUIRE(cin <= 64, "%s: %d input channels (at most 64 into a 32-channel layer)", name.c_str(), cin);
+    L.cin_pad = cin <= 32 ? 32 : 64;
+  }
   DGR_REQUIRE(cout <= 256 && cin <= 256, "%s: channel count above 256 not supported", name.c_str());
   const dgr_weight_desc *kd = find_desc(descs, nd, name + ".kernel");
   DGR_REQUIRE(kd != nullptr, "state_dict is missing '%s.kernel'", name.c_str());
@@ -378,6 +383,11 @@ struct Fwd {
       o.res = res ? res->ptr : nullptr; o.res_ld = res ? res->ld : 0; o.res_relu = res ? res->relu : 0;
       o.nbr = t; o.n_out_dev = cout_map.n_dev; o.n_out_cap = cout_map.n_cap;
       o.cin = L.cin; o.cin_pad = L.cin_pad; o.cout = L.cout;
+      // same-stride layers with C <= 64 (the two finest levels of ResUNetBN2C): dense tiles, no pair lists
+      static const bool os_lists = getenv("DGR_OS_LISTS") != nullptr;   // A/B + the bit-identity test of the two kernels
+      bool same_stride = false;
+      for (int l = 0; l < 4; ++l) same_stride = same_stride || t == &ms.nsame[l];
+      o.dense = same_stride && o.row_scale && !os_lists && dgr_conv_dense_supported(L.cin, L.cin_pad, L.cout);
       const char *kname = "sparse_conv_os";
       DGR_CHECK(dgr_conv_os_launch(o, stream, &kname));
       if (prof) {

@@ -324,9 +324,14 @@ __global__ void __launch_bounds__(REG_THREADS) registration_kernel(RegArgs a) {
 #ifdef DGR_REG_TIMING
     const long long tc0 = clock64();
 #endif
-#ifndef DGR_REG_F64_PARTIALS
+#ifdef DGR_REG_F32_PARTIALS
     // per-thread partial sums in f32 (<= ~100 terms each; the reference sums everything in f32), combined across
-    // threads in f64 in a fixed order: 10 % faster than f64 partials (13 conversions + 13 f64 adds per point)
+    // threads in f64 in a fixed order: 10 % faster per iteration than f64 partials (13 conversions + 13 f64 adds per
+    // point less).  NOT the default: with the f32 accumulators the compiler forms packed-f32 chains (v_pk_fma_f32 on
+    // loop-carried registers), and that build is reproducible only while the process has the GPU to itself -- next to
+    // a second process on the same GPU 4 % of 3000 runs of this kernel on fixed inputs ended a few ulps .. 2e-5 away
+    // (the iteration count moving by one), while the f64-partials build and a -fno-slp-vectorize build gave 0 of 3000
+    // twice (tools/contention_reg.sh).  The cause below the ISA level was not established.
     float g[13];
 #else
     double g[13];
@@ -382,7 +387,7 @@ __global__ void __launch_bounds__(REG_THREADS) registration_kernel(RegArgs a) {
     const long long tc1 = clock64();
 #endif
     double Gs[13];
-#ifndef DGR_REG_F64_PARTIALS
+#ifdef DGR_REG_F32_PARTIALS
     double gd[13];
 #pragma unroll
     for (int i = 0; i < 13; ++i) gd[i] = (double)g[i];

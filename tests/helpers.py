@@ -1,4 +1,6 @@
 """Shared helpers for the GPU parity tests."""
+import os
+
 import numpy as np
 
 
@@ -31,8 +33,24 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / max(1e-12, np.abs(b).max()))
 
 
+def _report(line):
+    """One line of the refinement-parity table: printed, and appended to $DGR_PARITY_REPORT/refine_parity.txt when
+    that directory is named (the round's table is committed as profiles/r03_refine_parity.txt)."""
+    print(line)
+    rep = os.environ.get('DGR_PARITY_REPORT')
+    if rep:
+        os.makedirs(rep, exist_ok=True)
+        with open(os.path.join(rep, 'refine_parity.txt'), 'a') as f:
+            f.write(line + '\n')
+
+
+def _case():
+    return os.environ.get('PYTEST_CURRENT_TEST', '?').split('::', 1)[-1].replace(' (call)', '')
+
+
 def assert_refine_parity(X, Y, w, R, t, stats, tol=1e-4, window=40, **kw):
-    """R, t of the HIP refinement vs the oracle (= the reference algorithm).
+    """FREE-RUNNING comparison: R, t of the HIP refinement vs the oracle (= the reference algorithm), each side
+    stopping by its own break counter.
 
     Bound: `tol` (1e-4, the north_star tolerance) -- or, where the reference itself does not settle to
     that level, the reference's own terminal oscillation band.  Adam with lr = 0.1 * 0.999^i keeps
@@ -52,16 +70,19 @@ def assert_refine_parity(X, Y, w, R, t, stats, tol=1e-4, window=40, **kw):
     to = to.reshape(3)
     assert abs(so['loss'] - stats['loss']) <= 2e-3 * abs(so['loss']) + 1e-9, (so, stats)
     dR, dt = np.abs(R - Ro).max(), np.abs(t - to).max()
-    if max(dR, dt) < tol:
-        return Ro, to, so
-    last = max(so['iterations'], stats['iterations']) + 1
-    kw2 = dict(kw)
-    kw2.update(max_iter=last, max_break_count=10 ** 9)
-    trace = []
-    oreg.global_registration(X, Y, w, trace=trace, **kw2)
-    tail = trace[max(0, min(so['iterations'], stats['iterations']) - window):]
-    band = max(max(np.abs(Ri - Ro).max(), np.abs(ti - to).max()) for Ri, ti in tail)
-    assert dR <= max(tol, band) and dt <= max(tol, band), (dR, dt, band, so, stats)
+    band = None
+    if max(dR, dt) >= tol:
+        last = max(so['iterations'], stats['iterations']) + 1
+        kw2 = dict(kw)
+        kw2.update(max_iter=last, max_break_count=10 ** 9)
+        trace = []
+        oreg.global_registration(X, Y, w, trace=trace, **kw2)
+        tail = trace[max(0, min(so['iterations'], stats['iterations']) - window):]
+        band = max(max(np.abs(Ri - Ro).max(), np.abs(ti - to).max()) for Ri, ti in tail)
+    _report(f'free-running       {_case():70s} n={len(X):6d} iterations hip {stats["iterations"]:4d} oracle {so["iterations"]:4d}  '
+            f'dR {dR:.1e} dt {dt:.1e}  ' + (f'oracle tail band {band:.1e}' if band is not None else 'inside 1e-4'))
+    if band is not None:
+        assert dR <= max(tol, band) and dt <= max(tol, band), (dR, dt, band, so, stats)
     return Ro, to, so
 
 
@@ -78,54 +99,36 @@ def oracle_pair_counts(maps, conv1_ks):
 
 
 def assert_iteration_matched(X, Y, w, tol=1e-4, **kw):
-    """Iteration-matched refinement parity on the given inputs: the oracle runs freely (k iterations), then BOTH sides
-    run exactly k iterations (max_iter = k, max_break_count = 10^9; the stopping logic is out of the picture).
+    """Iteration-matched refinement parity on the given inputs (the measurement is `oracle.parity.iteration_matched`):
+    the oracle runs freely (k iterations), then BOTH sides run exactly k iterations (max_iter = k, max_break_count =
+    10^9; the stopping logic is out of the picture).
     Required: |dR| <= tol, |dt| <= tol max(1, |t|), equal final losses (2e-3) -- unless the reference algorithm itself
     is not defined to that level on this input: Adam at lr = 0.1 * 0.999^i amplifies the f32 rounding of the loss /
     gradient sums (and HighDimSmoothL1Loss jumps at s = 1), so the oracle run on a fixed ROW PERMUTATION of the same
     input, or on the input changed by a few ULPs, with the same k moves by some band b; then the bound is
-    max(tol, 3 b).  Returns (deviation, band)."""
+    max(tol, 3 b).  The refinement starts at the weighted-Procrustes estimate, a stationary point of the loss whenever
+    all inlier residuals are below q: every gradient component is rounding noise and Adam's first step is lr * sign(g)
+    = +-0.1 per parameter whatever |g| is (measured: after ONE iteration the reference differs from itself by 0.27 when
+    its input changes by one ulp, tools/diag_refine.py; after 150 iterations most members of the perturbation family are
+    within 1e-4 of each other and one -- the sign pattern the HIP kernel also starts with -- is still 2e-3 away).
+    Returns (deviation, band)."""
     import torch
     from deepglobalregistration_amd import ops
-    from oracle import registration as oreg
-    X, Y = np.asarray(X, np.float32), np.asarray(Y, np.float32)
-    w = np.asarray(w, np.float32).reshape(-1, 1)
-    k = max(1, oreg.global_registration(X, Y, w, **kw)[2]['iterations'])
-    kw2 = dict(kw)
-    kw2.update(max_iter=k, max_break_count=10 ** 9)
-    Ro, to, so = oreg.global_registration(X, Y, w, **kw2)
-    R, t, st = ops.se3_refine(torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda(), torch.from_numpy(w).cuda(),
-                              kw.get('quantization_size', 1.0), k, 10 ** 9, kw.get('break_threshold_ratio', 1e-5))
-    assert st['iterations'] == so['iterations'], (st, so)
-    ts = max(1.0, float(np.abs(to).max()))      # metre-scale translations: absolute; KITTI scale (~10 m): relative
-    d = max(np.abs(R - Ro).max(), np.abs(t.reshape(-1) - to.reshape(-1)).max() / ts)
-    band = 0.0
+    from oracle import parity
+
+    def refine(Xn, Yn, wn, max_iter, max_break):
+        R, t, st = ops.se3_refine(torch.from_numpy(Xn).cuda(), torch.from_numpy(Yn).cuda(), torch.from_numpy(wn).cuda(),
+                                  kw.get('quantization_size', 1.0), max_iter, max_break, kw.get('break_threshold_ratio', 1e-5))
+        return R, t, st
+    r = parity.iteration_matched(X, Y, w, refine, tol=tol, **kw)
+    d, band = max(r['dR'], r['dt']), r['band'] or 0.0
+    _report(f'iteration-matched  {_case():70s} n={len(np.asarray(X)):6d} iterations {r["iterations"]:4d} (both sides)          '
+            f'dR {r["dR"]:.1e} dt {r["dt"]:.1e}  '
+            + (f'reference vs itself (row permutation / 1-ulp inputs) {band:.1e}' if r['band'] is not None else 'inside 1e-4')
+            + f'  loss hip {r["loss"]:.6e} oracle {r["loss_oracle"]:.6e}')
+    assert r['iterations_impl'] == r['iterations_oracle'], r
     if d > tol:
-        # Conditioning of the REFERENCE on this input.  The refinement starts at the weighted-Procrustes estimate, which
-        # is a stationary point of the loss whenever all inlier residuals are below q (0.5 s branch = the least-squares
-        # objective): every gradient component is rounding noise, and Adam's first step is lr * sign(g) = +-0.1 per
-        # parameter whatever |g| is.  The trajectory therefore starts with a kick whose signs are decided by the last
-        # bit (measured: after ONE iteration the reference differs from itself by 0.27 when its input changes by one
-        # ulp, tools/diag_refine.py) and the iterates keep oscillating around the optimum afterwards.  The band: the
-        # reference against itself on (a) a row permutation (order of its f32 sums) and (b) the source points changed
-        # by +-1 ulp (per-point roundings, what any re-implementation of `points @ R.T + t` differs in from a BLAS
-        # sgemm), over the last iterations before k.
-        # Measured on the 6000-point pipeline input (tools/diag_refine.py): after one iteration the members of this
-        # family sit at t0 +- 0.1 per component in eight different sign patterns; after 150 iterations most are within
-        # 1e-4 of each other and one (the pattern the HIP kernel also starts with) is still 2e-3 away.
-        perm = np.random.default_rng(0).permutation(len(X))
-        variants = [(X[perm], Y[perm], w[perm])]
-        for j in range(1, 9):
-            variants.append((X * np.float32(1 + ((-1) ** j) * j * 2.0 ** -23), Y * np.float32(1 + (j % 3 - 1) * 2.0 ** -23), w))
-        for kk in sorted({k, max(1, k - 7), max(1, k - 15), max(1, k - 30)}):
-            kw3 = dict(kw2, max_iter=kk)
-            Rb, tb, _ = (Ro, to, None) if kk == k else oreg.global_registration(X, Y, w, **kw3)
-            for Xv, Yv, wv in variants:
-                Rp, tp, _ = oreg.global_registration(Xv, Yv, wv, **kw3)
-                band = max(band, np.abs(Rp - Rb).max(), np.abs(tp.reshape(-1) - tb.reshape(-1)).max() / ts)
-        assert d <= max(tol, 3 * band), (d, band, k)
+        assert d <= max(tol, 3 * band), (d, band, r['iterations'])
     else:
-        assert abs(st['loss'] - so['loss']) <= 2e-3 * abs(so['loss']) + 1e-9, (k, st, so)
-    print(f'iteration-matched parity: {d:.1e} after {k} iterations'
-          + (f' (the reference against itself on a row permutation / a 1-ulp change of the input, last 30 iterations: {band:.1e})' if band else ''))
+        assert abs(r['loss'] - r['loss_oracle']) <= 2e-3 * abs(r['loss_oracle']) + 1e-9, r
     return d, band

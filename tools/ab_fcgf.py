@@ -1,4 +1,5 @@
-"""A/B: FCGF forward of one 4-pair batch (8 clouds), output-stationary vs rule-major (env switch needs separate processes)."""
+"""A/B: FCGF forward of one 4-pair batch (8 clouds) with per-layer times; the variant is chosen by the environment
+(DGR_OS_LISTS=1: list-based kernel everywhere; DGR_HIP_LIB: another build of the library), one process per variant."""
 import os, sys, time, numpy as np, torch
 sys.path.insert(0, '.')
 from deepglobalregistration_amd import ops, synth
@@ -26,7 +27,8 @@ torch.cuda.synchronize()
 t0 = time.time()
 for _ in range(10): F = net.forward(C, ones)
 torch.cuda.synchronize()
-print('sorted' if os.environ.get('AB_SORT') else 'random-order', 'mode', 'rule-major' if os.environ.get('DGR_CONV3D_RULEMAJOR') else 'output-stationary', 'N', len(C), 'fwd ms', (time.time() - t0) * 100)
+tag = os.environ.get('AB_TAG', 'lists' if os.environ.get('DGR_OS_LISTS') else 'default')
+print('sorted' if os.environ.get('AB_SORT') else 'random-order', 'variant', tag, 'N', len(C), 'fwd ms', (time.time() - t0) * 100)
 ops.set_profiling('cuda', True)
 F = net.forward(C, ones)
 t, g = ops.conv_launch_times('cuda'); kinds = ops.conv_launch_kinds('cuda')
@@ -34,4 +36,4 @@ st = ops.stage_times('cuda')
 ops.set_profiling('cuda', False)
 print('maps_3d', st['maps_3d'], 'conv', st['conv_kernels'])
 for i, (a, k) in enumerate(zip(t, kinds)): print(f'  L{i:2d} {a*1e3:8.1f} us  {k}')
-np.save('gpurun_out/ab_F_%s.npy' % ('rm' if os.environ.get('DGR_CONV3D_RULEMAJOR') else 'os'), F.cpu().numpy())
+if os.environ.get('AB_SAVE'): np.save('gpurun_out/ab_F_%s.npy' % tag, F.cpu().numpy())
