@@ -30,6 +30,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // (native vector: HIP's uint4 struct copies as memcpy and stays in scratch)
 
 struct ConvDenseArgs {
@@ -43,6 +44,7 @@ struct ConvDenseArgs {
   int in_ld, in_relu, out_ld, out_relu, res_ld, res_relu;
   const float *row_scale;  // power-of-two scale per input row (dgr_row_scale)
   float w_unscale;         // inverse of the layer's weight scale
+  uint32_t in_bytes;       // size of the input tensor (row capacity x row stride): bound of the buffer loads
 };
 
 // CIN, COUT in {32, 64}; RG = 16-row groups per wave; WAVES per workgroup
@@ -84,7 +86,15 @@ __global__ void __launch_bounds__(64 * WAVES, 2) sparse_conv_dense_f16x2(ConvDen
 #pragma unroll
     for (int u = 0; u < WPT; ++u) {
       const int c = tid + u * THREADS;
-      if (WU % THREADS == 0 || c < WU) wlds[buf][c] = w.v[u];
+      if (WU % THREADS == 0 || c < WU) {
+        // fragment c = (piece, s, cb, lane' = (col, lq')) holds channels 8 lq' + (0..7) of its 32-channel step; the
+        // gather below hands lane (col, lq) the channels 4 lq + (0..3) and 16 + 4 lq + (0..3): each 8-byte half u goes
+        // to lane (col, 2 (lq' & 1) + u), first or second half by lq' >> 1
+        const int ln = c & 63, col = ln & 15, lqs = ln >> 4;
+        u32x2 *dst = reinterpret_cast<u32x2 *>(&wlds[buf][(c & ~63) + col]);
+        dst[(16 * (2 * (lqs & 1) + 0)) * 2 + (lqs >> 1)] = u32x2{w.v[u].x, w.v[u].y};
+        dst[(16 * (2 * (lqs & 1) + 1)) * 2 + (lqs >> 1)] = u32x2{w.v[u].z, w.v[u].w};
+      }
     }
   };
   WRegs wr;
@@ -117,68 +127,92 @@ __global__ void __launch_bounds__(64 * WAVES, 2) sparse_conv_dense_f16x2(ConvDen
   wload(1, wr);
 
   // gathered rows of the NEXT offset: requested here, consumed (split into pieces) at the top of the next iteration
-  f32x4 raw[RG][S][2];
-  float sc[RG];
-  int nv[RG];
-  auto gather = [&](int k) {
-    // unconditional requests (a missing neighbour reads row 0 under scale 0 -> a zero operand): no branches in the loop
-    // body, so that the requests stay where they are written (conv_os.hip, same reason)
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in), 0, a.in_bytes, 0x00020000);
+  // the gathered rows of one offset (raw f32, requested DEPTH offsets ahead), their row scales and table entries
+  struct RowSet { f32x4 raw[RG][S][2]; float sc[RG]; int nv[RG]; };
+  // Request layout: lane L = 4 r + c reads 16 bytes of row r of the group so that every QUAD of lanes reads 64
+  // contiguous bytes of one row -- one request of the vector-memory path per quad.  (Requesting straight in MFMA
+  // operand layout, lane = 16 chunk + row, makes every lane of a quad touch a different row: four requests per quad,
+  // measured 64 cycles per instruction and the kernel bounded by nothing else.)  The operand layout is restored after
+  // the split by ds_bpermute (the LDS crossbar, no LDS memory).
+  auto gather = [&](int k, RowSet &g) {
+    // unconditional requests: no branches in the loop body, so that the requests stay where they are written
+    // (conv_os.hip, same reason)
 #pragma unroll
     for (int rg = 0; rg < RG; ++rg) {
-      const int n = nbr_s[k][(wave * RG + rg) * 16 + lr];
+      const int n = nbr_s[k][(wave * RG + rg) * 16 + (lane >> 2)];
       const int ne = max(n, 0);
 #ifdef DGR_DENSE_ABL_NOGATHER   // timing ablations (outputs are garbage): tools/ab_fcgf.py with DGR_HIP_LIB
       const float sv = 1.f;
 #pragma unroll
-      for (int s = 0; s < S; ++s) raw[rg][s][0] = raw[rg][s][1] = f32x4{(float)ne, 1.f, 2.f, 3.f};
+      for (int s = 0; s < S; ++s) g.raw[rg][s][0] = g.raw[rg][s][1] = f32x4{(float)ne, 1.f, 2.f, 3.f};
 #else
-      const float *p = a.in + (int64_t)ne * a.in_ld + 8 * lq;
+      // buffer loads: a missing neighbour gets an offset past the tensor -- the bounds check returns zeros without a
+      // memory access, and the request stays branch-free
+      const uint32_t off = n >= 0 ? (uint32_t)n * (uint32_t)(a.in_ld * 4) + 16u * (lane & 3) : a.in_bytes;
       const float sv = a.row_scale[ne];
 #pragma unroll
       for (int s = 0; s < S; ++s) {
-        raw[rg][s][0] = *reinterpret_cast<const f32x4 *>(p + 32 * s);
-        raw[rg][s][1] = *reinterpret_cast<const f32x4 *>(p + 32 * s + 4);
+        g.raw[rg][s][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off + 128 * s, 0, 0));
+        g.raw[rg][s][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off + 128 * s + 64, 0, 0));
       }
 #endif
-      sc[rg] = sv;   // (selected against `nv` when it is consumed: nothing here may wait for the request)
-      nv[rg] = n;
+      g.sc[rg] = sv;   // (selected against `nv` when it is consumed: nothing here may wait for the request)
+      g.nv[rg] = n;
     }
   };
-  gather(0);
+#ifndef DGR_DENSE_DEPTH
+#define DGR_DENSE_DEPTH 1
+#endif
+  // offsets the row requests run ahead (one register set each).  Measured on the 195 k-row 64 -> 64 layers: depth 2
+  // (230 VGPRs) 202 us, depth 1 (176 VGPRs) 205 us -- the gather is bounded by the memory system's rate for random
+  // 256-byte rows beyond the L2 (tools/microbench/vmem_bw.hip), not by latency
+  constexpr int DEPTH = DGR_DENSE_DEPTH;
+  static_assert(DEPTH == 1 || DEPTH == 2, "prefetch depth");
+  RowSet gA, gB;
+  gather(0, gA);
+  if (DEPTH == 2) gather(1, gB);
   const int relu_lo = a.in_relu ? 0 : (int)0x80000000;   // pending ReLU of the producer as one integer max per value
   __syncthreads();
 
-#pragma unroll 1
-  for (int k = 0; k < KV; ++k) {
+  auto body = [&](int k, RowSet &g) {
     // ---- operands of this offset: s x = h + m, two f16 pieces (dgr_split2), in MFMA B layout
     f16x8 bh[RG][S], bm[RG][S];
     float fold[RG];
+    // lane T = 16 lq + lr of the operand layout takes from lane 4 lr + lq of the request layout
+    const int from = 4 * (4 * (lane & 15) + (lane >> 4));
 #pragma unroll
     for (int rg = 0; rg < RG; ++rg) {
-      const float sx = nv[rg] >= 0 ? sc[rg] : 0.f;
-      fold[rg] = sx != 0.f ? dgr_inv_pow2(sx) * a.w_unscale : 0.f;
+      const float sx = g.nv[rg] >= 0 ? g.sc[rg] : 0.f;
+      const float fl = sx != 0.f ? dgr_inv_pow2(sx) * a.w_unscale : 0.f;
+      fold[rg] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(16 * (lane & 15), __builtin_bit_cast(int, fl)));
 #pragma unroll
       for (int s = 0; s < S; ++s) {
-#ifdef DGR_DENSE_ABL_NOCONV
-        bh[rg][s] = __builtin_bit_cast(f16x8, raw[rg][s][0]);
-        bm[rg][s] = __builtin_bit_cast(f16x8, raw[rg][s][1]);
-        continue;
-#endif
-        float x[8];
+        i32x4 hw, mw;   // four dwords = eight halves each: elements 0..3 from the first request, 4..7 from the second
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const i32x4 v = __builtin_bit_cast(i32x4, raw[rg][s][h]);
+#ifdef DGR_DENSE_ABL_NOCONV
+          const i32x4 v = __builtin_bit_cast(i32x4, g.raw[rg][s][h]);
+          hw[2 * h] = v[0]; hw[2 * h + 1] = v[1]; mw[2 * h] = v[2]; mw[2 * h + 1] = v[3];
+#else
+          const i32x4 v = __builtin_bit_cast(i32x4, g.raw[rg][s][h]);
 #pragma unroll
-          for (int u = 0; u < 4; ++u) x[4 * h + u] = __builtin_bit_cast(float, max(v[u], relu_lo));
+          for (int u = 0; u < 4; u += 2) {
+            const f32x2 xs = f32x2{__builtin_bit_cast(float, max(v[u], relu_lo)), __builtin_bit_cast(float, max(v[u + 1], relu_lo))} * sx;
+            const f16x2 hh = __builtin_convertvector(xs, f16x2);
+            const f16x2 mm = __builtin_convertvector(xs - __builtin_convertvector(hh, f32x2), f16x2);
+            hw[2 * h + u / 2] = __builtin_bit_cast(int, hh);
+            mw[2 * h + u / 2] = __builtin_bit_cast(int, mm);
+          }
+#endif
         }
 #pragma unroll
-        for (int u = 0; u < 8; u += 2) {
-          const f32x2 xs = f32x2{x[u], x[u + 1]} * sx;
-          const f16x2 hh = __builtin_convertvector(xs, f16x2);
-          const f16x2 mm = __builtin_convertvector(xs - __builtin_convertvector(hh, f32x2), f16x2);
-          bh[rg][s][u] = hh[0]; bh[rg][s][u + 1] = hh[1];
-          bm[rg][s][u] = mm[0]; bm[rg][s][u + 1] = mm[1];
+        for (int d = 0; d < 4; ++d) {
+          hw[d] = __builtin_amdgcn_ds_bpermute(from, hw[d]);
+          mw[d] = __builtin_amdgcn_ds_bpermute(from, mw[d]);
         }
+        bh[rg][s] = __builtin_bit_cast(f16x8, hw);
+        bm[rg][s] = __builtin_bit_cast(f16x8, mw);
       }
     }
     __builtin_amdgcn_sched_barrier(0);   // operands complete before the raw registers are re-requested (else the scheduler
@@ -186,13 +220,13 @@ __global__ void __launch_bounds__(64 * WAVES, 2) sparse_conv_dense_f16x2(ConvDen
                                          // conversions wait for the NEW requests)
     // ---- next offset: weights into the other LDS buffer (its readers finished before the last barrier), rows and
     //      the offset after next's weights requested; everything arrives during this offset's MFMAs
+    // (the weights are requested BEFORE the rows: the memory counter is in order, and the next wstore must not have to
+    // wait for row requests that are younger than its weights)
 #ifndef DGR_DENSE_ABL_NOW
     wstore((k + 1) & 1, wr);   // (after the last offset: into the buffer nobody reads any more)
-#endif
-    gather(min(k + 1, KV - 1));
-#ifndef DGR_DENSE_ABL_NOW
     wload(min(k + 2, KV - 1), wr);
 #endif
+    gather(min(k + DEPTH, KV - 1), g);   // refills the set just consumed
     __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks these requests below the MFMAs: no time in flight)
     // ---- this offset's tile: tmp = W[k]^T x (zero for missing neighbours)
     f32x4 tmp[RG][NCB];
@@ -225,6 +259,17 @@ __global__ void __launch_bounds__(64 * WAVES, 2) sparse_conv_dense_f16x2(ConvDen
 #ifndef DGR_DENSE_ABL_NOBAR
     __syncthreads();   // buffer k & 1 is free again; buffer (k + 1) & 1 is complete
 #endif
+  };
+  if (DEPTH == 1) {
+#pragma unroll 1
+    for (int k = 0; k < KV; ++k) body(k, gA);
+  } else {
+#pragma unroll 1
+    for (int k = 0; k < KV - 1; k += 2) {
+      body(k, gA);
+      body(k + 1, gB);
+    }
+    body(KV - 1, gA);
   }
 
   // ---- the rows are written once (ReLU applied here when the tensor carries one)
@@ -276,6 +321,8 @@ int dgr_conv_dense_launch(const DgrConvOsLaunch &a, hipStream_t stream, const ch
   ka.in_ld = a.in_ld; ka.in_relu = a.in_relu; ka.out_ld = a.out_ld; ka.out_relu = a.out_relu;
   ka.res_ld = a.res_ld; ka.res_relu = a.res_relu;
   ka.row_scale = a.row_scale; ka.w_unscale = a.w_unscale;
+  DGR_REQUIRE(a.n_in_cap > 0 && a.n_in_cap * (int64_t)a.in_ld * 4 < (1ll << 31), "dense-tile conv: input tensor beyond 2 GB");
+  ka.in_bytes = (uint32_t)(a.n_in_cap * (int64_t)a.in_ld * 4);
 #define DGR_DENSE(CI, CO)                                                                   \
   if (a.cin == CI && a.cout == CO) {                                                        \
     if (kernel_name) *kernel_name = "sparse_conv_dense_f16x2<" #CI ", " #CO ">";            \

@@ -1,8 +1,11 @@
 """The dense-tile kernel of the same-stride C <= 64 layers of the 3-D net (conv_dense.hip) against the list-based
 output-stationary kernel it replaces there (conv_os.hip, forced by DGR_OS_LISTS=1): both compute, per (output row,
-offset), the same product row with the same MFMA sequence and add it in ascending offset order onto shift + residual,
-so every tensor of the FCGF forward must come out BIT FOR BIT equal (model/resunet.py:598-649).  The list-based kernel
-is held to the oracle and to f64 by tests/test_gpu_resunet.py / test_gpu_split_f64.py; this test carries that over."""
+offset), one product row from the same two-f16-piece operands with three MFMAs per 32-channel step and add it, scaled
+back, in ascending offset order onto shift + residual (model/resunet.py:598-649).  The dense kernel feeds the input
+channels of a 32-channel step to the matrix unit in a different order (its quad-coalesced gather), so the f32 sums inside
+one MFMA round differently: the tensors of the FCGF forward must agree to a few f32 ulps of their scale, far below the
+1e-4 parity tolerance; the unit-norm output features to 2e-6.  The list-based kernel is held to the oracle and to f64 by
+tests/test_gpu_resunet.py / test_gpu_split_f64.py, and so -- being the default -- is the dense one."""
 import os
 import subprocess
 import sys
@@ -30,15 +33,17 @@ def dumps(tmp_path_factory):
 def test_each_variant_ran_its_kernels(dumps):
     for net in ('k7', 'k3'):
         kd, kl = dumps['dense'][net + '_kinds'].tolist(), dumps['lists'][net + '_kinds'].tolist()
-        # block1 (32 -> 32 twice), block2 (64 -> 64 twice), block2_tr and block1_tr (64 -> 64 twice each): 8 layers
+        # block1 (32 -> 32 twice), block2 (64 -> 64 twice), block3_tr and block2_tr (64 -> 64 twice each): 8 layers
         assert sum(k.startswith('sparse_conv_dense_f16x2') for k in kd) == 8, kd
         assert not any('dense' in k for k in kl) and sum(k.startswith('sparse_conv_os') for k in kl) >= 8
 
 
-def test_every_tensor_bit_for_bit(dumps):
-    assert dumps['dense']['n'].sum() % 128 != 0
+def test_every_tensor_agrees_with_the_list_based_kernel(dumps):
+    assert dumps['dense']['n'].sum() % 128 != 0     # the last row block is partial
     for net in ('k7', 'k3'):
         for n in ('s1', 's2', 's4', 's8', 's4_tr', 's2_tr', 's1_tr', 'F'):
             a, b = dumps['dense'][f'{net}_{n}'], dumps['lists'][f'{net}_{n}']
-            assert np.isfinite(a).all() and np.abs(a).max() > 0
-            np.testing.assert_array_equal(a, b, err_msg=f'{net} {n}')
+            assert np.isfinite(a).all() and np.abs(a).max() > 0 and a.shape == b.shape
+            err = float(np.abs(a.astype(np.float64) - b).max() / np.abs(b).max())
+            print(f'{net} {n:6s} max |dense - lists| / max |lists| = {err:.1e}')
+            assert err < 2e-6, (net, n, err)
