@@ -15,8 +15,15 @@ if [ "$1" != quick ]; then
   timeout 900 $B --total-pairs 512 --steps 2 --warmup 1 --no-parity > $O/bench_c4shape_512pairs_1gpu.json 2> $O/bench_c4shape.err
   timeout 300 $B --from-host --no-parity > $O/bench_c1_from_host.json 2> $O/bench_c1_from_host.err
 fi
-# split-operand arithmetic against f64 (stand-alone harness around the wide-layer kernel; built by hand, see its header)
-for b in p2 p2_64 p2_128 p2_256_128 p3; do [ -x $R/tools/microbench/bf3_check_$b ] && (cd $R/tools/microbench && timeout 60 ./bf3_check_$b | grep max) ; done > $O/split_operand_vs_f64.txt 2>&1
+# the reference arithmetic (exact-f32 MFMA kernels) on the same workload, register() as shipped (ICP on), and every pair
+# forced through the safeguard
+DGR_EXACT_F32=1 timeout 600 $B --steps 20 --warmup 3 --no-parity > $O/bench_c1_exact_f32.json 2> $O/bench_c1_exact_f32.err
+timeout 600 $B --full-register --no-parity > $O/bench_c1_full_register.json 2> $O/bench_c1_full_register.err
+timeout 600 $B --force-safeguard --no-parity --steps 3 --warmup 1 > $O/bench_c1_force_safeguard.json 2> $O/bench_c1_force_safeguard.err
+# the whole GPU suite with the parity tables (split operands vs f64; refinement vs the oracle, iteration-matched and free-running)
+if [ "$1" != quick ]; then
+  (cd $R && DGR_PARITY_REPORT=$O/parity timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -15 > $O/pytest_gpu.log)
+fi
 # kernel stats: the single-stream command gives durations free of time-slicing (comparable with roofline.avg_launch_us)
 timeout 300 rocprofv3 --kernel-trace -d $O/kt1 -o kt -- $B --streams 1 --pairs-per-step 4 --no-parity --steps 5 > $O/kt1.log 2>&1
 python $R/tools/rocpd_summary.py $O/kt1/kt_results.db $O/kernel_stats_s1_b4.csv --trace sparse_conv $O/conv_trace_s1_b4.csv
@@ -32,7 +39,8 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_VALU_
 done
 python $R/tools/pmc_dominant.py "$K" "BASELINE configs[1]" $DBS > $O/dominant_pmc.json
 python $R/tools/pmc_dominant.py "sparse_conv_os<64, 64" "BASELINE configs[1]" $DBS > $O/os_conv_pmc.json
-python $R/tools/pmc_dominant.py "reduce_rows_kernel<64>" "BASELINE configs[1]" $DBS > $O/reduce_rows_pmc.json
+python $R/tools/pmc_dominant.py "sparse_conv_dense_f16x2<64, 64" "BASELINE configs[1]" $DBS > $O/dense_conv_pmc.json
+python $R/tools/pmc_dominant.py "reduce_rows_kernel<64" "BASELINE configs[1]" $DBS > $O/reduce_rows_pmc.json
 python $R/tools/pmc_dominant.py "sparse_conv_os<32, 32" "BASELINE configs[1]" $DBS > $O/os_conv32_pmc.json
 rm -rf $O/kt1 $O/kt3 $O/pmc
 ls -la $O; tail -c 400 $O/bench_c1_default.json
