@@ -4,8 +4,8 @@
 // conv of ResUNetBN2C (model/resunet.py:598-649, model/residual_block.py:15-80).
 //
 // Since round 2 this file holds the exact-f32 MFMA kernel of the layers the split-operand kernels do not cover
-// (k = 1 convs, C_out = 64 in the 6-D net, odd widths; all wide layers with DGR_CONV_F32=1), the reduction pass
-// shared with conv_bf3.hip, and the FCGF conv1 kernels; the wide 6-D layers run in conv_bf3.hip and every K = 27
+// (k = 1 convs, C_out = 64 in the 6-D net, odd widths; all wide layers with DGR_EXACT_F32=1), the reduction pass
+// shared with conv_wide.hip, and the FCGF conv1 kernels; the wide 6-D layers run in conv_wide.hip and every K = 27
 // conv of the 3-D net in conv_os.hip.
 //
 // Phase 1 (sparse_conv_mfma_v2): the kernel map lists pairs (in, out) per kernel offset k ("rule").  A

@@ -82,11 +82,11 @@ __global__ void __launch_bounds__(CS * 4 * (TM / 16 / GW)) sparse_conv_os(ConvOs
   constexpr int KPW = (KV + NW - 1) / NW;   // offsets compacted per wave
   constexpr int NGMAX = KV * ((MB / 16 + GP - 1) / GP * GP) + GP;
   static_assert(CP % CK == 0, "shape");
-  constexpr int LDP = CK + 8;                 // BF3: bf16 elements per plane row
+  constexpr int LDP = CK + 8;                 // split planes: f16 elements per plane row
   constexpr int PLANE = TM * LDP;             // bf16 elements per plane
-  constexpr int G32 = CK / 32;                // BF3: 32-channel k-steps per phase
+  constexpr int G32 = CK / 32;                // split planes: 32-channel k-steps per phase
   constexpr int ABYTES = BF3 ? 2 * NP * PLANE * 2 : 2 * TM * LDA * 4;
-  __shared__ __attribute__((aligned(16))) char abuf[ABYTES];   // f32: As[2][TM][LDA]; BF3: planes [2][3][TM][LDP] bf16
+  __shared__ __attribute__((aligned(16))) char abuf[ABYTES];   // f32: As[2][TM][LDA]; split: planes [2][2][TM][LDP] f16
   float (*As)[TM][LDA] = reinterpret_cast<float (*)[TM][LDA]>(abuf);
   unsigned short *Ps = reinterpret_cast<unsigned short *>(abuf);
   __shared__ __attribute__((aligned(16))) float acc_s[MB][LDC];

@@ -1,5 +1,5 @@
 """The split-operand conv kernels (two f16 pieces per f32 operand, three MFMA products per MAC: conv_wide.hip,
-conv_os.hip) against float64 truth, next to the exact-f32 MFMA kernels (DGR_EXACT_F32=1) on the same inputs.
+conv_os.hip, conv_dense.hip) against float64 truth, next to the exact-f32 MFMA kernels (DGR_EXACT_F32=1) on the same inputs.
 
 Every device result is produced by the real layer kernels -- through `dgr_resunet_forward` for (a) and (b), through
 `dgr_debug_conv_layer` for (c) -- in two processes (the arithmetic mode is fixed when a net is built) and compared with
@@ -140,7 +140,7 @@ def test_single_layers_on_adversarial_rows(dumps, which):
             tiny = rb <= 1e-30
             if tiny.any():
                 assert np.abs(y - truth)[tiny].max() <= 1e-36, mode   # denormal neighbourhoods: absolutely negligible
-        kern = 'sparse_conv_wide_f16x2<256, 2>' if which == '6' else 'sparse_conv_os<64, 64, .., f16x2>'
+        kern = 'sparse_conv_wide_f16x2<256, 2>' if which == '6' else 'sparse_conv_dense_f16x2<64, 64>'
         report(f'{kern:34s} relu={relu} max over rows of max|y - f64| / max sum|x||w|:  split {res["split"]:.2e}   '
                f'exact-f32 {res["f32"]:.2e}   ratio {res["split"] / max(res["f32"], 1e-300):.2f}')
         assert res['split'] <= max(1.5 * res['f32'], 2e-7), (which, relu, res)

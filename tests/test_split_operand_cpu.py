@@ -1,11 +1,11 @@
-"""The split-operand arithmetic of the conv kernels (conv_bf3.hip, conv_os.hip), restated in numpy on the CPU.
+"""The split-operand arithmetic of the conv kernels (conv_wide.hip, conv_os.hip, conv_dense.hip), restated in numpy on the CPU.
 
 An f32 operand x under a power-of-two scale s is represented as s x = h + m + d with h = rn16(s x),
 m = rn16(s x - h); the kernels keep the products w_h x_h + w_h x_m + w_m x_h.  This test states the two claims
 DESIGN.md 4.2 makes about it, without a GPU: (1) the representation error per operand is <= 2^-22 relative (and
 zero for most operands), rows of any magnitude included; (2) a dot product formed from the three kept products is
 closer to the exact result than an f32 FMA chain over the unsplit operands.  The GPU-side measurement of the real
-kernel is tools/microbench/bf3_check.hip (profiles/r02_split_operand_vs_f64.txt)."""
+kernels is tests/test_gpu_split_f64.py (profiles/r03_split_vs_f64.txt)."""
 import numpy as np
 
 
