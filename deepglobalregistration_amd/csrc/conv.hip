@@ -37,6 +37,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvKArgs {
   const float *in;
@@ -48,6 +50,7 @@ struct ConvKArgs {
   const int4 *tile_desc;
   int in_ld, out_ld, in_relu, y_ld;
   int cin, cin_pad, cout, K;
+  int l2_normalize;    // identity maps, Cout <= 32 (one 32-channel block per row): x / (|x|_2 + 1e-8) on the way out
 };
 
 // Product rows are written once and read once.  Measured on the 256-wide layers (3.7 GB of product rows per
@@ -294,6 +297,25 @@ __global__ void __launch_bounds__(64 * WM * WN, (MB * NB >= 4 ? DGR_WIDE_WAVES :
 #pragma unroll
       for (int i = 0; i < MB; ++i) {
         const int r = 32 * (wm * MB + i) + (lane & 31);
+        if (identity && a.l2_normalize) {
+          // the feature row of the `final` conv leaves unit-norm (model/resunet.py:643-647): a row's <= 32 channels sit
+          // in lanes l and l ^ 32 of the one wave column -- shift first, one cross-lane add, one division per value
+          float ss = 0.f;
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int col = 8 * g + 4 * (lane >> 5) + u;
+              float v = acc[i][0][4 * g + u] + ((a.shift && col < a.cout) ? a.shift[col] : 0.f);
+              if (col >= a.cout) v = 0.f;
+              acc[i][0][4 * g + u] = v;
+              ss += v * v;
+            }
+          ss += __shfl_xor(ss, 32, 64);
+          const float den = sqrtf(ss) + 1e-8f;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][0][e] = acc[i][0][e] / den;
+        }
         if (r < cnt) {
 #ifdef DGR_ABL_STORE0
           float *dst = a.y + (int64_t)(r + 64 * (blockIdx.x & 1023)) * a.y_ld;  // timing ablation: L2-resident product rows
@@ -308,12 +330,12 @@ __global__ void __launch_bounds__(64 * WM * WN, (MB * NB >= 4 ? DGR_WIDE_WAVES :
               f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
               if (identity) {
                 if (col + 3 < a.cout && (a.out_ld & 3) == 0) {
-                  if (a.shift) v += *reinterpret_cast<const f32x4 *>(a.shift + col);
+                  if (a.shift && !a.l2_normalize) v += *reinterpret_cast<const f32x4 *>(a.shift + col);
                   *reinterpret_cast<f32x4 *>(dst + col) = v;
                 } else {
 #pragma unroll
                   for (int u = 0; u < 4; ++u)
-                    if (col + u < a.cout) dst[col + u] = v[u] + (a.shift ? a.shift[col + u] : 0.f);
+                    if (col + u < a.cout) dst[col + u] = v[u] + ((a.shift && !a.l2_normalize) ? a.shift[col + u] : 0.f);
                 }
               } else if (col < a.cout) {
                 *reinterpret_cast<f32x4 *>(dst + col) = v;  // y_ld = cout is a multiple of 32 here
@@ -359,6 +381,9 @@ int dgr_conv_launch(const DgrConvLaunch &a, int num_cus, hipStream_t stream, con
   ka.n_rows_dev = a.n_rows_dev; ka.tile_desc = a.tile_desc;
   ka.in_ld = a.in_ld; ka.out_ld = a.out_ld; ka.in_relu = a.in_relu;
   ka.cin = a.cin; ka.cin_pad = a.cin_pad; ka.cout = a.cout; ka.K = a.K;
+  ka.l2_normalize = a.l2_normalize;
+  DGR_REQUIRE(!a.l2_normalize || (a.pair_in == nullptr && a.cout <= 32 && a.cout_pad == 32),
+              "fused l2 normalisation needs an identity map and Cout <= 32 (got %d)", a.cout);
   DGR_REQUIRE(a.cin_pad % 8 == 0 && a.cin_pad >= a.cin && a.cin_pad <= 256, "bad cin_pad %d", a.cin_pad);
   const int64_t tile_bound = a.tile_bound > 0 ? a.tile_bound : (int64_t)num_cus * 4;
   // specialised (compile-time Cin, pipelined) instantiations for every layer shape of ResUNetBN2C
@@ -427,7 +452,7 @@ __global__ void __launch_bounds__(256)
       acc += v0; acc += v1; acc += v2; acc += v3;
     }
     for (; j < end; ++j) acc += dgr_y_load<LPR == 64>(y + (int64_t)pos[j] * y_ld + c);
-    *reinterpret_cast<f32x4 *>(out + row * out_ld + c) = acc;
+    if (!SPLIT || out) *reinterpret_cast<f32x4 *>(out + row * out_ld + c) = acc;   // (split-only tensors: out == nullptr)
     if constexpr (SPLIT) {
       // the row as the wide-layer kernel gathers it (conv_wide.hip): scale from the row's largest |x| after the
       // consumers' pending ReLU (the LPR lanes of a row are consecutive lanes of one wave), two f16 planes
@@ -450,9 +475,17 @@ __global__ void __launch_bounds__(256)
         dgr_split2(__builtin_bit_cast(float, xb[u]), sx, hh, mm);
         h[u] = hh; m[u] = mm;
       }
+      // lanes 2 j and 2 j + 1 hold channels 8 j .. 8 j + 3 and 8 j + 4 .. 8 j + 7: they swap one piece, so that the even
+      // lane stores 16 bytes of h and the odd lane 16 bytes of m (one 16-byte store per lane instead of two 8-byte ones)
+      const bool odd = threadIdx.x & 1;
+      const u32x2 hb = __builtin_bit_cast(u32x2, h), mb = __builtin_bit_cast(u32x2, m);
+      const u32x2 give = odd ? hb : mb;
+      u32x2 got;
+      got.x = (uint32_t)__shfl_xor((int)give.x, 1, 64);
+      got.y = (uint32_t)__shfl_xor((int)give.y, 1, 64);
+      const u32x4 st = odd ? u32x4{got.x, got.y, mb.x, mb.y} : u32x4{hb.x, hb.y, got.x, got.y};
       unsigned char *dst = planes + row * (LPR * 16);
-      *reinterpret_cast<f16x4 *>(dst + dgr_split_row_offset(c, 0)) = h;
-      *reinterpret_cast<f16x4 *>(dst + dgr_split_row_offset(c, 1)) = m;
+      *reinterpret_cast<u32x4 *>(dst + dgr_split_row_offset(c & ~7, odd ? 1 : 0)) = st;
       if (c == 0) scale_out[row] = sx;
     }
   }
@@ -462,6 +495,7 @@ int dgr_reduce_rows(const float *y, int cout, const int32_t *ptr, const int32_t 
                     int64_t n_cap, float *out, int out_ld, const float *shift, const float *res, int res_ld,
                     int res_relu, hipStream_t stream, const DgrSplitRows *split, int out_relu) {
   DGR_REQUIRE((out_ld & 3) == 0 && (res == nullptr || (res_ld & 3) == 0), "reduce_rows: row strides must be x4");
+  DGR_REQUIRE(out || split, "reduce_rows: no output");
   DGR_REQUIRE(!split || (split->planes && split->scale && split->channels == cout && cout % 64 == 0),
               "reduce_rows: split rows need planes, scales and the layer's width (a multiple of 64)");
   const int lpr = cout / 4;

@@ -182,6 +182,7 @@ struct DgrConvLaunch {
   const int4 *tile_desc;                                     // per-tile (k, first pair, count)
   const int32_t *n_rows_dev;                                 // identity map: number of rows
   int64_t tile_bound;                                        // host upper bound on the tile count (0 = unknown)
+  int l2_normalize = 0;   // identity maps with Cout <= 32: rows leave as x / (|x|_2 + 1e-8) (model/resunet.py:643-647)
 };
 int dgr_conv_launch(const DgrConvLaunch &a, int num_cus, hipStream_t stream, const char **kernel_name = nullptr);
 // A tensor in the form the wide-layer kernel gathers (conv_wide.hip): per row channels / 64 blocks of 256 bytes

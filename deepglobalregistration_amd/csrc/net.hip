@@ -46,6 +46,7 @@ struct LayerRun {  // bookkeeping of the last forward, for dgr_net_layer_stats /
   DgrConvLaunch launch;   // the exact launch of phase 1
   DgrSplitRows split_in, split_out;   // wide-layer kernel: the input as split rows; what the reduction also writes
   int out_relu = 0;
+  bool split_only = false;
   bool small_cin = false;  // conv1 ran through the output-stationary kernel instead
   const int32_t *fused_pairs = nullptr;  // conv1 fused with its neighbour search: device pair counter
   bool os = false;                       // ran through the output-stationary kernel
@@ -312,6 +313,7 @@ struct Tensor {
   int ld;
   int relu;  // consumers must apply ReLU when reading
   DgrSplitRows split;   // set for tensors a wide layer gathers: written by the tensor's producer (ReLU applied)
+  bool split_only = false;   // ... and nobody reads the f32 rows (a block's middle tensor): they are not written
 };
 
 struct Fwd {
@@ -320,6 +322,7 @@ struct Fwd {
   hipStream_t stream;
   DgrMapSet ms;
   bool prof;
+  bool l2_next = false;   // the next identity-map conv writes unit-norm rows (the `final` conv of a normalising net)
 
   float *ybuf = nullptr;  // per-pair product rows, sized for the largest layer of this forward
 
@@ -351,6 +354,8 @@ struct Fwd {
       a.tile_desc = nullptr;
       a.n_rows_dev = cout_map.n_dev;
       a.tile_bound = dgr_ceil_div(cout_map.n_cap, DGR_TILE_M);
+      a.l2_normalize = l2_next ? 1 : 0;
+      l2_next = false;
     }
     hipEvent_t e0 = nullptr, em = nullptr, e1 = nullptr;
     if (prof) {
@@ -421,7 +426,7 @@ struct Fwd {
     DGR_REQUIRE(!out.split.planes || (km && !small_cin), "layer %s: only a reduction can write split rows", L.name.c_str());
     if (km && !small_cin)
       DGR_CHECK(dgr_reduce_rows(ybuf, L.cout, swapped ? km->in_ptr : km->out_ptr, swapped ? km->in_pos : km->out_pos,
-                                cout_map.n_dev, cout_map.n_cap, out.ptr, out.ld, L.shift, res ? res->ptr : nullptr,
+                                cout_map.n_dev, cout_map.n_cap, out.split_only ? nullptr : out.ptr, out.ld, L.shift, res ? res->ptr : nullptr,
                                 res ? res->ld : 0, res ? res->relu : 0, stream, out.split.planes ? &out.split : nullptr,
                                 out.relu));
     if (prof) {
@@ -435,6 +440,7 @@ struct Fwd {
     r.split_in = wide ? in.split : DgrSplitRows();
     r.split_out = out.split;
     r.out_relu = out.relu;
+    r.split_only = out.split_only;
     r.has_reduce = km != nullptr;
     r.small_cin = small_cin;
     if (km) r.km = *km;
@@ -492,7 +498,10 @@ int dgr_resunet_forward_impl(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, 
   float *u2 = buf(n2, 64), *v2 = buf(n2, 64);
   float *u1 = buf(n1, 64), *v1 = buf(n1, 64);
   float *h = buf(n1, 64);
-  float *fin = net->normalize ? buf(n1, net->cout) : out;
+  // unit-norm output features (model/resunet.py:643-647): fused into the `final` conv's epilogue when a row's channels
+  // fit one 32-channel block (every FCGF checkpoint of the reference: 16 or 32), else a pass of its own
+  const bool fuse_l2 = net->normalize && net->cout <= 32;
+  float *fin = (net->normalize && !fuse_l2) ? buf(n1, net->cout) : out;
   if (!t1 || !y1 || !cat1 || !t2 || !y2 || !cat2 || !t4 || !y4 || !cat4 || !t8 || !y8 || !s8 || !u4 ||
       !v4 || !u2 || !v2 || !u1 || !v1 || !h || !fin)
     return DGR_ENOMEM;
@@ -507,12 +516,15 @@ int dgr_resunet_forward_impl(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, 
   const Tensor S4T{cat4, 256, 1};
   // tensors that a wide layer (conv_wide.hip) gathers are also written as split rows by their producer
   {
-    struct { Tensor *t; int consumer, channels; int64_t rows; } sp[] = {
-        {&S2, 6, 64, n2}, {&T4, 7, 128, n4}, {&Y4, 8, 128, n4}, {&S4, 9, 128, n4}, {&T8, 10, 256, n8},
-        {&Y8, 11, 256, n8}, {&S8, 12, 256, n8}, {&U4, 13, 128, n4}, {&V4, 14, 128, n4}};
+    // (middle: the tensor between the two convs of a residual block -- its only reader is the block's second conv)
+    struct { Tensor *t; int consumer, channels; int64_t rows; bool middle; } sp[] = {
+        {&S2, 6, 64, n2, false}, {&T4, 7, 128, n4, false}, {&Y4, 8, 128, n4, true}, {&S4, 9, 128, n4, false},
+        {&T8, 10, 256, n8, false}, {&Y8, 11, 256, n8, true}, {&S8, 12, 256, n8, false}, {&U4, 13, 128, n4, false},
+        {&V4, 14, 128, n4, true}};
     for (auto &e : sp) {
       if (!net->layers[e.consumer].wb) continue;
       e.t->split.channels = e.channels;
+      e.t->split_only = e.middle;
       DGR_ALLOC(e.t->split.planes, A, unsigned char, (size_t)e.rows * 4 * e.channels);
       DGR_ALLOC(e.t->split.scale, A, float, e.rows);
     }
@@ -575,8 +587,9 @@ int dgr_resunet_forward_impl(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, 
   DGR_CHECK(f.conv(li++, V1, &ms.same[0], false, 0, 0, S1T, &U1));
   const Tensor CAT1{cat1, 96, 1};
   DGR_CHECK(f.conv(li++, CAT1, nullptr, false, 0, 0, H, nullptr));      // conv1_tr (k=1), ReLU pending
-  DGR_CHECK(f.conv(li++, H, nullptr, false, 0, 0, FIN, nullptr));       // final (k=1) + bias
-  if (net->normalize)
+  f.l2_next = fuse_l2;
+  DGR_CHECK(f.conv(li++, H, nullptr, false, 0, 0, FIN, nullptr));       // final (k=1) + bias (+ normalisation)
+  if (net->normalize && !fuse_l2)
     DGR_CHECK(dgr_l2_normalize_rows(fin, net->cout, out, net->cout, net->cout, 0, ms.cm[0].n_dev, n1, stream));
 
   auto &I = net->inter;
@@ -805,8 +818,8 @@ extern "C" int dgr_net_rerun_layer(dgr_ctx *ctx, dgr_net *net, int layer, int re
       DGR_CHECK(dgr_conv_launch(r.launch, ctx->num_cus, nullptr));
     DGR_HIP_CHECK(hipEventRecord(e1, nullptr));
     if (r.has_reduce && !r.small_cin && !r.os)
-      DGR_CHECK(dgr_reduce_rows(r.launch.y, L.cout, r.red_ptr, r.red_pos, r.n_out, r.n_out_cap, r.launch.out,
-                                r.launch.out_ld, L.shift, r.res, r.res_ld, r.res_relu, nullptr,
+      DGR_CHECK(dgr_reduce_rows(r.launch.y, L.cout, r.red_ptr, r.red_pos, r.n_out, r.n_out_cap,
+                                r.split_only ? nullptr : r.launch.out, r.launch.out_ld, L.shift, r.res, r.res_ld, r.res_relu, nullptr,
                                 r.split_out.planes ? &r.split_out : nullptr, r.out_relu));
     DGR_HIP_CHECK(hipEventRecord(e2, nullptr));
     DGR_HIP_CHECK(hipEventSynchronize(e2));

@@ -45,6 +45,17 @@ def test_fcgf_forward_general_input_features():
     _check(3, 3, 16, 3, False, coords, feats, seed=5)
 
 
+@pytest.mark.parametrize('n_out', [16, 32, 64])
+def test_unit_norm_output_features(n_out):
+    """`normalize_feature` (model/resunet.py:643-647): fused into the epilogue of the `final` conv for <= 32 output
+    channels (16: half of the 32-channel block is masked), a pass of its own above."""
+    rng = np.random.default_rng(44)
+    coords = np.concatenate([random_cloud_coords(rng, 1500, 14, 3, batch=b) for b in (0, 1)])
+    feats = np.ones((len(coords), 1), np.float32)
+    net, out, ref = _check(3, 1, n_out, 5, True, coords, feats, seed=9)
+    np.testing.assert_allclose(np.linalg.norm(out, axis=1), 1.0, atol=1e-5)
+
+
 def test_3d_net_on_the_rule_major_path():
     """A 3-D net with more than 8 input channels does not take the fused conv1 / output-stationary route: all its
     layers run the rule-major two-phase kernels over kmap_search<3> / kmap_fill maps (conv.hip, kmap.hip)."""
