@@ -82,14 +82,22 @@ __device__ __forceinline__ int mask_rank(const uint32_t *__restrict__ m, int k) 
   return r + __popc(m[w] & ((1u << (k & 31)) - 1u));
 }
 
+// wpre (optional): pairs of the row in the mask words before word i (a row has at most 160 < 256 pairs: one byte)
 __global__ void mask_count_kernel(const uint32_t *__restrict__ mask, int KW, const int32_t *n_dev, int64_t n_cap,
-                                  int32_t *__restrict__ cnt) {
+                                  int32_t *__restrict__ cnt, unsigned char *__restrict__ wpre = nullptr) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n_cap) return;
   int c = 0;
   if (r < *n_dev)
-    for (int i = 0; i < KW; ++i) c += __popc(mask[r * KW + i]);
+    for (int i = 0; i < KW; ++i) {
+      if (wpre) wpre[r * KW + i] = (unsigned char)min(c, 255);
+      c += __popc(mask[r * KW + i]);
+    }
   cnt[r] = c;
+}
+// rank of offset k among the row's set offsets, with the per-word prefix of the row
+__device__ __forceinline__ int mask_rank_pre(const uint32_t *__restrict__ m, const unsigned char *__restrict__ pre, int k) {
+  return pre[k >> 5] + __popc(m[k >> 5] & ((1u << (k & 31)) - 1u));
 }
 
 // =========================== D = 6: bit-matrix pipeline =====================================
@@ -98,11 +106,52 @@ __global__ void mask_count_kernel(const uint32_t *__restrict__ mask, int KW, con
 //   bits     search (pruned or generic) sets mask_out[o][k] (and mask_in[i][k] for maps that are
 //            also used swapped).  Same-stride maps are symmetric -- (o, k) -> i  <=>  (i, K-1-k) -> o
 //            -- so only offsets below the centre are searched and every hit sets both bits.
-//   colmask  transposes the bit matrix per 64-row group (one ballot per offset) and counts the
-//            pairs of every (offset, 256-row block) cell -> exclusive scan = cell bases.
-//   place    one thread per non-zero mask word: re-probes the (few) set offsets, ranks each pair
-//            inside its row (CSR slot) and inside its cell (rule-major position) with popcounts.
+//            Every hit is also APPENDED as a record (offset, row, input row) to a hit list -- in no particular
+//            order: one wave-aggregated atomic per call and wave (round 3; the records replace the re-probe of every
+//            set bit in the placing pass, which cost 0.64 of the 2.44 ms of a batch's seven maps).
+//   colmask  transposes the bit matrix per 64-row group (one ballot per offset), counts the pairs of every
+//            (offset, 256-row block) cell -> exclusive scan = cell bases -- and of every row (CSR row pointers).
+//   place    one thread per hit record: ranks the pair inside its row (CSR slot) and inside its cell (rule-major
+//            position) with popcounts.  The positions depend on the bit matrix only, not on the order of the list.
 // Result identical to the generic path: pairs sorted by (k, out), CSR slots in ascending k.
+
+// hit record: offset k (10 bits) | output row (27 bits) | input row (27 bits)
+__device__ __forceinline__ unsigned long long hit_pack(int k, int64_t o, int64_t in) {
+  return ((unsigned long long)k << 54) | ((unsigned long long)o << 27) | (unsigned long long)in;
+}
+// The hit list needs no global counter (one that is bumped per hit, per wave-call or even per 128-slot chunk serialises
+// on its one address at ~40 ns per atomic: measured 13 / 5.3 ms instead of 2.4 ms per batch): every wave of the search
+// owns a fixed REGION of the list, sized for the most records its 64 threads can produce, hands slots out from a
+// cursor in LDS and leaves its record count in wave_count[wave id].  The regions are address space, not traffic: only
+// the used prefix of a region is ever touched.
+struct HitList {
+  unsigned long long *recs;   // [waves][region]
+  int32_t *wave_count;        // [waves]
+  int region;                 // records per wave
+};
+__device__ __forceinline__ int hit_wave_id() {
+  return (int)((blockIdx.y * gridDim.x + blockIdx.x) * (KM_THREADS / 64) + (threadIdx.x >> 6));
+}
+__device__ __forceinline__ void hit_begin(volatile int *cur) {
+  if ((threadIdx.x & 63) == 0) cur[threadIdx.x >> 6] = 0;
+}
+// First of `n` (1 or 2) consecutive slots for this lane.  Called from divergent code by the lanes that found a pair:
+// the active lanes of the wave share one cursor update.
+__device__ __forceinline__ int64_t hit_slots(int n, const HitList &h, volatile int *cur) {
+  const unsigned long long act = __ballot(1), two = __ballot(n == 2);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  int base = 0;
+  if (lane == __ffsll((long long)act) - 1) {
+    base = cur[w];
+    cur[w] = base + __popcll(act) + __popcll(two);
+  }
+  base = __builtin_amdgcn_readfirstlane(base);   // the first ACTIVE lane is the one that moved the cursor
+  return (int64_t)hit_wave_id() * h.region + base + __popcll(act & below) + __popcll(two & below);
+}
+__device__ __forceinline__ void hit_end(const HitList &h, volatile int *cur) {
+  if ((threadIdx.x & 63) == 0) h.wave_count[hit_wave_id()] = cur[threadIdx.x >> 6];
+}
 
 // generic search, bits only: grid = (row blocks, ceil(offsets to probe / 4)); a thread probes four consecutive
 // offsets of its row with the batched look-up (two memory latencies for the four probes)
@@ -111,14 +160,19 @@ template <int D>
 __global__ void __launch_bounds__(KM_THREADS)
     kmap_bits(const int32_t *__restrict__ out_coords, const int32_t *n_out_dev,
               const int32_t *__restrict__ in_coords, const int32_t *__restrict__ in_table, uint32_t in_mask,
-              int ks, int ts_in, int K, int KW, int n_probe, int symmetric, uint32_t *mask_out, uint32_t *mask_in) {
+              int ks, int ts_in, int K, int KW, int n_probe, int symmetric, uint32_t *mask_out, uint32_t *mask_in,
+              HitList hl) {
   constexpr int NC = D + 1;
+  __shared__ int hit_cur[KM_THREADS / 64];
+  hit_begin(hit_cur);
   const int k0 = blockIdx.y * KM_PROBES;
   const int64_t o = (int64_t)blockIdx.x * KM_THREADS + threadIdx.x;
-  if (o >= *n_out_dev) return;
+  if (o < *n_out_dev) {
   if (symmetric && k0 == 0) {  // the centre offset always maps a row onto itself
     const int c = K >> 1;
     atomicOr(&mask_out[o * KW + (c >> 5)], 1u << (c & 31));
+    const int64_t s = hit_slots(1, hl, hit_cur);
+    hl.recs[s] = hit_pack(c, o, o);
   }
   int32_t base[NC];
 #pragma unroll
@@ -139,13 +193,19 @@ __global__ void __launch_bounds__(KM_THREADS)
     const int k = k0 + u;
     if (k >= n_probe || hit[u] < 0) continue;
     atomicOr(&mask_out[o * KW + (k >> 5)], 1u << (k & 31));
+    const int km = K - 1 - k;
     if (symmetric) {
-      const int km = K - 1 - k;
       atomicOr(&mask_out[(int64_t)hit[u] * KW + (km >> 5)], 1u << (km & 31));
     } else if (mask_in) {
       atomicOr(&mask_in[(int64_t)hit[u] * KW + (k >> 5)], 1u << (k & 31));
     }
+    const int n = symmetric ? 2 : 1;   // (k < K / 2 here: the mirror is another pair)
+    const int64_t s = hit_slots(n, hl, hit_cur);
+    hl.recs[s] = hit_pack(k, o, hit[u]);
+    if (n == 2) hl.recs[s + 1] = hit_pack(km, hit[u], o);
   }
+  }
+  hit_end(hl, hit_cur);
 }
 
 // pruned search, bits only: one thread per (output row, first-half offset).  A 6-D neighbour
@@ -155,22 +215,26 @@ __global__ void __launch_bounds__(KM_THREADS)
 __global__ void __launch_bounds__(KM_THREADS)
     kmap_bits_pruned6(const int32_t *__restrict__ out_coords, const int32_t *n_out_dev,
                       const int32_t *__restrict__ in_coords, DgrHalfBuckets hb, int ts_in, int KW,
-                      int symmetric, uint32_t *mask_out, uint32_t *mask_in) {
+                      int symmetric, uint32_t *mask_out, uint32_t *mask_in, HitList hl) {
+  __shared__ int hit_cur[KM_THREADS / 64];
+  hit_begin(hit_cur);
   const int NJ = symmetric ? 14 : 27;
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t o = t / NJ;
   const int ja = (int)(t - o * NJ);
-  if (o >= *n_out_dev) return;
+  int b = -1;
   const int32_t *co = out_coords + o * 7;
-  int32_t q[4];
-  q[0] = co[0];
-  q[1] = co[1] + ((ja % 3) - 1) * ts_in;
-  q[2] = co[2] + (((ja / 3) % 3) - 1) * ts_in;
-  q[3] = co[3] + ((ja / 9) - 1) * ts_in;
-  const int b = dgr_lookup<4>(hb.table, hb.mask, hb.bkeys, q);
-  if (b < 0) return;
-  const int c4 = co[4], c5 = co[5], c6 = co[6];
-  const int beg = hb.start[b], end = hb.start[b + 1];
+  if (o < *n_out_dev) {
+    int32_t q[4];
+    q[0] = co[0];
+    q[1] = co[1] + ((ja % 3) - 1) * ts_in;
+    q[2] = co[2] + (((ja / 3) % 3) - 1) * ts_in;
+    q[3] = co[3] + ((ja / 9) - 1) * ts_in;
+    b = dgr_lookup<4>(hb.table, hb.mask, hb.bkeys, q);
+  }
+  // (no early return: every wave closes its last chunk of the hit list at the end)
+  const int c4 = b >= 0 ? co[4] : 0, c5 = b >= 0 ? co[5] : 0, c6 = b >= 0 ? co[6] : 0;
+  const int beg = b >= 0 ? hb.start[b] : 0, end = b >= 0 ? hb.start[b + 1] : 0;
   // four bucket rows per trip: their indices, then their second halves, are fetched together (a
   // one-row-at-a-time loop pays two dependent L2 latencies per candidate)
   for (int p0 = beg; p0 < end; p0 += 4) {
@@ -192,32 +256,41 @@ __global__ void __launch_bounds__(KM_THREADS)
         const int k = ja + 27 * ((d4 / ts_in + 1) + 3 * (d5 / ts_in + 1) + 9 * (d6 / ts_in + 1));
         if (symmetric && ja == 13 && k > 364) continue;  // ja == 13 mirrors onto itself: upper half found from the other row
         atomicOr(&mask_out[o * KW + (k >> 5)], 1u << (k & 31));
+        const int km = 728 - k;
         if (symmetric) {
-          const int km = 728 - k;
           if (km != k) atomicOr(&mask_out[(int64_t)r[u] * KW + (km >> 5)], 1u << (km & 31));
         } else if (mask_in) {
           atomicOr(&mask_in[(int64_t)r[u] * KW + (k >> 5)], 1u << (k & 31));
         }
+        const int n = (symmetric && km != k) ? 2 : 1;
+        const int64_t s = hit_slots(n, hl, hit_cur);
+        hl.recs[s] = hit_pack(k, o, r[u]);
+        if (n == 2) hl.recs[s + 1] = hit_pack(km, r[u], o);
       }
     }
   }
+  hit_end(hl, hit_cur);
 }
 
 // transposed bit matrix: cell[g * K + k] = {rows of 64-row group g that have offset k (one ballot, 2 words),
 // rule-major position of the group's first pair of that offset, 0}; counts[k * RB + rb] = pairs of the
-// (offset, 256-row block) cell.  The position is written in two steps: the pairs of the earlier groups of the
-// same block here, the cell base (exclusive scan of counts) by kmap_cellbase_kernel.
+// (offset, 256-row block) cell.  A pair's position = cell base (exclusive scan of counts) + the pairs of the earlier
+// groups of the same block (here) + its rank inside the group's ballot (kmap_place_hits).
 constexpr int KM_KMAX = 736;
 __global__ void __launch_bounds__(KM_THREADS)
     kmap_colmask(const uint32_t *__restrict__ mask_out, const int32_t *n_out_dev, int K, int KW, int RB,
-                 int4 *__restrict__ cell, int32_t *__restrict__ counts) {
+                 int4 *__restrict__ cell, int32_t *__restrict__ counts, int32_t *__restrict__ row_cnt,
+                 unsigned char *__restrict__ wpre) {
   __shared__ unsigned long long bal[KM_THREADS / 64][KM_KMAX];
   const int rb = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n_out = *n_out_dev;
   const int64_t o = (int64_t)rb * KM_THREADS + threadIdx.x;
+  int row_pairs = 0;
   for (int w = 0; w < KW; ++w) {
     const uint32_t word = (o < n_out) ? mask_out[o * KW + w] : 0u;
+    if (o < n_out) wpre[o * KW + w] = (unsigned char)min(row_pairs, 255);
+    row_pairs += __popc(word);
     unsigned long long mine = 0;
 #pragma unroll
     for (int b = 0; b < 32; ++b) {
@@ -226,6 +299,7 @@ __global__ void __launch_bounds__(KM_THREADS)
     }
     if (lane < 32 && 32 * w + lane < KM_KMAX) bal[wave][32 * w + lane] = mine;
   }
+  if (o < n_out) row_cnt[o] = row_pairs;   // (rows beyond the count: cleared together with the bit matrix)
   __syncthreads();
   for (int k = threadIdx.x; k < K; k += KM_THREADS) {
     int run = 0;
@@ -239,65 +313,38 @@ __global__ void __launch_bounds__(KM_THREADS)
   }
 }
 
-__global__ void kmap_cellbase_kernel(int4 *__restrict__ cell, const int32_t *__restrict__ base, int K, int RB, int64_t n_cells) {
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= n_cells) return;
-  const int64_t g = c / K;
-  const int k = (int)(c - g * K);
-  cell[c].z += base[(int64_t)k * RB + (g >> 2)];
-}
-
-// one thread per (row, mask word): places the pairs of the set offsets.  pair_out / pair_k may be NULL (maps
-// whose consumers never read them): two random stores less per pair.
+// one wave per region of the hit list, one lane per record: places the pair.  pair_out / pair_k may be NULL (maps whose
+// consumers never read them): two random stores less per pair.
 __global__ void __launch_bounds__(KM_THREADS)
-    kmap_place6(const int32_t *__restrict__ out_coords, const int32_t *n_out_dev,
-                const int32_t *__restrict__ in_coords, const int32_t *__restrict__ in_table, uint32_t in_mask,
-                int ts_in, int K, int KW, const uint32_t *__restrict__ mask_out,
-                const int32_t *__restrict__ out_ptr, const int4 *__restrict__ cell,
-                int32_t *__restrict__ pair_in, int32_t *__restrict__ pair_out, uint16_t *__restrict__ pair_k,
-                int32_t *__restrict__ out_pos, int64_t pair_cap, int32_t *overflow,
-                const uint32_t *__restrict__ mask_in, const int32_t *__restrict__ in_ptr,
-                int32_t *__restrict__ in_pos) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t o = t / KW;
-  const int w = (int)(t - o * KW);
-  if (o >= *n_out_dev) return;
-  const uint32_t *mrow = mask_out + o * KW;
-  uint32_t m = mrow[w];
-  if (m == 0u) return;
-  int64_t slot = out_ptr[o];
-  for (int i = 0; i < w; ++i) slot += __popc(mrow[i]);
-  int32_t co[7];
-#pragma unroll
-  for (int d = 0; d < 7; ++d) co[d] = out_coords[o * 7 + d];
-  const int64_t g = o >> 6;
-  const unsigned long long below = (1ull << (o & 63)) - 1ull;
-  while (m) {
-    const int b = __ffs(m) - 1;
-    m &= m - 1u;
-    const int k = 32 * w + b;
-    int32_t q[7];
-    q[0] = co[0];
-    int kk = k;
-#pragma unroll
-    for (int d = 0; d < 6; ++d) {
-      q[1 + d] = co[1 + d] + ((kk % 3) - 1) * ts_in;
-      kk /= 3;
+    kmap_place_hits(HitList h, int n_waves, int K, int KW, int RB, const uint32_t *__restrict__ mask_out,
+                    const int32_t *__restrict__ out_ptr, const int4 *__restrict__ cell, const int32_t *__restrict__ base,
+                    int32_t *__restrict__ pair_in, int32_t *__restrict__ pair_out, uint16_t *__restrict__ pair_k,
+                    int32_t *__restrict__ out_pos, int64_t pair_cap, int32_t *overflow,
+                    const uint32_t *__restrict__ mask_in, const int32_t *__restrict__ in_ptr,
+                    int32_t *__restrict__ in_pos, const unsigned char *__restrict__ wpre_out,
+                    const unsigned char *__restrict__ wpre_in) {
+  const int lane = threadIdx.x & 63;
+  for (int r = blockIdx.x * (KM_THREADS / 64) + (threadIdx.x >> 6); r < n_waves; r += gridDim.x * (KM_THREADS / 64)) {
+    const int n = h.wave_count[r];
+    for (int e = lane; e < n; e += 64) {
+      const unsigned long long rec = h.recs[(int64_t)r * h.region + e];
+      const int k = (int)(rec >> 54);
+      const int64_t o = (int64_t)((rec >> 27) & 0x7ffffffull), in = (int64_t)(rec & 0x7ffffffull);
+      const int64_t slot = (int64_t)out_ptr[o] + mask_rank_pre(mask_out + o * KW, wpre_out + o * KW, k);
+      const int64_t g = o >> 6;
+      const int4 c = cell[g * K + k];   // ONE 16-byte read: column ballot + pairs of the block's earlier groups
+      const unsigned long long cm = ((unsigned long long)(uint32_t)c.y << 32) | (uint32_t)c.x;
+      const int64_t pos = (int64_t)base[(int64_t)k * RB + (g >> 2)] + c.z + __popcll(cm & ((1ull << (o & 63)) - 1ull));
+      if (pos < pair_cap && slot < pair_cap) {
+        pair_in[pos] = (int32_t)in;
+        if (pair_out) pair_out[pos] = (int32_t)o;
+        if (pair_k) pair_k[pos] = (uint16_t)k;
+        out_pos[slot] = (int32_t)pos;
+        if (mask_in) in_pos[in_ptr[in] + mask_rank_pre(mask_in + in * KW, wpre_in + in * KW, k)] = (int32_t)pos;
+      } else {
+        *overflow = 2;
+      }
     }
-    const int in = dgr_lookup<7>(in_table, in_mask, in_coords, q);
-    const int4 c = cell[g * K + k];   // ONE 16-byte read: column ballot + position of the group's first pair
-    const unsigned long long cm = ((unsigned long long)(uint32_t)c.y << 32) | (uint32_t)c.x;
-    const int64_t pos = (int64_t)c.z + __popcll(cm & below);
-    if (pos < pair_cap && slot < pair_cap && in >= 0) {
-      pair_in[pos] = in;
-      if (pair_out) pair_out[pos] = (int32_t)o;
-      if (pair_k) pair_k[pos] = (uint16_t)k;
-      out_pos[slot] = (int32_t)pos;
-      if (mask_in) in_pos[in_ptr[in] + mask_rank(mask_in + (int64_t)in * KW, k)] = (int32_t)pos;
-    } else {
-      *overflow = 2;
-    }
-    ++slot;
   }
 }
 
@@ -430,38 +477,66 @@ static int build_kernel_map_t(DgrArena &arena, const DgrCoordMap &in, const DgrC
   DGR_ALLOC(counts, arena, int32_t, (int64_t)K * RB);
   DGR_ALLOC(base, arena, int32_t, (int64_t)K * RB);
   DGR_ALLOC(total, arena, int32_t, 1);
-  // the two bit matrices (out rows; in rows for maps used swapped) come out of ONE allocation: one clear
+  // the two bit matrices (out rows; in rows for maps used swapped) and the row counts of the 6-D path come out of
+  // ONE allocation: one clear
   uint32_t *mask_out, *mask_in = nullptr;
   int32_t *cnt_out, *cnt_in = nullptr;
   {
     const size_t w_out = (size_t)(n_cap + 1) * KW, w_in = need_in_csr ? (size_t)(n_in_cap + 1) * KW : 0;
-    DGR_ALLOC(mask_out, arena, uint32_t, w_out + w_in);
+    const size_t w_cnt = D == 6 ? (size_t)(n_cap + 1) : 0;
+    DGR_ALLOC(mask_out, arena, uint32_t, w_out + w_in + w_cnt);
     if (need_in_csr) mask_in = mask_out + w_out;
-    DGR_HIP_CHECK(hipMemsetAsync(mask_out, 0, (w_out + w_in) * sizeof(uint32_t), stream));
+    DGR_HIP_CHECK(hipMemsetAsync(mask_out, 0, (w_out + w_in + w_cnt) * sizeof(uint32_t), stream));
+    if (D == 6) {
+      cnt_out = reinterpret_cast<int32_t *>(mask_out + w_out + w_in);
+    } else {
+      DGR_ALLOC(cnt_out, arena, int32_t, n_cap + 1);
+    }
   }
-  DGR_ALLOC(cnt_out, arena, int32_t, n_cap + 1);
   if (need_in_csr) DGR_ALLOC(cnt_in, arena, int32_t, n_in_cap + 1);
   int32_t *hits = nullptr;
   int4 *cell = nullptr;
   int64_t n_cells = 0;
+  unsigned long long *hit_list = nullptr;
+  int32_t *hit_wave_count = nullptr;
+  unsigned char *wpre_out = nullptr, *wpre_in = nullptr;
+  int64_t hit_waves = 0;
+  int hit_region = 0;
   if constexpr (D == 6) {
     DGR_REQUIRE(ks == 3, "6-D kernel maps support kernel size 3 only (got %d)", ks);
+    DGR_REQUIRE(n_cap < (1ll << 27) && n_in_cap < (1ll << 27), "6-D kernel maps: more than 2^27 rows");
     n_cells = (int64_t)RB * (KM_THREADS / 64) * K;
     DGR_ALLOC(cell, arena, int4, n_cells);
+    // hit list: one region per wave of the search, sized for the most records 64 of its threads can produce
+    // (pruned: 27 second halves per (row, first half), generic: KM_PROBES probes per thread + the centre record; twice
+    // that for symmetric maps, where a hit is recorded with its mirror)
+    const int symmetric0 = (in.coords == out.coords && !need_in_csr) ? 1 : 0;
+    const bool pruned = in_buckets && in_buckets->built && ks == 3;
+    const int64_t search_blocks = pruned ? dgr_ceil_div(n_cap * (symmetric0 ? 14 : 27), KM_THREADS)
+                                         : (int64_t)RB * dgr_ceil_div(symmetric0 ? K / 2 : K, KM_PROBES);
+    hit_waves = search_blocks * (KM_THREADS / 64);
+    hit_region = 64 * ((pruned ? 27 : KM_PROBES) * (symmetric0 ? 2 : 1) + (pruned ? 0 : 1));
+    DGR_REQUIRE(hit_waves < (1ll << 31), "6-D kernel map: too many search waves");
+    DGR_ALLOC(hit_list, arena, unsigned long long, hit_waves * hit_region);
+    DGR_ALLOC(hit_wave_count, arena, int32_t, hit_waves);
+    DGR_ALLOC(wpre_out, arena, unsigned char, (n_cap + 1) * KW);
+    if (need_in_csr) DGR_ALLOC(wpre_in, arena, unsigned char, (n_in_cap + 1) * KW);
     // same-stride maps (in and out are the SAME coordinate set) are symmetric: search half the offsets
     const int symmetric = (in.coords == out.coords && !need_in_csr) ? 1 : 0;
     if (in_buckets && in_buckets->built && ks == 3) {
       const int64_t threads = n_cap * (symmetric ? 14 : 27);
       kmap_bits_pruned6<<<(int)dgr_ceil_div(threads, KM_THREADS), KM_THREADS, 0, stream>>>(
-          out.coords, out.n_dev, in.coords, *in_buckets, in.ts, KW, symmetric, mask_out, mask_in);
+          out.coords, out.n_dev, in.coords, *in_buckets, in.ts, KW, symmetric, mask_out, mask_in,
+          HitList{hit_list, hit_wave_count, hit_region});
     } else {
       const int n_probe = symmetric ? K / 2 : K;
       dim3 grid(RB, (n_probe + KM_PROBES - 1) / KM_PROBES);
       kmap_bits<D><<<grid, KM_THREADS, 0, stream>>>(out.coords, out.n_dev, in.coords, in.table, in.table_mask, ks,
-                                                    in.ts, K, KW, n_probe, symmetric, mask_out, mask_in);
+                                                    in.ts, K, KW, n_probe, symmetric, mask_out, mask_in,
+                                                    HitList{hit_list, hit_wave_count, hit_region});
     }
     DGR_LAUNCH_CHECK();
-    kmap_colmask<<<RB, KM_THREADS, 0, stream>>>(mask_out, out.n_dev, K, KW, RB, cell, counts);
+    kmap_colmask<<<RB, KM_THREADS, 0, stream>>>(mask_out, out.n_dev, K, KW, RB, cell, counts, cnt_out, wpre_out);
   } else {
     DGR_ALLOC(hits, arena, int32_t, (int64_t)K * n_cap);
     dim3 grid(RB, K);
@@ -470,10 +545,12 @@ static int build_kernel_map_t(DgrArena &arena, const DgrCoordMap &in, const DgrC
                                                     mask_out, mask_in);
   }
   DGR_LAUNCH_CHECK();
-  // per-row pair counts -> CSR row pointers (out rows; in rows for maps used swapped)
-  mask_count_kernel<<<(int)dgr_ceil_div(n_cap + 1, 256), 256, 0, stream>>>(mask_out, KW, out.n_dev, n_cap + 1, cnt_out);
+  // per-row pair counts -> CSR row pointers (out rows -- 6-D: counted by kmap_colmask; in rows for maps used swapped)
+  if (D != 6)
+    mask_count_kernel<<<(int)dgr_ceil_div(n_cap + 1, 256), 256, 0, stream>>>(mask_out, KW, out.n_dev, n_cap + 1, cnt_out);
   if (need_in_csr)
-    mask_count_kernel<<<(int)dgr_ceil_div(n_in_cap + 1, 256), 256, 0, stream>>>(mask_in, KW, in.n_dev, n_in_cap + 1, cnt_in);
+    mask_count_kernel<<<(int)dgr_ceil_div(n_in_cap + 1, 256), 256, 0, stream>>>(mask_in, KW, in.n_dev, n_in_cap + 1, cnt_in,
+                                                                               wpre_in);
   {
     // row pointers of the out-major CSR (and of the in-major one for maps used swapped) + the cell bases: one
     // multi-array scan = three launches for all of them
@@ -486,11 +563,10 @@ static int build_kernel_map_t(DgrArena &arena, const DgrCoordMap &in, const DgrC
   tile_desc_kernel<<<(int)dgr_ceil_div(km->tile_cap, 256), 256, 0, stream>>>(km->tile_ptr, km->rule_ptr, K,
                                                                             km->tile_desc, km->tile_cap);
   if constexpr (D == 6) {
-    kmap_cellbase_kernel<<<(int)dgr_ceil_div(n_cells, 256), 256, 0, stream>>>(cell, base, K, RB, n_cells);
-    const int64_t threads = n_cap * KW;
-    kmap_place6<<<(int)dgr_ceil_div(threads, KM_THREADS), KM_THREADS, 0, stream>>>(
-        out.coords, out.n_dev, in.coords, in.table, in.table_mask, in.ts, K, KW, mask_out, km->out_ptr, cell,
-        km->pair_in, km->pair_out, km->pair_k, km->out_pos, km->pair_cap, overflow, mask_in, km->in_ptr, km->in_pos);
+    const int blocks = (int)std::min<int64_t>(dgr_ceil_div(hit_waves, KM_THREADS / 64), 16384);
+    kmap_place_hits<<<blocks, KM_THREADS, 0, stream>>>(HitList{hit_list, hit_wave_count, hit_region}, (int)hit_waves, K, KW, RB, mask_out, km->out_ptr,
+                                                       cell, base, km->pair_in, km->pair_out, km->pair_k, km->out_pos,
+                                                       km->pair_cap, overflow, mask_in, km->in_ptr, km->in_pos, wpre_out, wpre_in);
   } else {
     dim3 fill_grid(RB, (K + KM_KGROUP - 1) / KM_KGROUP);
     kmap_fill<<<fill_grid, KM_THREADS, 0, stream>>>(out.n_dev, RB, K, n_cap, hits, counts, base, km->pair_in,
