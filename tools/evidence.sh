@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round evidence bundle, run on the GPU box from the repo root: bench lines (configs[1], [2], [4], the 512-pair
 # configs[3] shape on one GPU), rocprofv3 kernel stats and the PMC passes of the dominant kernel.  Everything lands
-# in gpurun_out/final/ (copy what should be judged into profiles/).   bash tools/evidence.sh [quick]
+# in gpurun_out/final/ (copy what should be judged into profiles/).   bash tools/evidence.sh [quick|nopmc]
+# (nopmc: everything but the counter passes -- for a refresh after changes that did not touch the profiled kernels)
 R=$PWD; O=$R/gpurun_out/final; mkdir -p $O; rm -rf $O/*
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py"
@@ -29,6 +30,7 @@ timeout 300 rocprofv3 --kernel-trace -d $O/kt1 -o kt -- $B --streams 1 --pairs-p
 python $R/tools/rocpd_summary.py $O/kt1/kt_results.db $O/kernel_stats_s1_b4.csv --trace sparse_conv $O/conv_trace_s1_b4.csv
 timeout 300 rocprofv3 --kernel-trace -d $O/kt3 -o kt -- $B --no-parity --steps 5 > $O/kt3.log 2>&1
 python $R/tools/rocpd_summary.py $O/kt3/kt_results.db $O/kernel_stats_s3_b4.csv
+if [ "$1" = nopmc ]; then rm -rf $O/kt1 $O/kt3; ls -la $O; tail -c 400 $O/bench_c1_default.json; exit 0; fi
 # PMC: one pass per counter set, never combined with other trace domains
 K=$(python -c "import json;print(json.loads(open('$O/bench_c1_s1_b4.json').read().strip().splitlines()[-1])['roofline']['kernel'])")
 i=0; DBS=""
