@@ -82,21 +82,21 @@ __device__ __forceinline__ int mask_rank(const uint32_t *__restrict__ m, int k) 
   return r + __popc(m[w] & ((1u << (k & 31)) - 1u));
 }
 
-// wpre (optional): pairs of the row in the mask words before word i (a row has at most 160 < 256 pairs: one byte)
+// wpre (optional): pairs of the row in the mask words before word i (a row can have all K = 729 offsets: 16 bits)
 __global__ void mask_count_kernel(const uint32_t *__restrict__ mask, int KW, const int32_t *n_dev, int64_t n_cap,
-                                  int32_t *__restrict__ cnt, unsigned char *__restrict__ wpre = nullptr) {
+                                  int32_t *__restrict__ cnt, unsigned short *__restrict__ wpre = nullptr) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n_cap) return;
   int c = 0;
   if (r < *n_dev)
     for (int i = 0; i < KW; ++i) {
-      if (wpre) wpre[r * KW + i] = (unsigned char)min(c, 255);
+      if (wpre) wpre[r * KW + i] = (unsigned short)c;
       c += __popc(mask[r * KW + i]);
     }
   cnt[r] = c;
 }
 // rank of offset k among the row's set offsets, with the per-word prefix of the row
-__device__ __forceinline__ int mask_rank_pre(const uint32_t *__restrict__ m, const unsigned char *__restrict__ pre, int k) {
+__device__ __forceinline__ int mask_rank_pre(const uint32_t *__restrict__ m, const unsigned short *__restrict__ pre, int k) {
   return pre[k >> 5] + __popc(m[k >> 5] & ((1u << (k & 31)) - 1u));
 }
 
@@ -280,7 +280,7 @@ constexpr int KM_KMAX = 736;
 __global__ void __launch_bounds__(KM_THREADS)
     kmap_colmask(const uint32_t *__restrict__ mask_out, const int32_t *n_out_dev, int K, int KW, int RB,
                  int4 *__restrict__ cell, int32_t *__restrict__ counts, int32_t *__restrict__ row_cnt,
-                 unsigned char *__restrict__ wpre) {
+                 unsigned short *__restrict__ wpre) {
   __shared__ unsigned long long bal[KM_THREADS / 64][KM_KMAX];
   const int rb = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -289,7 +289,7 @@ __global__ void __launch_bounds__(KM_THREADS)
   int row_pairs = 0;
   for (int w = 0; w < KW; ++w) {
     const uint32_t word = (o < n_out) ? mask_out[o * KW + w] : 0u;
-    if (o < n_out) wpre[o * KW + w] = (unsigned char)min(row_pairs, 255);
+    if (o < n_out) wpre[o * KW + w] = (unsigned short)row_pairs;
     row_pairs += __popc(word);
     unsigned long long mine = 0;
 #pragma unroll
@@ -321,8 +321,8 @@ __global__ void __launch_bounds__(KM_THREADS)
                     int32_t *__restrict__ pair_in, int32_t *__restrict__ pair_out, uint16_t *__restrict__ pair_k,
                     int32_t *__restrict__ out_pos, int64_t pair_cap, int32_t *overflow,
                     const uint32_t *__restrict__ mask_in, const int32_t *__restrict__ in_ptr,
-                    int32_t *__restrict__ in_pos, const unsigned char *__restrict__ wpre_out,
-                    const unsigned char *__restrict__ wpre_in) {
+                    int32_t *__restrict__ in_pos, const unsigned short *__restrict__ wpre_out,
+                    const unsigned short *__restrict__ wpre_in) {
   const int lane = threadIdx.x & 63;
   for (int r = blockIdx.x * (KM_THREADS / 64) + (threadIdx.x >> 6); r < n_waves; r += gridDim.x * (KM_THREADS / 64)) {
     const int n = h.wave_count[r];
@@ -499,7 +499,7 @@ static int build_kernel_map_t(DgrArena &arena, const DgrCoordMap &in, const DgrC
   int64_t n_cells = 0;
   unsigned long long *hit_list = nullptr;
   int32_t *hit_wave_count = nullptr;
-  unsigned char *wpre_out = nullptr, *wpre_in = nullptr;
+  unsigned short *wpre_out = nullptr, *wpre_in = nullptr;
   int64_t hit_waves = 0;
   int hit_region = 0;
   if constexpr (D == 6) {
@@ -519,8 +519,8 @@ static int build_kernel_map_t(DgrArena &arena, const DgrCoordMap &in, const DgrC
     DGR_REQUIRE(hit_waves < (1ll << 31), "6-D kernel map: too many search waves");
     DGR_ALLOC(hit_list, arena, unsigned long long, hit_waves * hit_region);
     DGR_ALLOC(hit_wave_count, arena, int32_t, hit_waves);
-    DGR_ALLOC(wpre_out, arena, unsigned char, (n_cap + 1) * KW);
-    if (need_in_csr) DGR_ALLOC(wpre_in, arena, unsigned char, (n_in_cap + 1) * KW);
+    DGR_ALLOC(wpre_out, arena, unsigned short, (n_cap + 1) * KW);
+    if (need_in_csr) DGR_ALLOC(wpre_in, arena, unsigned short, (n_in_cap + 1) * KW);
     // same-stride maps (in and out are the SAME coordinate set) are symmetric: search half the offsets
     const int symmetric = (in.coords == out.coords && !need_in_csr) ? 1 : 0;
     if (in_buckets && in_buckets->built && ks == 3) {

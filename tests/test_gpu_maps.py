@@ -121,3 +121,27 @@ def test_6d_maps_pipeline_shaped():
         k, i, o = maps.kernel_map('down', ts)
         assert kmap_set(k, i, o) == kmap_set(*me.kernel_map(ocoords[ts], ocoords[2 * ts], 6, 3, ts))
         assert np.all(np.diff(k) >= 0) and np.all(np.diff(o)[np.diff(k) == 0] > 0)
+
+
+def test_6d_maps_rows_with_hundreds_of_neighbours():
+    """A dense 6-D block: the full 4^6 lattice (4096 rows, interior rows own ALL 729 offsets) next to sparse rows.
+    A row's pair count exceeds every small-integer bound a builder might assume (the per-word rank prefixes of the
+    placing pass are 16-bit for this reason: an 8-bit one passed every other map test and corrupted the CSR of the
+    benchmark's pairs 4-7) while the average stays below the reserved 160 pairs per row."""
+    from deepglobalregistration_amd import ops
+    g = np.stack(np.meshgrid(*[np.arange(4)] * 6, indexing='ij'), -1).reshape(-1, 6)
+    rng = np.random.default_rng(5)
+    sparse = np.unique(rng.integers(20, 400, (24000, 6)), axis=0)
+    rows = np.concatenate([g, sparse]).astype(np.int32)
+    rows = rows[rng.permutation(len(rows))]
+    coords = np.concatenate([np.zeros((len(rows), 1), np.int32), rows], axis=1)
+    maps = ops.Maps(coords, 6, 3)
+    k, i, o = maps.kernel_map('same', 1)
+    ok, oi, oo = me.kernel_map(coords, coords, 6, 3, 1)
+    assert kmap_set(k, i, o) == kmap_set(ok, oi, oo)
+    per_row = np.bincount(o, minlength=len(coords))
+    assert per_row.max() == 729 and (per_row > 255).sum() > 50
+    assert np.all(np.diff(k) >= 0) and np.all(np.diff(o)[np.diff(k) == 0] > 0)
+    c2 = me.stride_coords(coords, 2)
+    k, i, o = maps.kernel_map('down', 1)
+    assert kmap_set(k, i, o) == kmap_set(*me.kernel_map(coords, c2, 6, 3, 1))
