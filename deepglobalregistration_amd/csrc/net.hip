@@ -392,7 +392,9 @@ struct Fwd {
       static const bool os_lists = getenv("DGR_OS_LISTS") != nullptr;   // A/B + the bit-identity test of the two kernels
       bool same_stride = false;
       for (int l = 0; l < 4; ++l) same_stride = same_stride || t == &ms.nsame[l];
-      o.dense = same_stride && o.row_scale && !os_lists && dgr_conv_dense_supported(L.cin, L.cin_pad, L.cout);
+      // (its buffer loads address the input with 32-bit byte offsets: tensors of 2 GB and more stay on the list kernel)
+      o.dense = same_stride && o.row_scale && !os_lists && dgr_conv_dense_supported(L.cin, L.cin_pad, L.cout) &&
+                cin_map.n_cap * (int64_t)in.ld * 4 < (1ll << 31);
       const char *kname = "sparse_conv_os";
       DGR_CHECK(dgr_conv_os_launch(o, stream, &kname));
       if (prof) {
