@@ -38,7 +38,7 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
 PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md, dense v_mfma_f32_32x32x16_f16 / _bf16
 # The conv kernels compute f32-level results on the f16 matrix pipe: every f32 operand is split into two f16 pieces
-# under an exact power-of-two scale and a MAC costs THREE v_mfma_*_f16 products (conv_bf3.hip, conv_os.hip).  The
+# under an exact power-of-two scale and a MAC costs THREE v_mfma_*_f16 products (conv_wide.hip, conv_dense.hip, conv_os.hip).  The
 # headline `roofline` therefore prices the dominant kernel against the pipe it issues on: achieved = 3 x the
 # algorithmic FLOP/s, peak = the dense f16 MFMA peak.  `roofline.f32_view` is the same launches counted as plain f32
 # MACs against the f32 MFMA peak (what an exact-f32 kernel would be priced against); it can exceed 1 and is NOT the
@@ -104,7 +104,28 @@ def layer_flop(s):
 
 
 def roofline_time_s(s):
+    """max(compulsory bytes / HBM peak, FLOP / f32 MFMA peak) -- the model the coverage contract states."""
     return max(layer_bytes(s) / (PEAK_HBM_GBPS * 1e9), layer_flop(s) / (PEAK_FP32_MFMA_TFLOPS * 1e12))
+
+
+def roofline_time_own_pipe_s(s, kind):
+    """The same layer priced on the pipe its kernel ISSUES on: split-operand kernels (`f16x2`) spend three f16 MFMA
+    products per MAC against the dense f16 peak; the others f32 MFMA.  A fraction of this time cannot exceed 1."""
+    if 'f16x2' in kind:
+        return max(layer_bytes(s) / (PEAK_HBM_GBPS * 1e9), PRODUCTS_PER_MAC * layer_flop(s) / (PEAK_F16_MFMA_TFLOPS * 1e12))
+    return roofline_time_s(s)
+
+
+def layer_gather_bytes(s):
+    """SURVEY.md 8d's secondary figure: what a gather -> GEMM -> scatter-add implementation moves,
+    4 P (Cin + 2 Cout) + 8 P + 4 K_ne Cin Cout."""
+    return 4.0 * s['pairs'] * (s['cin'] + 2 * s['cout']) + 8.0 * s['pairs'] + 4.0 * s['nonempty'] * s['cin'] * s['cout']
+
+
+# measured ceiling of the memory system for RANDOM 256-byte rows from a region beyond the 4-MB L2 of an XCD
+# (tools/microbench/vmem_bw.hip, profiles/r03_vmem_load_ceiling.txt: 20 B/ns/CU from a 16-MB region = 5.1 TB/s chip-wide,
+# 14 B/ns/CU = 3.6 TB/s from HBM): what bounds a kernel whose operand rows are gathered, whatever its arithmetic
+RANDOM_ROW_CEILING_GBPS = 5100.0
 
 
 # ----------------------------------------------------------------------------------------------
@@ -123,14 +144,26 @@ def oracle_parity_and_baseline(ck, args, pair0, do_baseline):
     p0, c0, p1, c1 = pair0['xyz0'], pair0['coords0'], pair0['xyz1'], pair0['coords1']
     n0, n1 = len(p0), len(p1)
     t = {}
-    t0 = time.time()
-    oF0 = oresunet.resunet_forward(ck['state_dict'], c0, np.ones((n0, 1), np.float32), 3, ks, True)
-    oF1 = oresunet.resunet_forward(ck['state_dict'], c1, np.ones((n1, 1), np.float32), 3, ks, True)
-    t['fcgf'] = time.time() - t0
-    t0 = time.time()
-    c6, f6 = opipe.inlier_inputs(p0, p1, c0, c1, np.arange(n0), pair0['idx1'])
-    ologit = oresunet.resunet_forward(ck['state_dict_inlier'], c6, f6, 6, 3, False).reshape(-1)
-    t['inlier_net'] = time.time() - t0
+    runs = {'fcgf': [], 'inlier_net': []}
+    n_runs = 3 if do_baseline else 1
+    c6 = f6 = None
+    if do_baseline:
+        # warm-up (thread pool, allocator, the oracle's per-map caches are rebuilt every call): one FCGF forward and the 6-D
+        # net on the first eighth of the correspondences
+        oresunet.resunet_forward(ck['state_dict'], c1, np.ones((n1, 1), np.float32), 3, ks, True)
+        c6w, f6w = opipe.inlier_inputs(p0, p1, c0, c1, np.arange(n0 // 8), pair0['idx1'][:n0 // 8])
+        oresunet.resunet_forward(ck['state_dict_inlier'], c6w, f6w, 6, 3, False)
+    for _ in range(n_runs):
+        t0 = time.time()
+        oF0 = oresunet.resunet_forward(ck['state_dict'], c0, np.ones((n0, 1), np.float32), 3, ks, True)
+        oF1 = oresunet.resunet_forward(ck['state_dict'], c1, np.ones((n1, 1), np.float32), 3, ks, True)
+        runs['fcgf'].append(time.time() - t0)
+        t0 = time.time()
+        c6, f6 = opipe.inlier_inputs(p0, p1, c0, c1, np.arange(n0), pair0['idx1'])
+        ologit = oresunet.resunet_forward(ck['state_dict_inlier'], c6, f6, 6, 3, False).reshape(-1)
+        runs['inlier_net'].append(time.time() - t0)
+    t['fcgf'] = float(np.median(runs['fcgf']))
+    t['inlier_net'] = float(np.median(runs['inlier_net']))
     parity = {'pair': 0, 'voxels': [n0, n1],
               'dF': float(max(np.abs(pair0['F0'] - oF0).max(), np.abs(pair0['F1'] - oF1).max())),
               'dlogit_rel': float(np.abs(pair0['logit'] - ologit).max() / max(1e-12, np.abs(ologit).max())),
@@ -162,8 +195,18 @@ def oracle_parity_and_baseline(ck, args, pair0, do_baseline):
                        'parity_TE_m': rp['dt'] * rp['t_scale'],
                        'band_what': 'largest |dR|, |dt| of the oracle against ITSELF at the same iteration counts '
                                     '(k, k-15) on a row permutation and 4 few-ulp perturbations of its input'})
-        parity['rt_ok'] = bool(max(rp['dR'], rp['dt']) <= max(1e-4, 3 * (rp['band'] or 0.0)))
-    parity['ok'] = bool(parity['dF'] < 1e-4 and parity['dlogit_rel'] < 1e-4 and parity.get('rt_ok', True))
+        # two separate statements: the stated tolerance (north_star: R / t within 1e-4), and the band criterion that is
+        # accepted where the reference does not reproduce ITSELF to 1e-4 on this input
+        parity['rt_within_1e-4'] = bool(max(rp['dR'], rp['dt']) <= 1e-4)
+        parity['rt_within_3x_reference_band'] = bool(max(rp['dR'], rp['dt']) <= 3 * (rp['band'] or 0.0))
+        parity['rt_ok'] = bool(parity['rt_within_1e-4'] or parity['rt_within_3x_reference_band'])
+        if not parity['rt_within_1e-4']:
+            parity['rt_note'] = ('R / t exceed the stated 1e-4 at equal iteration counts; accepted because the reference '
+                                 f'moves by {rp["band"]:.1e} from itself under a row permutation / few-ulp input changes '
+                                 '(Adam from a stationary start, core/registration.py:161-194; DESIGN.md section 2)')
+    parity['features_logits_within_1e-4'] = bool(parity['dF'] < 1e-4 and parity['dlogit_rel'] < 1e-4)
+    parity['within_1e-4'] = bool(parity['features_logits_within_1e-4'] and parity.get('rt_within_1e-4', True))
+    parity['ok'] = bool(parity['features_logits_within_1e-4'] and parity.get('rt_ok', True))
     if not do_baseline:
         return parity, None
     # 1-NN: the whole search, chunked like the reference (nn_max_n = 250), one run
@@ -179,10 +222,13 @@ def oracle_parity_and_baseline(ck, args, pair0, do_baseline):
     t['registration'] = float(np.median(runs))
     total = sum(t.values())
     base = {'value': 1.0 / total, 'unit': 'pairs/s', 'cores': threads, 'host_cores_found': found, 'kind': 'port',
-            'sample': f'pair 0 of the timed batch at FULL size ({n0}/{n1} voxels): FCGF x2, 6-D net and the whole 1-NN '
-                      f'search ({n0} x {n1} rows, chunks of 250 like the reference) one run each, registration median '
-                      f'of 3; voxelisation excluded; {threads} torch threads on a host that reports {found} cores',
+            'sample': f'pair 0 of the last timed batch at FULL size ({n0}/{n1} voxels): FCGF x2 and the 6-D net after one '
+                      f'warm-up, median of {n_runs} runs each; the whole 1-NN search ({n0} x {n1} rows, chunks of 250 like '
+                      f'the reference) one run; registration median of 3; voxelisation excluded; {threads} torch threads '
+                      f'on a host that reports {found} cores (the oracle is thousands of small gather / mm / index_add '
+                      'calls per forward: beyond ~16 threads their fork/join overhead outweighs the parallel work)',
             'stage_s': {k: round(v, 3) for k, v in t.items()},
+            'stage_runs_s': {k: [round(x, 3) for x in v] for k, v in runs.items()},
             'reference_modules_in_container': {
                 'note': 'the reference\'s own core/knn.py / core/registration.py timed on CPU tensors in the build '
                         'container (8 cores, torch 2.10; BASELINE.md section 2) -- /root/reference is absent on the GPU box',
@@ -245,6 +291,9 @@ def main():
                     '(use_icp = True, core/deep_global_registration.py:78,317-322); NOT the headline configuration')
     ap.add_argument('--force-safeguard', action='store_true', help='every pair takes the safeguard branch (RANSAC over its '
                     'correspondences, :302-315): the confidence gate threshold is put out of reach')
+    ap.add_argument('--rotate-sets', type=int, default=2, help='weak-scaling mode: every stream holds this many DISTINCT '
+                    'batches of pairs and consecutive steps take them in turn, so that no step repeats the inputs of the '
+                    'step before it (1 = every step re-registers the same pairs)')
     ap.add_argument('--dump-results', default=None, help='rank 0 writes the gathered per-pair results (pair ids, T, status, stats) '
                     'of the last timed step to this .npz (tests)')
     ap.add_argument('--launch-check', action='store_true', help='CPU-only check of the multi-rank plumbing')
@@ -262,7 +311,18 @@ def main():
     backend = os.environ.get('DGR_BENCH_BACKEND', 'gloo' if args.launch_check else 'nccl')
     if os.environ.get('DGR_BENCH_ONE_GPU'):
         local_rank = 0
-    if world > 1:
+    # DGR_BENCH_FORCE_PG=1: a one-rank run initialises the process group as well and executes every collective of the
+    # multi-GPU path (object broadcast, the flat weight broadcast, result all-gather, MAX all-reduce, barriers) on a
+    # one-rank communicator -- on a 1-GPU box that is the only way to run the RCCL code before an 8-GPU node does
+    # (tests/test_gpu_bench_ranks.py)
+    force_pg = os.environ.get('DGR_BENCH_FORCE_PG') == '1' and world == 1 and not args.launch_check
+    if force_pg:
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+        os.environ.setdefault('MASTER_PORT', str(_free_port()))
+        os.environ['DGR_DIST_FORCE_COLLECTIVES'] = '1'
+    pg_up = world > 1 or force_pg
+    if pg_up:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if backend == 'nccl':
@@ -278,8 +338,9 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback)'
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
-    if world > 1:
-        log(f'{dist.get_backend()} process group up: {dist.get_world_size()} ranks (backend "nccl" = RCCL on ROCm)')
+    if pg_up:
+        log(f'{dist.get_backend()} process group up: {dist.get_world_size()} rank(s) (backend "nccl" = RCCL on ROCm)'
+            + (' -- forced one-rank group, every collective of the multi-GPU path runs' if force_pg else ''))
 
     from deepglobalregistration_amd import _lib, dist as ddist, ops, synth
     from deepglobalregistration_amd.core.deep_global_registration import DeepGlobalRegistration
@@ -322,10 +383,13 @@ def main():
         log(f'strong scaling: {P} pairs dealt by cost, this rank {len(my_pairs)} (cost share '
             f'{cost[my_pairs].sum() / cost.sum():.4f})')
     else:
-        my_pairs = [rank * S * B + i for i in range(S * B)]  # weak scaling: S x B own pairs per rank
-    # batches of B pairs, dealt over the S streams
+        # weak scaling: S x B own pairs per rank and step, R distinct sets of them taken in turn
+        R = max(1, args.rotate_sets)
+        my_pairs = [rank * S * B * R + i for i in range(S * B * R)]
+    # batches of B pairs, dealt over the S streams (weak mode: stream w holds batches w, w + S, ...: one per set)
     batches = [my_pairs[i:i + B] for i in range(0, len(my_pairs), B)]
     per_stream = [batches[w::S] for w in range(S)]
+    rotate = not args.total_pairs
 
     class Worker:
         """One HIP stream + one library context + its resident batches, driven by one host thread."""
@@ -334,7 +398,7 @@ def main():
             self.wid, self.batch_ids = wid, batch_ids
             self.ctx = _lib.new_ctx(device) if S > 1 else None
             self.stream = torch.cuda.Stream(device) if S > 1 else torch.cuda.current_stream(device)
-            self.results = []
+            self.results, self.result_ids, self.last_bt, self.k = [], [], None, 0
 
         def __enter__(self):
             _lib.use_ctx(self.ctx)
@@ -382,6 +446,7 @@ def main():
                 for _ in range(args.warmup):
                     self.step()
                 torch.cuda.synchronize()
+                self.k = 0   # the timed region starts with set 0
 
         def run_batch(self, bt):
             if args.from_host and bt['forced'] is not None:
@@ -400,7 +465,12 @@ def main():
                                                icp=args.full_register)
 
         def step(self):
-            self.results = [self.run_batch(bt) for bt in self.batches]
+            """weak mode: the next of this stream's batches (set k mod R); strong mode: all of them."""
+            todo = [self.batches[self.k % len(self.batches)]] if rotate else self.batches
+            self.k += 1
+            self.results = [self.run_batch(bt) for bt in todo]
+            self.result_ids = [s for bt in todo for s in bt['ids']]
+            self.last_bt = todo[-1]
 
         def run(self, n):
             with self:
@@ -410,13 +480,14 @@ def main():
     workers = [Worker(w, ids) for w, ids in enumerate(per_stream) if ids]
     for w in workers:
         w.prepare()
-    n_local = sum(len(ids) for w in workers for ids in w.batch_ids)
+    # pairs this rank registers per step
+    n_local = sum(len(w.batch_ids[0]) if rotate else sum(len(ids) for ids in w.batch_ids) for w in workers)
     b0 = workers[0].batches[0]
     log(f'{len(workers)} stream(s) ready: weights resident, {n_local} pairs voxelised (first batch N0={b0["off0"][-1]} '
         f'N1={b0["off1"][-1]}), warm-up done')
 
     def barrier():
-        if world > 1:
+        if pg_up:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -435,7 +506,7 @@ def main():
     elapsed = time.perf_counter() - t0
     # host CPU seconds (all threads of this rank) per step: the budget of N ranks x S driver threads on one node
     cpu_s_per_step = (time.process_time() - cpu0) / args.steps
-    if world > 1:
+    if pg_up:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -444,13 +515,13 @@ def main():
     w0 = workers[0]
     _lib.use_ctx(w0.ctx)
     # outputs of the LAST call of stream 0 (the last batch of the last timed step), before anything else runs there
-    last_bt = w0.batches[-1]
+    last_bt = w0.last_bt
     with torch.cuda.stream(w0.stream):
         hip_out = {k: ops.batch_output(device, k).cpu().numpy() for k in ('idx1', 'logit', 'F0', 'F1')}
     T = np.concatenate([r[0] for w in workers for r in w.results])
     status = np.concatenate([r[1] for w in workers for r in w.results])
     stats = np.concatenate([r[2] for w in workers for r in w.results])
-    ids_local = [s for w in workers for ids in w.batch_ids for s in ids]
+    ids_local = [s for w in workers for s in w.result_ids]
     gathered = ddist.gather_results(T, status, stats, dst=0, device=coll_dev)
     gathered_ids = ddist.gather_results(np.tile(np.eye(4), (len(ids_local), 1, 1)) * np.asarray(ids_local)[:, None, None],
                                         np.zeros(len(ids_local), np.int32), np.zeros((len(ids_local), 4), np.float32),
@@ -499,20 +570,34 @@ def main():
                                              'roofline_ms': 0.0})
                 g['launches'] += 1; g['ms'] += ms; g['main_kernel_ms'] += gms
                 g['gflop'] += layer_flop(st) / 1e9; g['gbytes'] += layer_bytes(st) / 1e9
-                g['roofline_ms'] += roofline_time_s(st) * 1e3
-            for g in groups.values():
+                g['roofline_ms'] += roofline_time_own_pipe_s(st, kind) * 1e3
+            for kind, g in groups.items():
+                g['pipe'] = 'f16 MFMA x3 products' if 'f16x2' in kind else 'f32 MFMA'
                 g['tflops'] = g['gflop'] / max(g['ms'], 1e-9)
-                g['frac_of_roofline'] = g['roofline_ms'] / max(g['ms'], 1e-9)
+                g['frac_of_roofline'] = g['roofline_ms'] / max(g['ms'], 1e-9)   # on the pipe the kernel issues on: <= 1
             # the layers SURVEY.md 8d calls HBM-bound (C <= 64): COMPULSORY bytes over their measured durations
-            sel = [(st, ms) for st, ms in zip(per_layer, launch_ms) if max(st['cin'], st['cout']) <= 64]
+            sel = [(st, ms, kind) for st, ms, kind in zip(per_layer, launch_ms, kinds) if max(st['cin'], st['cout']) <= 64]
             if sel:
-                ms64 = sum(ms for _, ms in sel)
-                comp64 = sum(layer_bytes(st) for st, _ in sel)
-                c64 = {'layers': len(sel), 'ms_per_batch': ms64, 'gflop': sum(layer_flop(st) for st, _ in sel) / 1e9,
+                ms64 = sum(ms for _, ms, _ in sel)
+                comp64 = sum(layer_bytes(st) for st, _, _ in sel)
+                gath64 = sum(layer_gather_bytes(st) for st, _, _ in sel)
+                rows64 = sum(4.0 * st['pairs'] * st['cin'] for st, _, _ in sel)
+                own64 = sum(roofline_time_own_pipe_s(st, kind) for st, _, kind in sel) * 1e3
+                c64 = {'layers': len(sel), 'ms_per_batch': ms64, 'gflop': sum(layer_flop(st) for st, _, _ in sel) / 1e9,
                        'compulsory_gbytes': comp64 / 1e9, 'compulsory_gbps': comp64 / ms64 / 1e6,
                        'frac_of_hbm_peak_compulsory': comp64 / ms64 / 1e6 / PEAK_HBM_GBPS,
-                       'roofline_ms': sum(roofline_time_s(st) for st, _ in sel) * 1e3,
-                       'frac_of_roofline': sum(roofline_time_s(st) for st, _ in sel) * 1e3 / ms64}
+                       # SURVEY.md 8d's model (compulsory bytes at 8 TB/s | FLOP at the f32 MFMA peak): the contract's figure
+                       'roofline_ms': sum(roofline_time_s(st) for st, _, _ in sel) * 1e3,
+                       'frac_of_roofline': sum(roofline_time_s(st) for st, _, _ in sel) * 1e3 / ms64,
+                       # the same layers on the pipes their kernels issue on (f16 x3 for the split-operand kernels)
+                       'roofline_ms_own_pipe': own64, 'frac_of_roofline_own_pipe': own64 / ms64,
+                       # gather view: SURVEY 8d's Bgather and the input rows alone (4 P Cin) over the measured time,
+                       # against the measured rate of the memory system for random 256-byte rows beyond L2
+                       'bgather_gbytes': gath64 / 1e9, 'bgather_gbps': gath64 / ms64 / 1e6,
+                       'row_gather_gbytes': rows64 / 1e9, 'row_gather_gbps': rows64 / ms64 / 1e6,
+                       'random_row_ceiling_gbps': RANDOM_ROW_CEILING_GBPS,
+                       'bgather_frac_of_random_row_ceiling': gath64 / ms64 / 1e6 / RANDOM_ROW_CEILING_GBPS,
+                       'row_gather_frac_of_random_row_ceiling': rows64 / ms64 / 1e6 / RANDOM_ROW_CEILING_GBPS}
             # the dominant kernel = the variant with the largest share of the conv time
             dk = max(groups, key=lambda k: groups[k]['main_kernel_ms'])
             sel = [(st, gms) for st, gms, kind in zip(per_layer, gemm_ms, kinds) if kind == dk]
@@ -530,7 +615,7 @@ def main():
             np.savez(args.dump_results, ids=np.asarray(ids_all), T=T_all, status=status_all, stats=stats_all)
         te, re = [], []
         for p, seed in enumerate(ids_all):
-            if status_all[p] in (0, 3):   # estimated by the network path or by the safeguard RANSAC
+            if (int(status_all[p]) & 0xff) in (0, 3):   # estimated by the network path or by the safeguard RANSAC (flags masked)
                 Tg = vox_cache[seed][2] if seed in vox_cache else synth.synth_pair(seed, n_raw=args.n_raw, kind=args.kind)[2]
                 te.append(float(np.linalg.norm(T_all[p][:3, 3] - Tg[:3, 3])))
                 c = (np.trace(T_all[p][:3, :3].T @ Tg[:3, :3]) - 1) / 2
@@ -539,7 +624,7 @@ def main():
         # the same per-stream workload (tools/evidence.sh), committed under profiles/ -- not measurable from inside
         # this process; quoted only when kernel name and workload label match this run
         pmc, pmc_file = None, None
-        for cand in ('r03_dominant_pmc.json', 'r02_dominant_pmc.json'):
+        for cand in ('r04_dominant_pmc.json', 'r03_dominant_pmc.json'):
             ppath = os.path.join(ROOT, 'profiles', cand)
             if os.path.exists(ppath):
                 pj = json.load(open(ppath))
@@ -568,7 +653,9 @@ def main():
                                    f'({cfg_label(args)})',
                        'streams_per_gpu': len(workers),
                        'voxels_per_pair': [int(off0[-1] / nb), int(off1[-1] / nb)],
-                       'pairs_per_step': pairs_per_step, 'refinement': not args.no_refine,
+                       'pairs_per_step': pairs_per_step,
+                       'distinct_input_sets': (max(1, args.rotate_sets) if rotate else 1),
+                       'refinement': not args.no_refine,
                        'use_icp': bool(args.full_register), 'forced_safeguard': bool(args.force_safeguard),
                        'parallelism': f'pair-sharded x{world}, no data-path collective'},
             # roofline of the DOMINANT conv kernel variant against the pipe it issues on: achieved = products per MAC x
@@ -600,7 +687,9 @@ def main():
                                              'gflop_per_batch': flop / 1e9, 'compulsory_gbytes_per_batch': byts / 1e9,
                                              'hbm_gbps_compulsory': byts / (conv_ms * 1e-3) / 1e9,
                                              'roofline_ms_f32_model': sum(roofline_time_s(s) for s in per_layer) * 1e3,
-                                             'frac_of_roofline_f32_model': sum(roofline_time_s(s) for s in per_layer) * 1e3 / conv_ms},
+                                             'frac_of_roofline_f32_model': sum(roofline_time_s(s) for s in per_layer) * 1e3 / conv_ms,
+                                             'frac_of_roofline_own_pipe': (sum(roofline_time_own_pipe_s(s_, k_) for s_, k_ in zip(per_layer, kinds)) * 1e3 / conv_ms
+                                                                           if len(kinds) == len(per_layer) else None)},
                          'c_le_64_layers': c64,
                          'by_kernel': {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in g.items()}
                                        for k, g in groups.items()}},
@@ -626,7 +715,7 @@ def main():
             out['parity'], out['cpu_baseline'] = oracle_parity_and_baseline(ck, args, pair0, not args.no_cpu_baseline)
             log(f'parity: {out["parity"]}')
         print(json.dumps(out))
-    if world > 1:
+    if pg_up:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -15,7 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DGR_HIP_LIB') or os.path.join(_HERE, 'lib', 'libdgr_hip.so')  # override: experiments only
 
 DGR_OK, DGR_EINVAL, DGR_EHIP, DGR_ENOMEM, DGR_ESVD, DGR_EINTERNAL = 0, -1, -2, -3, -4, -5
-STATUS_OK, STATUS_LOW_CONFIDENCE, STATUS_SVD_FAILED, STATUS_SAFEGUARD, STATUS_ICP_SKIPPED = 0, 1, 2, 3, 4
+STATUS_OK, STATUS_LOW_CONFIDENCE, STATUS_SVD_FAILED, STATUS_SAFEGUARD = 0, 1, 2, 3
+STATUS_FLAG_ICP_SKIPPED, STATUS_MASK = 0x100, 0xff   # flag OR-ed onto a code: the final ICP could not run on the pair
 
 c_i32p, c_i64p, c_f32p, c_f64p = (C.POINTER(C.c_int32), C.POINTER(C.c_int64),
                                   C.POINTER(C.c_float), C.POINTER(C.c_double))
@@ -70,7 +71,7 @@ SIGNATURES = {
     'dgr_icp_point_to_point': (C.c_int, [vp, vp, C.c_int64, vp, C.c_int64, C.c_double, c_f64p, C.c_int, C.c_double,
                                           C.c_double, c_f64p, c_f64p, vp]),
     'dgr_ransac_correspondence': (C.c_int, [vp, vp, vp, C.c_int64, C.c_double, C.c_int64, C.c_uint32, c_f64p, c_f64p, vp]),
-    'dgr_ctx_stage_times': (C.c_int, [vp, c_f32p]),
+    'dgr_ctx_stage_times': (C.c_int, [vp, c_f32p, C.c_int, C.POINTER(C.c_int)]),
     'dgr_ctx_conv_launches': (C.c_int64, [vp]),
     'dgr_ctx_conv_launch_times': (C.c_int, [vp, c_f32p, c_f32p, C.c_int64, C.POINTER(C.c_int64)]),
     'dgr_ctx_conv_launch_kinds': (C.c_int, [vp, C.c_char_p, C.c_int64, C.POINTER(C.c_int64)]),

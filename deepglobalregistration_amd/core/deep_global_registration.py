@@ -42,6 +42,16 @@ class DeepGlobalRegistration:
         self.safeguard_method = 'correspondence'
         self.use_icp = bool(_cfg_get(config, 'use_icp', True))   # reference: self.use_icp = True (:75)
         self.ransac_seed = int(_cfg_get(config, 'ransac_seed', 0))
+        # the reference hard-codes RANSACConvergenceCriteria(4000000, ...) (:61); a config key so that parity tests can
+        # give both sides a count the CPU oracle finishes
+        self.ransac_max_iteration = int(_cfg_get(config, 'ransac_max_iteration', 4000000))
+        # harness-only hooks, None in production (DESIGN.md "Synthetic workload": untrained weights give meaningless
+        # matches and confidences): `matches(xyz0, xyz1, idx1) -> idx1` after the search ran, `logits(xyz0, xyz1_matched,
+        # logit) -> logit` after the inlier net ran -- device tensors in, device tensors out
+        self.harness_matches = None
+        self.harness_logits = None
+        self.last_corres_idx1 = None
+        self.last_logit = None
         self.feat_timer = Timer()
         self.reg_timer = Timer()
         self.last_status = None
@@ -139,7 +149,8 @@ class DeepGlobalRegistration:
         """Safeguard (:219-236): RANSAC over the putative correspondences.  `pcd0` / `pcd1` are the
         voxelised xyz tensors (the reference wraps them into Open3D clouds).  Like the reference's call
         (RANSACConvergenceCriteria(4000000, num_iterations) with the second argument clamped to
-        confidence 1.0), all 4 000 000 hypotheses are evaluated; `num_iterations` is accepted and unused."""
+        confidence 1.0), all 4 000 000 hypotheses (`ransac_max_iteration`) are evaluated; `num_iterations` is accepted
+        and unused."""
         if self.safeguard_method != 'correspondence':
             # :235.  The reference's other branch, 'fcgf_feature_matching' (:31-46), calls the pre-0.10
             # `o3d.registration` namespace, which does not exist in the pinned open3d==0.17.0: dead code there.
@@ -148,7 +159,8 @@ class DeepGlobalRegistration:
         X = pcd0 if len(idx0) == len(pcd0) and bool((idx0 == torch.arange(len(idx0), device=self.device)).all()) \
             else ops.gather_rows3(pcd0, idx0)
         Y = ops.gather_rows3(pcd1, torch.as_tensor(idx1, device=self.device).long())
-        T, h, count, rmse = ops.ransac_correspondence(X, Y, distance_threshold, 4000000, seed=self.ransac_seed)
+        T, h, count, rmse = ops.ransac_correspondence(X, Y, distance_threshold, self.ransac_max_iteration,
+                                                      seed=self.ransac_seed)
         self.last_stats = {'ransac_hypothesis': h, 'ransac_inliers': count, 'ransac_rmse': rmse}
         return T
 
@@ -165,10 +177,16 @@ class DeepGlobalRegistration:
         self.feat_timer.toc()
 
         corres_idx0, corres_idx1 = self.fcgf_feature_matching(fcgf_feats0, fcgf_feats1)
+        if self.harness_matches is not None:
+            corres_idx1 = self.harness_matches(xyz0, xyz1, corres_idx1).long().reshape(-1)
+        self.last_corres_idx1 = corres_idx1
 
         inlier_coords, inlier_feats = ops.inlier_inputs(coords0, xyz0, coords1, xyz1, corres_idx1,
                                                         self.inlier_feature_type)
         logit = self.inlier_prediction(inlier_feats.contiguous(), coords=inlier_coords)
+        if self.harness_logits is not None:
+            logit = self.harness_logits(xyz0, ops.gather_rows3(xyz1, corres_idx1), logit).float().reshape(-1, 1)
+        self.last_logit = logit
         weights, wsum = ops.sigmoid_clip_sum(logit, self.clip_weight_thresh)
 
         wsum_threshold = max(200, len(weights) * 0.05)
@@ -252,6 +270,7 @@ class DeepGlobalRegistration:
             self.voxel_size, clip_weight_thresh=self.clip_weight_thresh,
             inlier_feature_type=self.inlier_feature_type, break_threshold_ratio=1e-4,
             skip_refinement=skip_refinement, forced_logit=forced_logits, override_idx1=override_idx1,
-            safeguard=safeguard, use_icp=icp, ransac_seed=self.ransac_seed)
+            safeguard=safeguard, use_icp=icp, ransac_hypotheses=self.ransac_max_iteration,
+            ransac_seed=self.ransac_seed)
         T = T.astype(np.float64)
         return T, status, stats

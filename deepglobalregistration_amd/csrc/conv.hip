@@ -717,24 +717,40 @@ __global__ void __launch_bounds__(256)
   if (live && c.x != b0s) mixed = 1;
   if (live && (c.x < 0 || c.x >= GRID_MAXB)) m->bad = 1;
   __syncthreads();
-  if (mixed) {   // block straddles batch elements: plain atomics
-    if (live && c.x >= 0 && c.x < GRID_MAXB) {
-      atomicMin(&m->mn[c.x][0], c.y); atomicMax(&m->mx[c.x][0], c.y);
-      atomicMin(&m->mn[c.x][1], c.z); atomicMax(&m->mx[c.x][1], c.z);
-      atomicMin(&m->mn[c.x][2], c.w); atomicMax(&m->mx[c.x][2], c.w);
+  // min / max of the lanes selected by `mine` over the wave (the others carry the identities)
+  auto wave_minmax = [&](bool mine, int32_t (&v)[6]) {
+    v[0] = mine ? c.y : INT32_MAX; v[1] = mine ? c.z : INT32_MAX; v[2] = mine ? c.w : INT32_MAX;
+    v[3] = mine ? c.y : INT32_MIN; v[4] = mine ? c.z : INT32_MIN; v[5] = mine ? c.w : INT32_MIN;
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        v[d] = min(v[d], __shfl_xor(v[d], s, 64));
+        v[3 + d] = max(v[3 + d], __shfl_xor(v[3 + d], s, 64));
+      }
+    }
+  };
+  int32_t v[6];
+  if (mixed) {
+    // the block straddles batch elements (a handful of blocks per call): one reduction per wave and batch element
+    // present in it, six atomics each.  (Per-thread atomics here -- 1536 on the same few addresses per such block, at
+    // ~40 ns each chip-wide -- made this kernel 50 us of the 290-us conv1 layer.)
+    const bool ok = live && c.x >= 0 && c.x < GRID_MAXB;
+    unsigned long long todo = __ballot(ok);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int b = __shfl(c.x, leader, 64);
+      const bool mine = ok && c.x == b;
+      wave_minmax(mine, v);
+      if ((int)(threadIdx.x & 63) == leader) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { atomicMin(&m->mn[b][d], v[d]); atomicMax(&m->mx[b][d], v[3 + d]); }
+      }
+      todo &= ~__ballot(mine);
     }
     return;
   }
-  int32_t v[6] = {live ? c.y : INT32_MAX, live ? c.z : INT32_MAX, live ? c.w : INT32_MAX,
-                  live ? c.y : INT32_MIN, live ? c.z : INT32_MIN, live ? c.w : INT32_MIN};
-#pragma unroll
-  for (int s = 32; s >= 1; s >>= 1) {
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      v[d] = min(v[d], __shfl_xor(v[d], s, 64));
-      v[3 + d] = max(v[3 + d], __shfl_xor(v[3 + d], s, 64));
-    }
-  }
+  wave_minmax(live, v);
   if ((threadIdx.x & 63) == 0)
     for (int d = 0; d < 6; ++d) red[d][threadIdx.x >> 6] = v[d];
   __syncthreads();
@@ -749,25 +765,31 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// one wave: lane b sizes batch element b, a shuffle scan yields the bases (launched with 64 threads = GRID_MAXB)
 __global__ void grid_layout_kernel(DgrGridMeta *m, int pad, long long cap) {
-  if (threadIdx.x != 0) return;
-  long long total = 0;
-  bool ok = !m->bad;
-  for (int b = 0; b < GRID_MAXB; ++b) {
-    m->base[b] = total;
-    if (m->mx[b][0] < m->mn[b][0]) continue;   // no rows
-    long long vol = 1;
+  static_assert(GRID_MAXB == 64, "one lane per batch element");
+  const int b = threadIdx.x;
+  long long vol = 0;
+  if (m->mx[b][0] >= m->mn[b][0]) {   // the element has rows
+    vol = 1;
     for (int d = 0; d < 3; ++d) {
       const long long e = (long long)m->mx[b][d] - m->mn[b][d] + 1 + 2 * pad;
       m->dim[b][d] = (int32_t)(e < (1ll << 30) ? e : (1ll << 30));
       vol = (vol <= cap && e <= cap) ? vol * e : cap + 1;
     }
-    if (vol > cap) { ok = false; break; }
-    total += vol;
-    if (total > cap) { ok = false; break; }
   }
-  m->total = total;
-  m->ok = ok ? 1 : 0;
+  long long incl = vol;   // inclusive scan (every term <= cap + 1: no overflow over 64 lanes)
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1) {
+    const long long up = __shfl_up(incl, s, 64);
+    if (b >= s) incl += up;
+  }
+  m->base[b] = incl - vol;
+  const long long total = __shfl(incl, 63, 64);
+  if (b == 0) {
+    m->total = total <= cap ? total : cap + 1;
+    m->ok = (!m->bad && total <= cap) ? 1 : 0;
+  }
 }
 
 __global__ void grid_clear_kernel(const DgrGridMeta *m, int32_t *__restrict__ cells) {
@@ -782,13 +804,17 @@ __device__ __forceinline__ long long grid_cell(const DgrGridMeta *m, int b, int 
   return m->base[b] + ((long long)(z - m->mn[b][2] + pad) * dy + (y - m->mn[b][1] + pad)) * dx + (x - m->mn[b][0] + pad);
 }
 
+// cells[cell of row o] = o -- or, for a one-channel input (`values`), the row's input value itself: the MFMA kernel then
+// needs no second, dependent load per neighbour.  Empty cells hold -1 = 0xffffffff either way (as a float: a NaN
+// payload no arithmetic produces; an input feature with exactly these bits would read as "no voxel").
+constexpr uint32_t GRID_EMPTY = 0xffffffffu;
 __global__ void grid_fill_kernel(const int32_t *__restrict__ coords, const int32_t *n_dev, const DgrGridMeta *m, int pad,
-                                 int32_t *__restrict__ cells) {
+                                 int32_t *__restrict__ cells, const float *__restrict__ values, int values_ld) {
   if (!m->ok) return;
   const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= *n_dev) return;
   const int4 c = *reinterpret_cast<const int4 *>(coords + o * 4);
-  cells[grid_cell(m, c.x, c.y, c.z, c.w, pad)] = (int32_t)o;
+  cells[grid_cell(m, c.x, c.y, c.z, c.w, pad)] = values ? __builtin_bit_cast(int32_t, values[o * values_ld]) : (int32_t)o;
 }
 
 constexpr int C1_MAXK = 343;   // ks <= 7
@@ -882,20 +908,23 @@ __global__ void __launch_bounds__(256)
 // The same layer on the matrix cores, for ONE input channel (FCGF: feats = ones [N, 1]): per voxel the layer is a
 // 343-term (ks = 7) dot product per output channel, i.e. out[16 voxels x 32 channels] = G[16 x ks^3] . W[ks^3 x 32]
 // with G[v][k] = x[neighbour k of v] or 0 -- a GEMM whose left operand is gathered from the dense grid.  A wave owns
-// 16 voxels and walks the ks z-slabs of the kernel: lanes = (voxel, y-row) items read their ks consecutive grid cells
-// (+ the hit rows' input values) into a [16 x ks^2] slab of G in LDS, double-buffered per wave (no block barrier),
-// and ceil(ks^2 / 4) x 2 v_mfma_f32_16x16x4_f32 multiply it with the slab's weights.  Zeros of G contribute exactly
-// 0 to the fma chain, so a channel's value is the ascending-k chain over the hits, as in the scalar kernels
-// (one rounding per term instead of two).  Measured (8 clouds, 195 k voxels, 16 M pairs): 280 us vs 667 us scalar.
-// Compact weights wc[k][32] (net.hip); operands are swapped (D = W^T G^T): a lane ends with one voxel and 4
-// consecutive channels per 16-channel block.
+// 16 voxels and walks the ks z-slabs of the kernel: lanes = (voxel, y-row) items read their ks consecutive cells of the
+// VALUE grid (grid_fill_kernel: the cell holds the voxel's input value, so a neighbour costs no second, dependent load;
+// 28 contiguous bytes per item = two vector loads) into a [16 x ks^2] slab of G in LDS, double-buffered per wave (no
+// block barrier), and ceil(ks^2 / 4) x 2 v_mfma_f32_16x16x4_f32 multiply it with the slab's weights.  Zeros of G
+// contribute exactly 0 to the fma chain, so a channel's value is the ascending-k chain over the hits, as in the scalar
+// kernels (one rounding per term instead of two).
+// Weights: wt[kz][s][lane] = {W[k][lane & 15], W[k][16 + (lane & 15)]} with k = kz ks^2 + 4 s + (lane >> 4) (zero past
+// the slab): the A operands of step s as ONE coalesced 8-byte load per lane (net.hip); operands are swapped
+// (D = W^T G^T): a lane ends with one voxel and 4 consecutive channels per 16-channel block.
+// Round 3 kept row indices in the grid: per item 7 index loads + 7 dependent value loads, every lane on its own cache
+// line -- 196 scattered load instructions per 16 voxels, 213 us for 195 k voxels, bound by the address path.
 // ------------------------------------------------------------------------------------------
 template <int KS>
 __global__ void __launch_bounds__(256)
     conv1_grid_mfma(const int32_t *__restrict__ coords, const int32_t *n_dev, const DgrGridMeta *__restrict__ m,
-                    const int32_t *__restrict__ cells, const float *__restrict__ in, int in_ld,
-                    const float *__restrict__ wc, const float *__restrict__ shift, float *__restrict__ out, int out_ld,
-                    int32_t *pair_count) {
+                    const int32_t *__restrict__ cells, const float *__restrict__ wt, const float *__restrict__ shift,
+                    float *__restrict__ out, int out_ld, int32_t *pair_count) {
   constexpr int KS2 = KS * KS, HALF = KS / 2;
   constexpr int RS = (KS2 + 3) / 4 * 4;          // slab length padded to MFMA k-steps
   constexpr int LDG = RS + 1;
@@ -903,85 +932,90 @@ __global__ void __launch_bounds__(256)
   constexpr int ROUNDS = (ITEMS + 63) / 64;
   __shared__ float G[4][2][16][LDG];
   __shared__ int4 vc[4][16];
+  __shared__ int pair_sum;
   if (!m->ok) return;
   const int n = *n_dev;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t v0 = ((int64_t)blockIdx.x * 4 + wv) * 16;
-  if (v0 >= n) return;
-  if (lane < 16) vc[wv][lane] = v0 + lane < n ? *reinterpret_cast<const int4 *>(coords + (v0 + lane) * 4) : make_int4(-1, 0, 0, 0);
-  // the padding columns stay zero for the whole kernel
-  for (int e = lane; e < 2 * 16 * (LDG - KS2); e += 64) {
-    const int b = e / (16 * (LDG - KS2)), r = (e / (LDG - KS2)) % 16, c = KS2 + e % (LDG - KS2);
-    G[wv][b][r][c] = 0.f;
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (threadIdx.x == 0) pair_sum = 0;
+  __syncthreads();
   int pairs = 0;
-  int hit[ROUNDS][KS];
-  // request the grid cells of slab kz for this lane's items (a deeper pipeline -- cells two slabs ahead, input
-  // values one slab ahead -- measured slower: 333 vs 280 us, register pressure)
-  auto cells_of = [&](int kz) {
-#pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) {
-      const int it = lane + 64 * r;
-      const int v = it / KS, ky = it % KS;
-      const int4 c = vc[wv][min(v, 15)];
-      const bool live = it < ITEMS && c.x >= 0;
-      const long long c0 = live ? grid_cell(m, c.x, c.y - HALF, c.z + ky - HALF, c.w + kz - HALF, HALF) : 0;
-#pragma unroll
-      for (int kx = 0; kx < KS; ++kx) hit[r][kx] = live ? cells[c0 + kx] : -1;
+  if (v0 < n) {
+    if (lane < 16) vc[wv][lane] = v0 + lane < n ? *reinterpret_cast<const int4 *>(coords + (v0 + lane) * 4) : make_int4(-1, 0, 0, 0);
+    // the padding columns stay zero for the whole kernel
+    for (int e = lane; e < 2 * 16 * (LDG - KS2); e += 64) {
+      const int b = e / (16 * (LDG - KS2)), r = (e / (LDG - KS2)) % 16, c = KS2 + e % (LDG - KS2);
+      G[wv][b][r][c] = 0.f;
     }
-  };
-  // input values of the hits -> slab buffer b
-  auto fill = [&](int b) {
-#pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) {
-      const int it = lane + 64 * r;
-      const int v = it / KS, ky = it % KS;
-      float xv[KS];
-#pragma unroll
-      for (int kx = 0; kx < KS; ++kx) xv[kx] = in[(int64_t)max(hit[r][kx], 0) * in_ld];
-#pragma unroll
-      for (int kx = 0; kx < KS; ++kx) {
-        pairs += hit[r][kx] >= 0;
-        if (it < ITEMS) G[wv][b][v][kx + KS * ky] = hit[r][kx] >= 0 ? xv[kx] : 0.f;
-      }
-    }
-  };
-  typedef float f32x4 __attribute__((ext_vector_type(4)));
-  f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-  cells_of(0);
-  fill(0);
-  for (int kz = 0; kz < KS; ++kz) {
-    if (kz + 1 < KS) cells_of(kz + 1);          // in flight while this slab is multiplied
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const float *g = &G[wv][kz & 1][lane & 15][lane >> 4];
-    const float *w = wc + ((int64_t)kz * KS2 + (lane >> 4)) * 32 + (lane & 15);
+    uint32_t cell[ROUNDS][KS];
+    // request the grid cells of slab kz for this lane's items (dead items read cell 0 of the grid: no branch)
+    auto cells_of = [&](int kz) {
 #pragma unroll
-    for (int s = 0; s < RS / 4; ++s) {
-      const float b = g[4 * s];
-      const int kk = min(4 * s + (lane >> 4), KS2 - 1) - (lane >> 4);   // padded steps read a valid weight (times G = 0)
-      const float a0 = w[kk * 32], a1 = w[kk * 32 + 16];
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc[1], 0, 0, 0);
-    }
-    if (kz + 1 < KS) fill((kz + 1) & 1);
-  }
-  const int64_t o = v0 + (lane & 15);
-  if (o < n) {
+      for (int r = 0; r < ROUNDS; ++r) {
+        const int it = lane + 64 * r;
+        const int v = it / KS, ky = it % KS;
+        const int4 c = vc[wv][min(v, 15)];
+        const bool live = it < ITEMS && c.x >= 0;
+        const long long c0 = live ? grid_cell(m, c.x, c.y - HALF, c.z + ky - HALF, c.w + kz - HALF, HALF) : 0;
 #pragma unroll
-    for (int jb = 0; jb < 2; ++jb) {
-      f32x4 v = acc[jb];
-      if (shift) v += *reinterpret_cast<const f32x4 *>(shift + 16 * jb + 4 * (lane >> 4));
-      *reinterpret_cast<f32x4 *>(out + o * out_ld + 16 * jb + 4 * (lane >> 4)) = v;
+        for (int kx = 0; kx < KS; ++kx) cell[r][kx] = (uint32_t)cells[c0 + kx];
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) cell[r][kx] = live ? cell[r][kx] : GRID_EMPTY;
+      }
+    };
+    // the landed values -> slab buffer b
+    auto fill = [&](int b) {
+#pragma unroll
+      for (int r = 0; r < ROUNDS; ++r) {
+        const int it = lane + 64 * r;
+        const int v = it / KS, ky = it % KS;
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+          const bool hit = cell[r][kx] != GRID_EMPTY;
+          pairs += hit;
+          if (it < ITEMS) G[wv][b][v][kx + KS * ky] = hit ? __builtin_bit_cast(float, cell[r][kx]) : 0.f;
+        }
+      }
+    };
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    cells_of(0);
+    fill(0);
+    for (int kz = 0; kz < KS; ++kz) {
+      if (kz + 1 < KS) cells_of(kz + 1);          // in flight while this slab is multiplied
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const float *g = &G[wv][kz & 1][lane & 15][lane >> 4];
+      const f32x2 *w = reinterpret_cast<const f32x2 *>(wt) + (int64_t)kz * (RS / 4) * 64 + lane;
+#pragma unroll
+      for (int s = 0; s < RS / 4; ++s) {
+        const float b = g[4 * s];
+        const f32x2 a = w[s * 64];
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b, acc[1], 0, 0, 0);
+      }
+      if (kz + 1 < KS) fill((kz + 1) & 1);
+    }
+    const int64_t o = v0 + (lane & 15);
+    if (o < n) {
+#pragma unroll
+      for (int jb = 0; jb < 2; ++jb) {
+        f32x4 v = acc[jb];
+        if (shift) v += *reinterpret_cast<const f32x4 *>(shift + 16 * jb + 4 * (lane >> 4));
+        *reinterpret_cast<f32x4 *>(out + o * out_ld + 16 * jb + 4 * (lane >> 4)) = v;
+      }
     }
   }
-  if (pair_count) {
+  if (pair_count) {   // (statistics: one atomic per workgroup)
     for (int d = 32; d > 0; d >>= 1) pairs += __shfl_down(pairs, d, 64);
-    if (lane == 0) atomicAdd(pair_count, pairs);
+    if (lane == 0 && pairs) atomicAdd(&pair_sum, pairs);
+    __syncthreads();
+    if (threadIdx.x == 0 && pair_sum) atomicAdd(pair_count, pair_sum);
   }
 }
 
@@ -1003,7 +1037,10 @@ int dgr_conv1_probe(DgrArena &arena, const DgrCoordMap &cm, int ks, const float 
     grid_bbox_kernel<<<(int)dgr_ceil_div(cm.n_cap, 256), 256, 0, stream>>>(cm.coords, cm.n_dev, meta);
     grid_layout_kernel<<<1, 64, 0, stream>>>(meta, ks >> 1, cap);
     grid_clear_kernel<<<2048, 256, 0, stream>>>(meta, cells);
-    grid_fill_kernel<<<(int)dgr_ceil_div(cm.n_cap, 256), 256, 0, stream>>>(cm.coords, cm.n_dev, meta, ks >> 1, cells);
+    // one input channel + MFMA-tiled weights: the grid holds the input VALUES and conv1_grid_mfma does the layer
+    const bool mfma = cin == 1 && w_compact && (out_ld & 3) == 0 && (ks == 3 || ks == 5 || ks == 7);
+    grid_fill_kernel<<<(int)dgr_ceil_div(cm.n_cap, 256), 256, 0, stream>>>(cm.coords, cm.n_dev, meta, ks >> 1, cells,
+                                                                           mfma ? in : nullptr, in_ld);
     // grid-stride kernel: a whole number of resident rounds (a ragged last round costs up to 10 %)
     static int resident = 0;
     if (resident == 0) {
@@ -1013,11 +1050,11 @@ int dgr_conv1_probe(DgrArena &arena, const DgrCoordMap &cm, int ks, const float 
       DGR_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
       resident = (per_cu < 1 ? 1 : per_cu) * (cus < 1 ? 1 : cus);
     }
-    if (cin == 1 && w_compact && (out_ld & 3) == 0 && (ks == 3 || ks == 5 || ks == 7)) {
+    if (mfma) {
       const int wgs = (int)dgr_ceil_div(cm.n_cap, 64);
-      if (ks == 7) conv1_grid_mfma<7><<<wgs, 256, 0, stream>>>(cm.coords, cm.n_dev, meta, cells, in, in_ld, w_compact, shift, out, out_ld, pair_count);
-      else if (ks == 5) conv1_grid_mfma<5><<<wgs, 256, 0, stream>>>(cm.coords, cm.n_dev, meta, cells, in, in_ld, w_compact, shift, out, out_ld, pair_count);
-      else conv1_grid_mfma<3><<<wgs, 256, 0, stream>>>(cm.coords, cm.n_dev, meta, cells, in, in_ld, w_compact, shift, out, out_ld, pair_count);
+      if (ks == 7) conv1_grid_mfma<7><<<wgs, 256, 0, stream>>>(cm.coords, cm.n_dev, meta, cells, w_compact, shift, out, out_ld, pair_count);
+      else if (ks == 5) conv1_grid_mfma<5><<<wgs, 256, 0, stream>>>(cm.coords, cm.n_dev, meta, cells, w_compact, shift, out, out_ld, pair_count);
+      else conv1_grid_mfma<3><<<wgs, 256, 0, stream>>>(cm.coords, cm.n_dev, meta, cells, w_compact, shift, out, out_ld, pair_count);
       if (kernel_name) *kernel_name = ks == 7 ? "conv1_grid_mfma<7>" : ks == 5 ? "conv1_grid_mfma<5>" : "conv1_grid_mfma<3>";
     } else {
     int64_t blocks = dgr_ceil_div(cm.n_cap, 8);

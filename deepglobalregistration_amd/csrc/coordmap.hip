@@ -359,13 +359,16 @@ __global__ void bucket_count_kernel(const int32_t *__restrict__ keys4, const int
   atomicAdd(&counts[b], 1);
 }
 
+// entry of a bucket: the row's SECOND half (x1, y1, z1) and the row itself, contiguous per bucket -- the kernel-map search
+// scans a bucket's entries with sequential 16-byte reads instead of an index read + a dependent coordinate read per row
 __global__ void bucket_fill_kernel(const int32_t *__restrict__ row_bucket, const int32_t *n_dev,
                                    const int32_t *__restrict__ start, int32_t *cursor,
-                                   int32_t *__restrict__ rows) {
+                                   const int32_t *__restrict__ coords7, int4 *__restrict__ second) {
   int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= *n_dev) return;
   const int b = row_bucket[r];
-  rows[start[b] + atomicAdd(&cursor[b], 1)] = (int32_t)r;   // order inside a bucket is irrelevant
+  const int32_t *c = coords7 + r * 7;
+  second[start[b] + atomicAdd(&cursor[b], 1)] = make_int4(c[4], c[5], c[6], (int32_t)r);   // order inside a bucket is irrelevant
 }
 
 int dgr_build_half_buckets(DgrArena &arena, const DgrCoordMap &cm, DgrHalfBuckets *hb, hipStream_t stream) {
@@ -376,22 +379,21 @@ int dgr_build_half_buckets(DgrArena &arena, const DgrCoordMap &cm, DgrHalfBucket
   DGR_ALLOC(rank, arena, int32_t, n);
   DGR_ALLOC(nb_dev, arena, int32_t, 1);
   DGR_ALLOC(row_bucket, arena, int32_t, n);
-  DGR_ALLOC(counts, arena, int32_t, n + 1);
-  DGR_ALLOC(cursor, arena, int32_t, n + 1);
+  DGR_ALLOC(counts, arena, int32_t, 2 * (n + 1));   // counts | cursor: one clear
+  cursor = counts + (n + 1);
   DGR_ALLOC(hb->bkeys, arena, int32_t, n * 4);
   DGR_ALLOC(hb->start, arena, int32_t, n + 1);
-  DGR_ALLOC(hb->rows, arena, int32_t, n);
+  DGR_ALLOC(hb->second, arena, int4, n);
   half_keys_kernel<<<grid_for(n), 256, 0, stream>>>(cm.coords, cm.n_dev, keys);
   DGR_CHECK(unique_rows_t<4>(arena, keys, cm.n_dev, n, flag, rank, nb_dev, &hb->table, &hb->mask, stream));
   unique_compact<4><<<grid_for(n), 256, 0, stream>>>(keys, cm.n_dev, n, flag, rank, hb->bkeys, nullptr);
   table_relabel<<<grid_for((int64_t)hb->mask + 1), 256, 0, stream>>>(hb->table, hb->mask + 1, rank);
-  DGR_HIP_CHECK(hipMemsetAsync(counts, 0, (size_t)(n + 1) * sizeof(int32_t), stream));
-  DGR_HIP_CHECK(hipMemsetAsync(cursor, 0, (size_t)(n + 1) * sizeof(int32_t), stream));
+  DGR_HIP_CHECK(hipMemsetAsync(counts, 0, (size_t)2 * (n + 1) * sizeof(int32_t), stream));
   bucket_count_kernel<<<grid_for(n), 256, 0, stream>>>(keys, cm.n_dev, hb->table, hb->mask, hb->bkeys, row_bucket,
                                                        counts);
   DGR_LAUNCH_CHECK();
   DGR_CHECK(dgr_exclusive_scan_i32(arena, counts, hb->start, n + 1, nullptr, stream));
-  bucket_fill_kernel<<<grid_for(n), 256, 0, stream>>>(row_bucket, cm.n_dev, hb->start, cursor, hb->rows);
+  bucket_fill_kernel<<<grid_for(n), 256, 0, stream>>>(row_bucket, cm.n_dev, hb->start, cursor, cm.coords, hb->second);
   DGR_LAUNCH_CHECK();
   hb->built = true;
   return DGR_OK;

@@ -79,7 +79,8 @@ struct DgrArena {
 // ------------------------------------------------------------------------------------------
 // coordinate maps / kernel maps (coordmap.hip, kmap.hip)
 // ------------------------------------------------------------------------------------------
-constexpr int DGR_TILE_M = 64;  // pairs per MFMA tile of the sparse conv
+constexpr int DGR_TILE_M = 64;    // pairs per MFMA tile of the sparse conv
+constexpr int DGR_TILE_M2 = 128;  // ... of the widest 6-D layers (conv_wide.hip: one weight fragment serves 128 pairs)
 
 struct DgrCoordMap {
   int32_t *coords = nullptr;  // [n_cap, nc] row-major, nc = 1 + D
@@ -97,7 +98,7 @@ struct DgrHalfBuckets {
   int32_t *table = nullptr;   // half-key hash -> bucket id
   uint32_t mask = 0;
   int32_t *start = nullptr;   // [n_cap + 1] exclusive prefix of bucket sizes
-  int32_t *rows = nullptr;    // [n] row indices grouped by bucket
+  int4 *second = nullptr;     // [n] per bucket, contiguous: (x1, y1, z1, row) of its rows
   bool built = false;
 };
 
@@ -106,6 +107,8 @@ struct DgrKernelMap {
   int32_t *rule_ptr = nullptr;  // [K+1] exclusive prefix of pairs per offset
   int32_t *tile_ptr = nullptr;  // [K+1] exclusive prefix of DGR_TILE_M-tiles per offset
   int4 *tile_desc = nullptr;    // [tile_cap] (k, first pair, pair count, 0) of every tile
+  int32_t *tile_ptr2 = nullptr; // the same tiling in DGR_TILE_M2-pair tiles
+  int4 *tile_desc2 = nullptr;
   int64_t tile_cap = 0;
   int32_t *pair_in = nullptr;   // [pair_cap]
   int32_t *pair_out = nullptr;  // [pair_cap]
@@ -137,7 +140,7 @@ struct DgrMapSet {
   DgrNbrTable ndown[3];      // ts -> 2 ts        (out rows = coarse map)
   DgrNbrTable nup[3];        // 2 ts -> ts, transposed convs (out rows = fine map)
   DgrCoordMap cm[4];     // ts = 1,2,4,8
-  DgrHalfBuckets hb[4];  // D = 6: half-key buckets of cm[l] (built for l < 3)
+  DgrHalfBuckets hb[4];  // D = 6: half-key buckets of cm[l]
   DgrKernelMap same[4];  // 3^D at ts 1,2,4,8
   DgrKernelMap conv1;    // ks^D at ts = 1 (aliases same[0] when ks == 3)
   DgrKernelMap down[3];  // ts -> 2 ts (also used, swapped, by the transposed convs)
@@ -160,7 +163,7 @@ int dgr_unique_rows(DgrArena &arena, const int32_t *keys, int64_t n, int nc, int
                     hipStream_t stream);
 int dgr_exclusive_scan_i32(DgrArena &arena, const int32_t *in, int32_t *out, int64_t n,
                            int32_t *total_out, hipStream_t stream);
-constexpr int DGR_SCAN_MAX = 4;
+constexpr int DGR_SCAN_MAX = 24;   // (all seven 6-D kernel maps of a forward scan their 17 arrays in one call)
 // `count` independent exclusive scans in the same three launches (total_out / its entries may be null)
 int dgr_exclusive_scan_multi(DgrArena &arena, int count, const int32_t *const *in, int32_t *const *out, const int64_t *n,
                              int32_t *const *total_out, hipStream_t stream);

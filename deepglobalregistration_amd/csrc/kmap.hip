@@ -121,40 +121,51 @@ __device__ __forceinline__ unsigned long long hit_pack(int k, int64_t o, int64_t
 }
 // The hit list needs no global counter (one that is bumped per hit, per wave-call or even per 128-slot chunk serialises
 // on its one address at ~40 ns per atomic: measured 13 / 5.3 ms instead of 2.4 ms per batch): every wave of the search
-// owns a fixed REGION of the list, sized for the most records its 64 threads can produce, hands slots out from a
-// cursor in LDS and leaves its record count in wave_count[wave id].  The regions are address space, not traffic: only
-// the used prefix of a region is ever touched.
+// owns a fixed REGION of the list, hands slots out from a cursor in LDS and leaves its record count in
+// wave_count[wave id].  Round 3 sized a region for the most records 64 threads can produce (3456 for the pruned
+// symmetric search: 6 KB of arena per output row, of which a few per cent were ever written).  Now a region holds
+// KM_REGION records -- several times what a wave of the benchmark's maps produces -- and a wave that runs out of slots
+// marks itself (count -1): the bit matrix is complete either way, and the placing kernel REPLAYS the search of a marked
+// wave and places its pairs directly (positions depend on the bit matrix only).  Arena per output row: 0.9 KB
+// (symmetric maps) / 1.7 KB (strided maps).
+constexpr int KM_REGION = 512;
 struct HitList {
   unsigned long long *recs;   // [waves][region]
-  int32_t *wave_count;        // [waves]
+  int32_t *wave_count;        // [waves]; -1: the region overflowed, replay the wave
   int region;                 // records per wave
 };
-__device__ __forceinline__ int hit_wave_id() {
-  return (int)((blockIdx.y * gridDim.x + blockIdx.x) * (KM_THREADS / 64) + (threadIdx.x >> 6));
-}
 __device__ __forceinline__ void hit_begin(volatile int *cur) {
   if ((threadIdx.x & 63) == 0) cur[threadIdx.x >> 6] = 0;
 }
-// First of `n` (1 or 2) consecutive slots for this lane.  Called from divergent code by the lanes that found a pair:
-// the active lanes of the wave share one cursor update.
-__device__ __forceinline__ int64_t hit_slots(int n, const HitList &h, volatile int *cur) {
+// First of `n` (1 or 2) consecutive slots for this lane, or -1 once the wave's region is full.  Called from divergent
+// code by the lanes that found a pair: the active lanes of the wave share one cursor update.
+__device__ __forceinline__ int64_t hit_slots(int n, const HitList &h, volatile int *cur, int wave_id) {
   const unsigned long long act = __ballot(1), two = __ballot(n == 2);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const unsigned long long below = (1ull << lane) - 1ull;
   int base = 0;
   if (lane == __ffsll((long long)act) - 1) {
     base = cur[w];
-    cur[w] = base + __popcll(act) + __popcll(two);
+    const int need = __popcll(act) + __popcll(two);
+    if (base >= 0 && base + need <= h.region) {
+      cur[w] = base + need;
+    } else {
+      cur[w] = -1;
+      base = -1;
+    }
   }
   base = __builtin_amdgcn_readfirstlane(base);   // the first ACTIVE lane is the one that moved the cursor
-  return (int64_t)hit_wave_id() * h.region + base + __popcll(act & below) + __popcll(two & below);
+  if (base < 0) return -1;
+  return (int64_t)wave_id * h.region + base + __popcll(act & below) + __popcll(two & below);
 }
-__device__ __forceinline__ void hit_end(const HitList &h, volatile int *cur) {
-  if ((threadIdx.x & 63) == 0) h.wave_count[hit_wave_id()] = cur[threadIdx.x >> 6];
+__device__ __forceinline__ void hit_end(const HitList &h, volatile int *cur, int wave_id) {
+  if ((threadIdx.x & 63) == 0) h.wave_count[wave_id] = cur[threadIdx.x >> 6];
 }
 
 // generic search, bits only: grid = (row blocks, ceil(offsets to probe / 4)); a thread probes four consecutive
-// offsets of its row with the batched look-up (two memory latencies for the four probes)
+// offsets of its row with the batched look-up (two memory latencies for the four probes).  Its regions hold the most
+// a wave can produce (64 x (4 probes x 2 + the centre record)): no overflow, no replay.  Since round 4 the 6-D maps of
+// the network all take the pruned search below; this one stays for DGR_KMAP_GENERIC8=1 (A/B of the stride-8 map).
 constexpr int KM_PROBES = 4;
 template <int D>
 __global__ void __launch_bounds__(KM_THREADS)
@@ -165,14 +176,15 @@ __global__ void __launch_bounds__(KM_THREADS)
   constexpr int NC = D + 1;
   __shared__ int hit_cur[KM_THREADS / 64];
   hit_begin(hit_cur);
+  const int wid = (int)((blockIdx.y * gridDim.x + blockIdx.x) * (KM_THREADS / 64) + (threadIdx.x >> 6));
   const int k0 = blockIdx.y * KM_PROBES;
   const int64_t o = (int64_t)blockIdx.x * KM_THREADS + threadIdx.x;
   if (o < *n_out_dev) {
   if (symmetric && k0 == 0) {  // the centre offset always maps a row onto itself
     const int c = K >> 1;
     atomicOr(&mask_out[o * KW + (c >> 5)], 1u << (c & 31));
-    const int64_t s = hit_slots(1, hl, hit_cur);
-    hl.recs[s] = hit_pack(c, o, o);
+    const int64_t s = hit_slots(1, hl, hit_cur, wid);
+    if (s >= 0) hl.recs[s] = hit_pack(c, o, o);
   }
   int32_t base[NC];
 #pragma unroll
@@ -200,82 +212,94 @@ __global__ void __launch_bounds__(KM_THREADS)
       atomicOr(&mask_in[(int64_t)hit[u] * KW + (k >> 5)], 1u << (k & 31));
     }
     const int n = symmetric ? 2 : 1;   // (k < K / 2 here: the mirror is another pair)
-    const int64_t s = hit_slots(n, hl, hit_cur);
-    hl.recs[s] = hit_pack(k, o, hit[u]);
-    if (n == 2) hl.recs[s + 1] = hit_pack(km, hit[u], o);
+    const int64_t s = hit_slots(n, hl, hit_cur, wid);
+    if (s >= 0) {
+      hl.recs[s] = hit_pack(k, o, hit[u]);
+      if (n == 2) hl.recs[s + 1] = hit_pack(km, hit[u], o);
+    }
   }
   }
-  hit_end(hl, hit_cur);
+  hit_end(hl, hit_cur, wid);
 }
 
-// pruned search, bits only: one thread per (output row, first-half offset).  A 6-D neighbour
-// (ca + da, cb + db) can only exist among the rows whose first half equals ca + da: look that bucket
-// up once (27 -- symmetric: 14 -- lookups per row instead of 729 probes) and test the second half
-// of its rows.
-__global__ void __launch_bounds__(KM_THREADS)
-    kmap_bits_pruned6(const int32_t *__restrict__ out_coords, const int32_t *n_out_dev,
-                      const int32_t *__restrict__ in_coords, DgrHalfBuckets hb, int ts_in, int KW,
-                      int symmetric, uint32_t *mask_out, uint32_t *mask_in, HitList hl) {
-  __shared__ int hit_cur[KM_THREADS / 64];
-  hit_begin(hit_cur);
-  const int NJ = symmetric ? 14 : 27;
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// pruned search: one thread per (output row, first-half offset).  A 6-D neighbour (ca + da, cb + db) can only exist
+// among the rows whose first half equals ca + da: look that bucket up once (27 -- symmetric: 14 -- look-ups per row
+// instead of 729 probes) and test the second half of its entries, which lie contiguously in `hb.second` (sequential
+// 16-byte reads; round 3 read a row index and then, dependently, the row's coordinates per candidate -- at tensor
+// stride 8, where a bucket holds tens to hundreds of rows, that made the generic 364-probe search the cheaper one:
+// 449 us for the one stride-8 map of a batch).  `emit(k, o, in)` is called, from divergent code, by the lane that
+// found input row `in` under offset k of output row o; the search kernel sets bits and records the hit, the placing
+// kernel's replay of an overflowed wave places the pair.
+struct PrunedArgs {
+  const int32_t *out_coords, *n_out_dev;
+  DgrHalfBuckets hb;
+  int ts_in, symmetric;
+};
+template <class Emit>
+__device__ __forceinline__ void pruned_search6(const PrunedArgs &a, int64_t t, Emit &&emit) {
+  const int NJ = a.symmetric ? 14 : 27;
+  const int ts_in = a.ts_in;
   const int64_t o = t / NJ;
   const int ja = (int)(t - o * NJ);
   int b = -1;
-  const int32_t *co = out_coords + o * 7;
-  if (o < *n_out_dev) {
+  const int32_t *co = a.out_coords + o * 7;
+  if (o < *a.n_out_dev) {
     int32_t q[4];
     q[0] = co[0];
     q[1] = co[1] + ((ja % 3) - 1) * ts_in;
     q[2] = co[2] + (((ja / 3) % 3) - 1) * ts_in;
     q[3] = co[3] + ((ja / 9) - 1) * ts_in;
-    b = dgr_lookup<4>(hb.table, hb.mask, hb.bkeys, q);
+    b = dgr_lookup<4>(a.hb.table, a.hb.mask, a.hb.bkeys, q);
   }
-  // (no early return: every wave closes its last chunk of the hit list at the end)
   const int c4 = b >= 0 ? co[4] : 0, c5 = b >= 0 ? co[5] : 0, c6 = b >= 0 ? co[6] : 0;
-  const int beg = b >= 0 ? hb.start[b] : 0, end = b >= 0 ? hb.start[b + 1] : 0;
-  // four bucket rows per trip: their indices, then their second halves, are fetched together (a
-  // one-row-at-a-time loop pays two dependent L2 latencies per candidate)
+  const int beg = b >= 0 ? a.hb.start[b] : 0, end = b >= 0 ? a.hb.start[b + 1] : 0;
+  // four bucket entries per trip, fetched together
   for (int p0 = beg; p0 < end; p0 += 4) {
-    int r[4];
-    int32_t e4[4], e5[4], e6[4];
+    int4 e[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) r[u] = hb.rows[min(p0 + u, end - 1)];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int32_t *ci = in_coords + (int64_t)r[u] * 7;
-      e4[u] = ci[4]; e5[u] = ci[5]; e6[u] = ci[6];
-    }
+    for (int u = 0; u < 4; ++u) e[u] = a.hb.second[min(p0 + u, end - 1)];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (p0 + u >= end) break;
-      const int d4 = e4[u] - c4, d5 = e5[u] - c5, d6 = e6[u] - c6;
+      const int d4 = e[u].x - c4, d5 = e[u].y - c5, d6 = e[u].z - c6;
       // every component must be -ts, 0 or +ts (all coordinates of a level are multiples of ts)
       if (abs(d4) <= ts_in && abs(d5) <= ts_in && abs(d6) <= ts_in) {
         const int k = ja + 27 * ((d4 / ts_in + 1) + 3 * (d5 / ts_in + 1) + 9 * (d6 / ts_in + 1));
-        if (symmetric && ja == 13 && k > 364) continue;  // ja == 13 mirrors onto itself: upper half found from the other row
-        atomicOr(&mask_out[o * KW + (k >> 5)], 1u << (k & 31));
-        const int km = 728 - k;
-        if (symmetric) {
-          if (km != k) atomicOr(&mask_out[(int64_t)r[u] * KW + (km >> 5)], 1u << (km & 31));
-        } else if (mask_in) {
-          atomicOr(&mask_in[(int64_t)r[u] * KW + (k >> 5)], 1u << (k & 31));
-        }
-        const int n = (symmetric && km != k) ? 2 : 1;
-        const int64_t s = hit_slots(n, hl, hit_cur);
-        hl.recs[s] = hit_pack(k, o, r[u]);
-        if (n == 2) hl.recs[s + 1] = hit_pack(km, r[u], o);
+        if (a.symmetric && ja == 13 && k > 364) continue;  // ja == 13 mirrors onto itself: upper half found from the other row
+        emit(k, o, e[u].w);
       }
     }
   }
-  hit_end(hl, hit_cur);
+}
+
+__global__ void __launch_bounds__(KM_THREADS)
+    kmap_bits_pruned6(PrunedArgs a, int KW, uint32_t *mask_out, uint32_t *mask_in, HitList hl) {
+  __shared__ int hit_cur[KM_THREADS / 64];
+  hit_begin(hit_cur);
+  const int wid = (int)(blockIdx.x * (KM_THREADS / 64) + (threadIdx.x >> 6));
+  // (no early return: every wave leaves its record count behind)
+  pruned_search6(a, (int64_t)blockIdx.x * KM_THREADS + threadIdx.x, [&](int k, int64_t o, int in) {
+    atomicOr(&mask_out[o * KW + (k >> 5)], 1u << (k & 31));
+    const int km = 728 - k;
+    if (a.symmetric) {
+      if (km != k) atomicOr(&mask_out[(int64_t)in * KW + (km >> 5)], 1u << (km & 31));
+    } else if (mask_in) {
+      atomicOr(&mask_in[(int64_t)in * KW + (k >> 5)], 1u << (k & 31));
+    }
+    const int n = (a.symmetric && km != k) ? 2 : 1;
+    const int64_t s = hit_slots(n, hl, hit_cur, wid);
+    if (s >= 0) {
+      hl.recs[s] = hit_pack(k, o, in);
+      if (n == 2) hl.recs[s + 1] = hit_pack(km, in, o);
+    }
+  });
+  hit_end(hl, hit_cur, wid);
 }
 
 // transposed bit matrix: cell[g * K + k] = {rows of 64-row group g that have offset k (one ballot, 2 words),
 // rule-major position of the group's first pair of that offset, 0}; counts[k * RB + rb] = pairs of the
 // (offset, 256-row block) cell.  A pair's position = cell base (exclusive scan of counts) + the pairs of the earlier
-// groups of the same block (here) + its rank inside the group's ballot (kmap_place_hits).
+// groups of the same block (here) + its rank inside the group's ballot (place_pair).
 constexpr int KM_KMAX = 736;
 __global__ void __launch_bounds__(KM_THREADS)
     kmap_colmask(const uint32_t *__restrict__ mask_out, const int32_t *n_out_dev, int K, int KW, int RB,
@@ -313,37 +337,60 @@ __global__ void __launch_bounds__(KM_THREADS)
   }
 }
 
-// one wave per region of the hit list, one lane per record: places the pair.  pair_out / pair_k may be NULL (maps whose
-// consumers never read them): two random stores less per pair.
+// everything needed to put ONE pair (k, o) -> in into the map.  pair_out / pair_k may be NULL (maps whose consumers
+// never read them): two random stores less per pair.
+struct PlaceArgs {
+  int K, KW, RB;
+  const uint32_t *mask_out;
+  const int32_t *out_ptr;
+  const int4 *cell;
+  const int32_t *base;
+  int32_t *pair_in, *pair_out;
+  uint16_t *pair_k;
+  int32_t *out_pos;
+  int64_t pair_cap;
+  int32_t *overflow;
+  const uint32_t *mask_in;
+  const int32_t *in_ptr;
+  int32_t *in_pos;
+  const unsigned short *wpre_out, *wpre_in;
+};
+__device__ __forceinline__ void place_pair(const PlaceArgs &p, int k, int64_t o, int64_t in) {
+  const int64_t slot = (int64_t)p.out_ptr[o] + mask_rank_pre(p.mask_out + o * p.KW, p.wpre_out + o * p.KW, k);
+  const int64_t g = o >> 6;
+  const int4 c = p.cell[g * p.K + k];   // ONE 16-byte read: column ballot + pairs of the block's earlier groups
+  const unsigned long long cm = ((unsigned long long)(uint32_t)c.y << 32) | (uint32_t)c.x;
+  const int64_t pos = (int64_t)p.base[(int64_t)k * p.RB + (g >> 2)] + c.z + __popcll(cm & ((1ull << (o & 63)) - 1ull));
+  if (pos < p.pair_cap && slot < p.pair_cap) {
+    p.pair_in[pos] = (int32_t)in;
+    if (p.pair_out) p.pair_out[pos] = (int32_t)o;
+    if (p.pair_k) p.pair_k[pos] = (uint16_t)k;
+    p.out_pos[slot] = (int32_t)pos;
+    if (p.mask_in) p.in_pos[p.in_ptr[in] + mask_rank_pre(p.mask_in + in * p.KW, p.wpre_in + in * p.KW, k)] = (int32_t)pos;
+  } else {
+    *p.overflow = 2;
+  }
+}
+
+// one wave per region of the hit list: one lane per record places the pair; a wave whose region overflowed during the
+// search (count -1) repeats that wave's search and places what it finds (`replay.hb.table` NULL: the generic search,
+// whose regions cannot overflow)
 __global__ void __launch_bounds__(KM_THREADS)
-    kmap_place_hits(HitList h, int n_waves, int K, int KW, int RB, const uint32_t *__restrict__ mask_out,
-                    const int32_t *__restrict__ out_ptr, const int4 *__restrict__ cell, const int32_t *__restrict__ base,
-                    int32_t *__restrict__ pair_in, int32_t *__restrict__ pair_out, uint16_t *__restrict__ pair_k,
-                    int32_t *__restrict__ out_pos, int64_t pair_cap, int32_t *overflow,
-                    const uint32_t *__restrict__ mask_in, const int32_t *__restrict__ in_ptr,
-                    int32_t *__restrict__ in_pos, const unsigned short *__restrict__ wpre_out,
-                    const unsigned short *__restrict__ wpre_in) {
+    kmap_place_hits(HitList h, int n_waves, PlaceArgs p, PrunedArgs replay) {
   const int lane = threadIdx.x & 63;
   for (int r = blockIdx.x * (KM_THREADS / 64) + (threadIdx.x >> 6); r < n_waves; r += gridDim.x * (KM_THREADS / 64)) {
     const int n = h.wave_count[r];
+    if (n < 0) {
+      if (!replay.hb.table) { *p.overflow = 2; continue; }
+      pruned_search6(replay, (int64_t)r * 64 + lane, [&](int k, int64_t o, int in) {
+        place_pair(p, k, o, in);
+        if (replay.symmetric && 728 - k != k) place_pair(p, 728 - k, in, o);
+      });
+      continue;
+    }
     for (int e = lane; e < n; e += 64) {
       const unsigned long long rec = h.recs[(int64_t)r * h.region + e];
-      const int k = (int)(rec >> 54);
-      const int64_t o = (int64_t)((rec >> 27) & 0x7ffffffull), in = (int64_t)(rec & 0x7ffffffull);
-      const int64_t slot = (int64_t)out_ptr[o] + mask_rank_pre(mask_out + o * KW, wpre_out + o * KW, k);
-      const int64_t g = o >> 6;
-      const int4 c = cell[g * K + k];   // ONE 16-byte read: column ballot + pairs of the block's earlier groups
-      const unsigned long long cm = ((unsigned long long)(uint32_t)c.y << 32) | (uint32_t)c.x;
-      const int64_t pos = (int64_t)base[(int64_t)k * RB + (g >> 2)] + c.z + __popcll(cm & ((1ull << (o & 63)) - 1ull));
-      if (pos < pair_cap && slot < pair_cap) {
-        pair_in[pos] = (int32_t)in;
-        if (pair_out) pair_out[pos] = (int32_t)o;
-        if (pair_k) pair_k[pos] = (uint16_t)k;
-        out_pos[slot] = (int32_t)pos;
-        if (mask_in) in_pos[in_ptr[in] + mask_rank_pre(mask_in + in * KW, wpre_in + in * KW, k)] = (int32_t)pos;
-      } else {
-        *overflow = 2;
-      }
+      place_pair(p, (int)(rec >> 54), (int64_t)((rec >> 27) & 0x7ffffffull), (int64_t)(rec & 0x7ffffffull));
     }
   }
 }
@@ -397,185 +444,282 @@ __global__ void __launch_bounds__(KM_THREADS)
   }
 }
 
-// rule_ptr[k] = block_base[k * RB], rule_ptr[K] = total; tile_ptr = exclusive scan of
-// ceil(P_k / TILE_M).  One block, K <= 1024.
-__global__ void __launch_bounds__(1024)
-    kmap_finalize(const int32_t *__restrict__ block_base, const int32_t *__restrict__ total, int K,
-                  int RB, int32_t *__restrict__ rule_ptr, int32_t *__restrict__ tile_ptr) {
-  __shared__ int s[1024];
+// Finalisation of up to KM_MAXJOBS kernel maps in ONE launch each (blockIdx.x / blockIdx.y = map): the seven 6-D maps of
+// a forward reach this point together (build_kernel_maps6).
+constexpr int KM_MAXJOBS = 8;
+struct FinalizeJobs {
+  const int32_t *base[KM_MAXJOBS], *total[KM_MAXJOBS];
+  int32_t *rule_ptr[KM_MAXJOBS], *tile_ptr[KM_MAXJOBS], *tile_ptr2[KM_MAXJOBS];
+  int4 *desc[KM_MAXJOBS], *desc2[KM_MAXJOBS];
+  long long tile_cap[KM_MAXJOBS];
+  int K[KM_MAXJOBS], RB[KM_MAXJOBS];
+};
+// rule_ptr[k] = block_base[k * RB], rule_ptr[K] = total; tile_ptr / tile_ptr2 = exclusive scans of
+// ceil(P_k / DGR_TILE_M) and ceil(P_k / DGR_TILE_M2).  One block per map, K <= 1024.
+__global__ void __launch_bounds__(1024) kmap_finalize(FinalizeJobs j) {
+  __shared__ int s[1024], s2[1024];
+  const int m = blockIdx.x, K = j.K[m], RB = j.RB[m];
+  const int32_t *block_base = j.base[m];
   const int k = threadIdx.x;
   int start = 0, end = 0;
   if (k < K) {
     start = block_base[(int64_t)k * RB];
-    end = (k + 1 < K) ? block_base[(int64_t)(k + 1) * RB] : *total;
-    rule_ptr[k] = start;
-    if (k == K - 1) rule_ptr[K] = end;
+    end = (k + 1 < K) ? block_base[(int64_t)(k + 1) * RB] : *j.total[m];
+    j.rule_ptr[m][k] = start;
+    if (k == K - 1) j.rule_ptr[m][K] = end;
   }
-  int tiles = (end - start + DGR_TILE_M - 1) / DGR_TILE_M;
-  s[k] = tiles;
+  const int tiles = (end - start + DGR_TILE_M - 1) / DGR_TILE_M, tiles2 = (end - start + DGR_TILE_M2 - 1) / DGR_TILE_M2;
+  s[k] = tiles; s2[k] = tiles2;
   __syncthreads();
   for (int d = 1; d < 1024; d <<= 1) {
-    int v = (k >= d) ? s[k - d] : 0;
+    const int v = (k >= d) ? s[k - d] : 0, v2 = (k >= d) ? s2[k - d] : 0;
     __syncthreads();
-    s[k] += v;
+    s[k] += v; s2[k] += v2;
     __syncthreads();
   }
-  if (k < K) tile_ptr[k] = s[k] - tiles;
-  if (k == K - 1) tile_ptr[K] = s[k];
+  if (k < K) { j.tile_ptr[m][k] = s[k] - tiles; j.tile_ptr2[m][k] = s2[k] - tiles2; }
+  if (k == K - 1) { j.tile_ptr[m][K] = s[k]; j.tile_ptr2[m][K] = s2[k]; }
 }
 
 // one thread per tile: (k, first pair, pair count) so that the conv kernels fetch a tile with ONE
 // 16-byte load instead of a 10-step binary search over tile_ptr on their critical path
-__global__ void tile_desc_kernel(const int32_t *__restrict__ tile_ptr, const int32_t *__restrict__ rule_ptr, int K,
-                                 int4 *__restrict__ desc, int64_t tile_cap) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void tile_desc_one(const int32_t *__restrict__ tile_ptr, const int32_t *__restrict__ rule_ptr, int K,
+                                              int4 *__restrict__ desc, int64_t tile_cap, int64_t t, int tile_m) {
   if (t >= tile_cap || t >= tile_ptr[K]) return;
   int lo = 0, hi = K;
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
     if (tile_ptr[mid] <= t) lo = mid; else hi = mid;
   }
-  const int pstart = rule_ptr[lo] + ((int)t - tile_ptr[lo]) * DGR_TILE_M;
-  desc[t] = make_int4(lo, pstart, min(DGR_TILE_M, rule_ptr[lo + 1] - pstart), 0);
+  const int pstart = rule_ptr[lo] + ((int)t - tile_ptr[lo]) * tile_m;
+  desc[t] = make_int4(lo, pstart, min(tile_m, rule_ptr[lo + 1] - pstart), 0);
+}
+__global__ void tile_desc_kernel(FinalizeJobs j) {
+  const int m = blockIdx.y;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  tile_desc_one(j.tile_ptr[m], j.rule_ptr[m], j.K[m], j.desc[m], j.tile_cap[m], t, DGR_TILE_M);
+  tile_desc_one(j.tile_ptr2[m], j.rule_ptr[m], j.K[m], j.desc2[m], j.tile_cap[m], t, DGR_TILE_M2);
 }
 
-template <int D>
-static int build_kernel_map_t(DgrArena &arena, const DgrCoordMap &in, const DgrCoordMap &out,
-                              const DgrHalfBuckets *in_buckets, int ks, int max_pairs_per_row,
-                              bool need_in_csr, bool want_pair_out, bool want_pair_k, DgrKernelMap *km,
-                              int32_t *overflow, hipStream_t stream) {
-  int K = 1;
-  for (int d = 0; d < D; ++d) K *= ks;
+// the parts of a kernel map that outlive the build
+static int alloc_kernel_map(DgrArena &arena, int K, int64_t n_cap, int64_t n_in_cap, int max_pairs_per_row, bool need_in_csr,
+                            bool want_pair_out, bool want_pair_k, DgrKernelMap *km) {
   DGR_REQUIRE(K <= 1024, "kernel volume %d > 1024 not supported", K);
   km->K = K;
-  const int64_t n_cap = out.n_cap;
-  const int RB = (int)dgr_ceil_div(n_cap, KM_THREADS);
-  int64_t per_row = K < max_pairs_per_row ? K : max_pairs_per_row;
+  const int64_t per_row = K < max_pairs_per_row ? K : max_pairs_per_row;
   km->pair_cap = per_row * n_cap;
   DGR_REQUIRE(km->pair_cap < (1ll << 31), "kernel map too large (%lld pairs)", (long long)km->pair_cap);
   DGR_ALLOC(km->rule_ptr, arena, int32_t, K + 1);
   DGR_ALLOC(km->tile_ptr, arena, int32_t, K + 1);
+  DGR_ALLOC(km->tile_ptr2, arena, int32_t, K + 1);
   DGR_ALLOC(km->pair_in, arena, int32_t, km->pair_cap);
   km->pair_out = nullptr;
   if (want_pair_out) DGR_ALLOC(km->pair_out, arena, int32_t, km->pair_cap);
   km->tile_cap = km->pair_cap / DGR_TILE_M + K;
   DGR_ALLOC(km->tile_desc, arena, int4, km->tile_cap);
+  DGR_ALLOC(km->tile_desc2, arena, int4, km->tile_cap);
   DGR_ALLOC(km->out_ptr, arena, int32_t, n_cap + 1);
   DGR_ALLOC(km->out_pos, arena, int32_t, km->pair_cap);
   km->pair_k = nullptr;
   if (want_pair_k) DGR_ALLOC(km->pair_k, arena, uint16_t, km->pair_cap);
-  const int64_t n_in_cap = in.n_cap;
   if (need_in_csr) {
     DGR_ALLOC(km->in_ptr, arena, int32_t, n_in_cap + 1);
     DGR_ALLOC(km->in_pos, arena, int32_t, km->pair_cap);
   }
+  return DGR_OK;
+}
+
+static void finalize_job(FinalizeJobs &fj, int m, const int32_t *base, const int32_t *total, int K, int RB, DgrKernelMap *km) {
+  fj.base[m] = base; fj.total[m] = total; fj.K[m] = K; fj.RB[m] = RB;
+  fj.rule_ptr[m] = km->rule_ptr; fj.tile_ptr[m] = km->tile_ptr; fj.tile_ptr2[m] = km->tile_ptr2;
+  fj.desc[m] = km->tile_desc; fj.desc2[m] = km->tile_desc2; fj.tile_cap[m] = km->tile_cap;
+}
+
+// D = 3 (rule-major maps of 3-D nets that do not run on neighbour tables; the stand-alone maps object): one map per call
+static int build_kernel_map3(DgrArena &arena, const DgrCoordMap &in, const DgrCoordMap &out, int ks, int max_pairs_per_row,
+                             bool need_in_csr, bool want_pair_out, bool want_pair_k, DgrKernelMap *km,
+                             int32_t *overflow, hipStream_t stream) {
+  constexpr int D = 3;
+  const int K = ks * ks * ks;
+  const int64_t n_cap = out.n_cap, n_in_cap = in.n_cap;
+  const int RB = (int)dgr_ceil_div(n_cap, KM_THREADS);
+  DGR_CHECK(alloc_kernel_map(arena, K, n_cap, n_in_cap, max_pairs_per_row, need_in_csr, want_pair_out, want_pair_k, km));
   const int KW = (K + 31) / 32;
-  // transients (released after the last pass): per-(offset, block) counts, row bitmasks and either the
-  // dense hit cache [K, n_cap] (D = 3) or the transposed bit matrix (D = 6)
+  // transients (released after the last pass): per-(offset, block) counts, row bitmasks and the dense hit cache [K, n_cap]
   DgrArena::Mark mk = arena.mark();
   int32_t *counts, *base, *total;
   DGR_ALLOC(counts, arena, int32_t, (int64_t)K * RB);
   DGR_ALLOC(base, arena, int32_t, (int64_t)K * RB);
   DGR_ALLOC(total, arena, int32_t, 1);
-  // the two bit matrices (out rows; in rows for maps used swapped) and the row counts of the 6-D path come out of
-  // ONE allocation: one clear
   uint32_t *mask_out, *mask_in = nullptr;
   int32_t *cnt_out, *cnt_in = nullptr;
   {
     const size_t w_out = (size_t)(n_cap + 1) * KW, w_in = need_in_csr ? (size_t)(n_in_cap + 1) * KW : 0;
-    const size_t w_cnt = D == 6 ? (size_t)(n_cap + 1) : 0;
-    DGR_ALLOC(mask_out, arena, uint32_t, w_out + w_in + w_cnt);
+    DGR_ALLOC(mask_out, arena, uint32_t, w_out + w_in);
     if (need_in_csr) mask_in = mask_out + w_out;
-    DGR_HIP_CHECK(hipMemsetAsync(mask_out, 0, (w_out + w_in + w_cnt) * sizeof(uint32_t), stream));
-    if (D == 6) {
-      cnt_out = reinterpret_cast<int32_t *>(mask_out + w_out + w_in);
-    } else {
-      DGR_ALLOC(cnt_out, arena, int32_t, n_cap + 1);
-    }
+    DGR_HIP_CHECK(hipMemsetAsync(mask_out, 0, (w_out + w_in) * sizeof(uint32_t), stream));
   }
+  DGR_ALLOC(cnt_out, arena, int32_t, n_cap + 1);
   if (need_in_csr) DGR_ALLOC(cnt_in, arena, int32_t, n_in_cap + 1);
-  int32_t *hits = nullptr;
-  int4 *cell = nullptr;
-  int64_t n_cells = 0;
-  unsigned long long *hit_list = nullptr;
-  int32_t *hit_wave_count = nullptr;
-  unsigned short *wpre_out = nullptr, *wpre_in = nullptr;
-  int64_t hit_waves = 0;
-  int hit_region = 0;
-  if constexpr (D == 6) {
-    DGR_REQUIRE(ks == 3, "6-D kernel maps support kernel size 3 only (got %d)", ks);
-    DGR_REQUIRE(n_cap < (1ll << 27) && n_in_cap < (1ll << 27), "6-D kernel maps: more than 2^27 rows");
-    n_cells = (int64_t)RB * (KM_THREADS / 64) * K;
-    DGR_ALLOC(cell, arena, int4, n_cells);
-    // hit list: one region per wave of the search, sized for the most records 64 of its threads can produce
-    // (pruned: 27 second halves per (row, first half), generic: KM_PROBES probes per thread + the centre record; twice
-    // that for symmetric maps, where a hit is recorded with its mirror)
-    const int symmetric0 = (in.coords == out.coords && !need_in_csr) ? 1 : 0;
-    const bool pruned = in_buckets && in_buckets->built && ks == 3;
-    const int64_t search_blocks = pruned ? dgr_ceil_div(n_cap * (symmetric0 ? 14 : 27), KM_THREADS)
-                                         : (int64_t)RB * dgr_ceil_div(symmetric0 ? K / 2 : K, KM_PROBES);
-    hit_waves = search_blocks * (KM_THREADS / 64);
-    hit_region = 64 * ((pruned ? 27 : KM_PROBES) * (symmetric0 ? 2 : 1) + (pruned ? 0 : 1));
-    DGR_REQUIRE(hit_waves < (1ll << 31), "6-D kernel map: too many search waves");
-    DGR_ALLOC(hit_list, arena, unsigned long long, hit_waves * hit_region);
-    DGR_ALLOC(hit_wave_count, arena, int32_t, hit_waves);
-    DGR_ALLOC(wpre_out, arena, unsigned short, (n_cap + 1) * KW);
-    if (need_in_csr) DGR_ALLOC(wpre_in, arena, unsigned short, (n_in_cap + 1) * KW);
-    // same-stride maps (in and out are the SAME coordinate set) are symmetric: search half the offsets
-    const int symmetric = (in.coords == out.coords && !need_in_csr) ? 1 : 0;
-    if (in_buckets && in_buckets->built && ks == 3) {
-      const int64_t threads = n_cap * (symmetric ? 14 : 27);
-      kmap_bits_pruned6<<<(int)dgr_ceil_div(threads, KM_THREADS), KM_THREADS, 0, stream>>>(
-          out.coords, out.n_dev, in.coords, *in_buckets, in.ts, KW, symmetric, mask_out, mask_in,
-          HitList{hit_list, hit_wave_count, hit_region});
-    } else {
-      const int n_probe = symmetric ? K / 2 : K;
-      dim3 grid(RB, (n_probe + KM_PROBES - 1) / KM_PROBES);
-      kmap_bits<D><<<grid, KM_THREADS, 0, stream>>>(out.coords, out.n_dev, in.coords, in.table, in.table_mask, ks,
-                                                    in.ts, K, KW, n_probe, symmetric, mask_out, mask_in,
-                                                    HitList{hit_list, hit_wave_count, hit_region});
-    }
-    DGR_LAUNCH_CHECK();
-    kmap_colmask<<<RB, KM_THREADS, 0, stream>>>(mask_out, out.n_dev, K, KW, RB, cell, counts, cnt_out, wpre_out);
-  } else {
-    DGR_ALLOC(hits, arena, int32_t, (int64_t)K * n_cap);
-    dim3 grid(RB, K);
-    kmap_search<D><<<grid, KM_THREADS, 0, stream>>>(out.coords, out.n_dev, in.coords, in.table,
-                                                    in.table_mask, ks, in.ts, RB, n_cap, hits, counts, KW,
-                                                    mask_out, mask_in);
-  }
+  int32_t *hits;
+  DGR_ALLOC(hits, arena, int32_t, (int64_t)K * n_cap);
+  kmap_search<D><<<dim3(RB, K), KM_THREADS, 0, stream>>>(out.coords, out.n_dev, in.coords, in.table, in.table_mask, ks,
+                                                         in.ts, RB, n_cap, hits, counts, KW, mask_out, mask_in);
   DGR_LAUNCH_CHECK();
-  // per-row pair counts -> CSR row pointers (out rows -- 6-D: counted by kmap_colmask; in rows for maps used swapped)
-  if (D != 6)
-    mask_count_kernel<<<(int)dgr_ceil_div(n_cap + 1, 256), 256, 0, stream>>>(mask_out, KW, out.n_dev, n_cap + 1, cnt_out);
+  // per-row pair counts -> CSR row pointers (out rows; in rows for maps used swapped)
+  mask_count_kernel<<<(int)dgr_ceil_div(n_cap + 1, 256), 256, 0, stream>>>(mask_out, KW, out.n_dev, n_cap + 1, cnt_out);
   if (need_in_csr)
-    mask_count_kernel<<<(int)dgr_ceil_div(n_in_cap + 1, 256), 256, 0, stream>>>(mask_in, KW, in.n_dev, n_in_cap + 1, cnt_in,
-                                                                               wpre_in);
+    mask_count_kernel<<<(int)dgr_ceil_div(n_in_cap + 1, 256), 256, 0, stream>>>(mask_in, KW, in.n_dev, n_in_cap + 1, cnt_in);
   {
-    // row pointers of the out-major CSR (and of the in-major one for maps used swapped) + the cell bases: one
-    // multi-array scan = three launches for all of them
     const int32_t *ins[3] = {cnt_out, counts, cnt_in};
     int32_t *outs[3] = {km->out_ptr, base, km->in_ptr}, *tots[3] = {nullptr, total, nullptr};
     const int64_t ns[3] = {n_cap + 1, (int64_t)K * RB, n_in_cap + 1};
     DGR_CHECK(dgr_exclusive_scan_multi(arena, need_in_csr ? 3 : 2, ins, outs, ns, tots, stream));
   }
-  kmap_finalize<<<1, 1024, 0, stream>>>(base, total, K, RB, km->rule_ptr, km->tile_ptr);
-  tile_desc_kernel<<<(int)dgr_ceil_div(km->tile_cap, 256), 256, 0, stream>>>(km->tile_ptr, km->rule_ptr, K,
-                                                                            km->tile_desc, km->tile_cap);
-  if constexpr (D == 6) {
-    const int blocks = (int)std::min<int64_t>(dgr_ceil_div(hit_waves, KM_THREADS / 64), 16384);
-    kmap_place_hits<<<blocks, KM_THREADS, 0, stream>>>(HitList{hit_list, hit_wave_count, hit_region}, (int)hit_waves, K, KW, RB, mask_out, km->out_ptr,
-                                                       cell, base, km->pair_in, km->pair_out, km->pair_k, km->out_pos,
-                                                       km->pair_cap, overflow, mask_in, km->in_ptr, km->in_pos, wpre_out, wpre_in);
-  } else {
-    dim3 fill_grid(RB, (K + KM_KGROUP - 1) / KM_KGROUP);
-    kmap_fill<<<fill_grid, KM_THREADS, 0, stream>>>(out.n_dev, RB, K, n_cap, hits, counts, base, km->pair_in,
-                                                    km->pair_out, km->pair_cap, overflow, KW, mask_out, km->out_ptr,
-                                                    km->out_pos, mask_in, km->in_ptr, km->in_pos, km->pair_k);
-  }
+  FinalizeJobs fj = {};
+  finalize_job(fj, 0, base, total, K, RB, km);
+  kmap_finalize<<<1, 1024, 0, stream>>>(fj);
+  tile_desc_kernel<<<dim3((unsigned)dgr_ceil_div(km->tile_cap, 256), 1), 256, 0, stream>>>(fj);
+  kmap_fill<<<dim3(RB, (K + KM_KGROUP - 1) / KM_KGROUP), KM_THREADS, 0, stream>>>(
+      out.n_dev, RB, K, n_cap, hits, counts, base, km->pair_in, km->pair_out, km->pair_cap, overflow, KW, mask_out,
+      km->out_ptr, km->out_pos, mask_in, km->in_ptr, km->in_pos, km->pair_k);
   DGR_LAUNCH_CHECK();
   arena.rewind(mk);
   km->built = true;
+  return DGR_OK;
+}
+
+// D = 6: ALL kernel maps of a sparse tensor (four same-stride maps, three strided ones) are built phase by phase
+// together -- one clear for all bit matrices, the searches and transposing passes back to back, ONE multi-array scan
+// (17 arrays), one finalisation launch, one tile-descriptor launch, then the placing passes.  Round 3 built map after
+// map: 21 scan launches, 7 finalisations, 7 descriptor launches and 7 clears per forward, ~5 us each and nothing else
+// running next to them.
+struct Kmap6Job {
+  const DgrCoordMap *in, *out;
+  const DgrHalfBuckets *hb;     // first-half buckets of `in`
+  bool need_in_csr, want_pair_out, want_pair_k;
+  DgrKernelMap *km;
+};
+static int build_kernel_maps6(DgrArena &arena, const Kmap6Job *jobs, int nj, int max_pairs_per_row, int32_t *overflow,
+                              hipStream_t stream) {
+  constexpr int K = 729, KW = (K + 31) / 32;
+  DGR_REQUIRE(nj >= 1 && nj <= KM_MAXJOBS, "6-D kernel maps: %d jobs", nj);
+  static const bool generic8 = getenv("DGR_KMAP_GENERIC8") != nullptr;   // A/B: the stride-8 map by 364 hash probes per row
+  struct Tr {   // transients of one job
+    int RB, symmetric;
+    bool pruned;
+    int64_t n_cap, n_in_cap, hit_waves;
+    int32_t *counts, *base, *total, *cnt_out, *cnt_in;
+    uint32_t *mask_out, *mask_in;
+    int4 *cell;
+    HitList hl;
+    unsigned short *wpre_out, *wpre_in;
+  } t[KM_MAXJOBS];
+  for (int m = 0; m < nj; ++m) {
+    const Kmap6Job &J = jobs[m];
+    t[m].n_cap = J.out->n_cap; t[m].n_in_cap = J.in->n_cap;
+    DGR_REQUIRE(t[m].n_cap < (1ll << 27) && t[m].n_in_cap < (1ll << 27), "6-D kernel maps: more than 2^27 rows");
+    DGR_CHECK(alloc_kernel_map(arena, K, t[m].n_cap, t[m].n_in_cap, max_pairs_per_row, J.need_in_csr, J.want_pair_out,
+                               J.want_pair_k, J.km));
+  }
+  DgrArena::Mark mk = arena.mark();
+  // the bit matrices (out rows; in rows for maps used swapped) and the row counts of ALL jobs: one allocation, one clear
+  {
+    size_t words = 0;
+    for (int m = 0; m < nj; ++m)
+      words += (size_t)(t[m].n_cap + 1) * KW + (jobs[m].need_in_csr ? (size_t)(t[m].n_in_cap + 1) * KW : 0) + (size_t)(t[m].n_cap + 1);
+    uint32_t *pool;
+    DGR_ALLOC(pool, arena, uint32_t, words);
+    DGR_HIP_CHECK(hipMemsetAsync(pool, 0, words * sizeof(uint32_t), stream));
+    for (int m = 0; m < nj; ++m) {
+      t[m].mask_out = pool; pool += (size_t)(t[m].n_cap + 1) * KW;
+      t[m].mask_in = nullptr;
+      if (jobs[m].need_in_csr) { t[m].mask_in = pool; pool += (size_t)(t[m].n_in_cap + 1) * KW; }
+      t[m].cnt_out = reinterpret_cast<int32_t *>(pool); pool += (size_t)(t[m].n_cap + 1);
+    }
+  }
+  for (int m = 0; m < nj; ++m) {
+    const Kmap6Job &J = jobs[m];
+    Tr &r = t[m];
+    r.RB = (int)dgr_ceil_div(r.n_cap, KM_THREADS);
+    // same-stride maps (in and out are the SAME coordinate set) are symmetric: search half the offsets
+    r.symmetric = (J.in->coords == J.out->coords && !J.need_in_csr) ? 1 : 0;
+    r.pruned = J.hb && J.hb->built && !(generic8 && J.in->ts == 8 && r.symmetric);
+    DGR_ALLOC(r.counts, arena, int32_t, (int64_t)K * r.RB);
+    DGR_ALLOC(r.base, arena, int32_t, (int64_t)K * r.RB);
+    DGR_ALLOC(r.total, arena, int32_t, 1);
+    r.cnt_in = nullptr;
+    if (J.need_in_csr) DGR_ALLOC(r.cnt_in, arena, int32_t, r.n_in_cap + 1);
+    DGR_ALLOC(r.cell, arena, int4, (int64_t)r.RB * (KM_THREADS / 64) * K);
+    // hit list: one region per wave of the search (pruned: KM_REGION records, overflow -> replay; generic: the most 64
+    // of its threads can produce)
+    const int64_t search_blocks = r.pruned ? dgr_ceil_div(r.n_cap * (r.symmetric ? 14 : 27), KM_THREADS)
+                                           : (int64_t)r.RB * dgr_ceil_div(r.symmetric ? K / 2 : K, KM_PROBES);
+    r.hit_waves = search_blocks * (KM_THREADS / 64);
+    // (fine levels: 2 .. 7 neighbours per row, a wave records a few dozen hits; stride 4 / 8: up to a few hundred)
+    r.hl.region = r.pruned ? (J.in->ts >= 4 ? KM_REGION : KM_REGION / 2) : 64 * (KM_PROBES * (r.symmetric ? 2 : 1) + 1);
+    DGR_REQUIRE(r.hit_waves < (1ll << 31), "6-D kernel map: too many search waves");
+    DGR_ALLOC(r.hl.recs, arena, unsigned long long, r.hit_waves * r.hl.region);
+    DGR_ALLOC(r.hl.wave_count, arena, int32_t, r.hit_waves);
+    DGR_ALLOC(r.wpre_out, arena, unsigned short, (r.n_cap + 1) * KW);
+    r.wpre_in = nullptr;
+    if (J.need_in_csr) DGR_ALLOC(r.wpre_in, arena, unsigned short, (r.n_in_cap + 1) * KW);
+  }
+  // ---- search (bits + hit records), transpose / count
+  for (int m = 0; m < nj; ++m) {
+    const Kmap6Job &J = jobs[m];
+    Tr &r = t[m];
+    if (r.pruned) {
+      const PrunedArgs pa{J.out->coords, J.out->n_dev, *J.hb, J.in->ts, r.symmetric};
+      kmap_bits_pruned6<<<(int)(r.hit_waves / (KM_THREADS / 64)), KM_THREADS, 0, stream>>>(pa, KW, r.mask_out, r.mask_in, r.hl);
+    } else {
+      const int n_probe = r.symmetric ? K / 2 : K;
+      kmap_bits<6><<<dim3(r.RB, (n_probe + KM_PROBES - 1) / KM_PROBES), KM_THREADS, 0, stream>>>(
+          J.out->coords, J.out->n_dev, J.in->coords, J.in->table, J.in->table_mask, 3, J.in->ts, K, KW, n_probe, r.symmetric,
+          r.mask_out, r.mask_in, r.hl);
+    }
+    kmap_colmask<<<r.RB, KM_THREADS, 0, stream>>>(r.mask_out, J.out->n_dev, K, KW, r.RB, r.cell, r.counts, r.cnt_out, r.wpre_out);
+    if (J.need_in_csr)
+      mask_count_kernel<<<(int)dgr_ceil_div(r.n_in_cap + 1, 256), 256, 0, stream>>>(r.mask_in, KW, J.in->n_dev, r.n_in_cap + 1,
+                                                                                  r.cnt_in, r.wpre_in);
+  }
+  DGR_LAUNCH_CHECK();
+  // ---- every scan of every map: CSR row pointers (out rows; in rows for maps used swapped) and the cell bases
+  {
+    const int32_t *ins[DGR_SCAN_MAX];
+    int32_t *outs[DGR_SCAN_MAX], *tots[DGR_SCAN_MAX];
+    int64_t ns[DGR_SCAN_MAX];
+    int c = 0;
+    for (int m = 0; m < nj; ++m) {
+      ins[c] = t[m].cnt_out; outs[c] = jobs[m].km->out_ptr; tots[c] = nullptr; ns[c++] = t[m].n_cap + 1;
+      ins[c] = t[m].counts; outs[c] = t[m].base; tots[c] = t[m].total; ns[c++] = (int64_t)K * t[m].RB;
+      if (jobs[m].need_in_csr) { ins[c] = t[m].cnt_in; outs[c] = jobs[m].km->in_ptr; tots[c] = nullptr; ns[c++] = t[m].n_in_cap + 1; }
+    }
+    DGR_CHECK(dgr_exclusive_scan_multi(arena, c, ins, outs, ns, tots, stream));
+  }
+  FinalizeJobs fj = {};
+  int64_t max_tiles = 0;
+  for (int m = 0; m < nj; ++m) {
+    finalize_job(fj, m, t[m].base, t[m].total, K, t[m].RB, jobs[m].km);
+    max_tiles = std::max<int64_t>(max_tiles, jobs[m].km->tile_cap);
+  }
+  kmap_finalize<<<nj, 1024, 0, stream>>>(fj);
+  tile_desc_kernel<<<dim3((unsigned)dgr_ceil_div(max_tiles, 256), nj), 256, 0, stream>>>(fj);
+  // ---- place
+  for (int m = 0; m < nj; ++m) {
+    const Kmap6Job &J = jobs[m];
+    Tr &r = t[m];
+    DgrKernelMap *km = J.km;
+    const PlaceArgs pl{K, KW, r.RB, r.mask_out, km->out_ptr, r.cell, r.base, km->pair_in, km->pair_out, km->pair_k, km->out_pos,
+                       km->pair_cap, overflow, r.mask_in, km->in_ptr, km->in_pos, r.wpre_out, r.wpre_in};
+    PrunedArgs pa{J.out->coords, J.out->n_dev, DgrHalfBuckets(), J.in->ts, r.symmetric};
+    if (r.pruned) pa.hb = *J.hb;
+    const int blocks = (int)std::min<int64_t>(dgr_ceil_div(r.hit_waves, KM_THREADS / 64), 16384);
+    kmap_place_hits<<<blocks, KM_THREADS, 0, stream>>>(r.hl, (int)r.hit_waves, pl, pa);
+    km->built = true;
+  }
+  DGR_LAUNCH_CHECK();
+  arena.rewind(mk);
   return DGR_OK;
 }
 
@@ -679,35 +823,39 @@ int dgr_build_maps(DgrArena &arena, const int32_t *coords, int64_t N, int D, int
     }
     if (lean) {   // the network forward needs nothing else (conv1 runs fused with its neighbour search)
       if (conv1_ks != 3 && !skip_conv1_map)
-        DGR_CHECK(build_kernel_map_t<3>(arena, ms->cm[0], ms->cm[0], nullptr, conv1_ks, 1024, false, false, true, &ms->conv1,
-                                        ms->overflow, stream));
+        DGR_CHECK(build_kernel_map3(arena, ms->cm[0], ms->cm[0], conv1_ks, 1024, false, false, true, &ms->conv1, ms->overflow,
+                                    stream));
       return DGR_OK;
     }
   }
   // capacity per output row: exact (K) in 3-D; in 6-D 3^6 = 729 offsets but measured mean
   // occupancy is 2..40 neighbours -- reserve 160 per row and raise the overflow flag beyond.
   const int cap_row = (D == 3) ? 1024 : 160;
-  if (D == 6) {
-    // the pruned search pays while buckets are small: fine levels (ts 1,2,4); at ts = 8 the ~20 k rows
-    // share only a few hundred first halves and the generic 729-probe search is as cheap
-    for (int l = 0; l < 3; ++l) DGR_CHECK(dgr_build_half_buckets(arena, ms->cm[l], &ms->hb[l], stream));
-  }
   // `lean` (the network forward): pair_out is only read by the transposed convs (strided maps used swapped),
   // pair_k only by the small-Cin conv1 (same[0] / the conv1 map); the stand-alone maps object keeps everything
-  auto build = [&](const DgrCoordMap &in, const DgrCoordMap &out, const DgrHalfBuckets *hb, int ks, bool rev,
-                   bool want_k, DgrKernelMap *km) -> int {
+  if (D == 6) {
+    DGR_REQUIRE(conv1_ks == 3, "6-D kernel maps support kernel size 3 only (got %d)", conv1_ks);
+    // first-half buckets of every level: the pruned search of all seven maps (since round 4 also at tensor stride 8)
+    for (int l = 0; l < 4; ++l) DGR_CHECK(dgr_build_half_buckets(arena, ms->cm[l], &ms->hb[l], stream));
+    Kmap6Job jobs[7];
+    for (int l = 0; l < 4; ++l) jobs[l] = {&ms->cm[l], &ms->cm[l], &ms->hb[l], false, !lean, !lean || l == 0, &ms->same[l]};
+    // strided maps are also used swapped by the transposed convs: the in-major CSR too
+    for (int l = 0; l < 3; ++l) jobs[4 + l] = {&ms->cm[l], &ms->cm[l + 1], &ms->hb[l], true, true, !lean, &ms->down[l]};
+    DGR_CHECK(build_kernel_maps6(arena, jobs, 7, cap_row, ms->overflow, stream));
+    ms->conv1 = ms->same[0];
+    return DGR_OK;
+  }
+  auto build = [&](const DgrCoordMap &in, const DgrCoordMap &out, int ks, bool rev, bool want_k, DgrKernelMap *km) -> int {
     const bool want_out = !lean || rev, want_pk = !lean || want_k;
-    if (D == 3)
-      return build_kernel_map_t<3>(arena, in, out, nullptr, ks, cap_row, rev, want_out, want_pk, km, ms->overflow, stream);
-    return build_kernel_map_t<6>(arena, in, out, hb, ks, cap_row, rev, want_out, want_pk, km, ms->overflow, stream);
+    return build_kernel_map3(arena, in, out, ks, cap_row, rev, want_out, want_pk, km, ms->overflow, stream);
   };
-  for (int l = 0; l < 4; ++l) DGR_CHECK(build(ms->cm[l], ms->cm[l], &ms->hb[l], 3, false, l == 0, &ms->same[l]));
+  for (int l = 0; l < 4; ++l) DGR_CHECK(build(ms->cm[l], ms->cm[l], 3, false, l == 0, &ms->same[l]));
   if (conv1_ks == 3)
     ms->conv1 = ms->same[0];
   else if (!skip_conv1_map)
-    DGR_CHECK(build(ms->cm[0], ms->cm[0], nullptr, conv1_ks, false, true, &ms->conv1));
+    DGR_CHECK(build(ms->cm[0], ms->cm[0], conv1_ks, false, true, &ms->conv1));
   // strided maps are also used swapped by the transposed convs: build the in-major CSR too
-  for (int l = 0; l < 3; ++l) DGR_CHECK(build(ms->cm[l], ms->cm[l + 1], &ms->hb[l], 3, true, false, &ms->down[l]));
+  for (int l = 0; l < 3; ++l) DGR_CHECK(build(ms->cm[l], ms->cm[l + 1], 3, true, false, &ms->down[l]));
   return DGR_OK;
 }
 

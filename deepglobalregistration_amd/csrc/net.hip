@@ -31,7 +31,7 @@ struct DgrLayer {
   float *w16 = nullptr;    // device, 16x16x4 fragment order (3-D K = 27 layers: output-stationary conv, conv_os.hip)
   void *w16b = nullptr;    // device, the same as two f16 pieces in 16x16x32 fragment order (conv_os.hip)
   int64_t w16b_piece = 0;
-  float *wc = nullptr;     // device, compact [K][32] (3-D conv1 with one input channel: conv1_grid_mfma, conv.hip)
+  float *wc = nullptr;     // device, conv1 weights in the operand order of conv1_grid_mfma (3-D conv1 with one input channel)
   void *wb = nullptr;      // device, two f16 pieces in 32x32x16 fragment order (wide layers, conv_wide.hip)
   int64_t wb_piece = 0;    // 16-byte units per piece
   int pieces = 2;          // wb / w16b: two f16 pieces of 2^e W; w_unscale = 2^-e
@@ -233,10 +233,23 @@ static int make_layer(dgr_net *net, const dgr_weight_desc *descs, int nd, const 
       net->param_bytes += pcs.size() * sizeof(uint16_t);
     }
   }
-  if (net->D == 3 && name == "conv1" && cin == 1 && cout == 32) {
-    std::vector<float> wc((size_t)K * 32);
-    for (int k = 0; k < K; ++k)
-      for (int c = 0; c < 32; ++c) wc[(size_t)k * 32 + c] = kd->data[(size_t)k * cout + c] * scale[c];
+  if (net->D == 3 && name == "conv1" && cin == 1 && cout == 32 && K <= 343) {
+    // conv1_grid_mfma (conv.hip): per z-slab kz and 4-offset step s the A operands of the two v_mfma_f32_16x16x4_f32,
+    // wt[kz][s][lane] = {W[k][lane & 15], W[k][16 + (lane & 15)]}, k = kz ks^2 + 4 s + (lane >> 4); zero past the slab
+    int ks = 1;
+    while (ks * ks * ks < K) ++ks;
+    const int ks2 = ks * ks, steps = (ks2 + 3) / 4;
+    std::vector<float> wc((size_t)ks * steps * 64 * 2, 0.f);
+    for (int kz = 0; kz < ks; ++kz)
+      for (int s = 0; s < steps; ++s)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int kk = 4 * s + (lane >> 4);
+          if (kk >= ks2) continue;
+          const int k = kz * ks2 + kk;
+          float *d = wc.data() + (((size_t)kz * steps + s) * 64 + lane) * 2;
+          d[0] = kd->data[(size_t)k * cout + (lane & 15)] * scale[lane & 15];
+          d[1] = kd->data[(size_t)k * cout + 16 + (lane & 15)] * scale[16 + (lane & 15)];
+        }
     DGR_HIP_CHECK(hipMalloc((void **)&L.wc, wc.size() * sizeof(float)));
     DGR_HIP_CHECK(hipMemcpy(L.wc, wc.data(), wc.size() * sizeof(float), hipMemcpyHostToDevice));
   }

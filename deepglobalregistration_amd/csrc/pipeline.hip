@@ -287,56 +287,65 @@ extern "C" int dgr_register_batch(dgr_ctx *ctx, dgr_net *fcgf, dgr_net *inlier, 
   DGR_CHECK(tm.rec(8, 0));
   if (prm->safeguard || prm->use_icp) {
     const DgrArena::Mark mk = A.mark();
+    // host landing buffers of the asynchronous copies below: they must outlive every copy in flight, so an error in the
+    // middle of the block synchronises the stream before this scope is left (the lambda's callers below)
     std::vector<double *> rs(npairs, nullptr);
     std::vector<double> Th((size_t)npairs * 16), rsh((size_t)npairs * DGR_RANSAC_RESULT_DOUBLES);
-    if (prm->safeguard)
-      for (int p = 0; p < npairs; ++p) {
-        if (res[p].status != DGR_STATUS_LOW_CONFIDENCE) continue;
-        // Case 1 (:302-315): RANSAC over the putative correspondences xyz0[i] <-> xyz1[idx1[i]]
-        const int64_t m0 = off0[p + 1] - off0[p];
-        float *Y;
-        DGR_ALLOC(Y, A, float, m0 * 3);
-        gather_rows3_kernel<<<(int)dgr_ceil_div(m0, 256), 256, 0, stream>>>(xyz1, idx1 + off0[p], m0, Y);
-        DGR_CHECK(dgr_ransac_begin(ctx, xyz0 + off0[p] * 3, Y, m0, 2.0 * prm->voxel_size,
-                                   prm->ransac_hypotheses > 0 ? prm->ransac_hypotheses : 4000000, prm->ransac_seed, &rs[p],
-                                   stream));
-        DGR_HIP_CHECK(hipMemcpyAsync(&rsh[(size_t)p * DGR_RANSAC_RESULT_DOUBLES], rs[p],
-                                     DGR_RANSAC_RESULT_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, stream));
-        status_out[p] = DGR_STATUS_SAFEGUARD;
-      }
     std::vector<DgrIcpJob> jobs(prm->use_icp ? npairs : 0);
-    if (prm->use_icp) {   // :317-322: max correspondence distance 2 voxel, Open3D defaults (1e-6, 1e-6, 30)
-      double *Tinit;
-      DGR_ALLOC(Tinit, A, double, (int64_t)npairs * 16);
-      for (int i = 0; i < npairs * 16; ++i) Th[i] = T_out[i];
-      DGR_HIP_CHECK(hipMemcpyAsync(Tinit, Th.data(), Th.size() * sizeof(double), hipMemcpyHostToDevice, stream));
-      for (int p = 0; p < npairs; ++p)
-        DGR_CHECK(dgr_icp_begin(ctx, xyz0 + off0[p] * 3, off0[p + 1] - off0[p], xyz1 + off1[p] * 3, off1[p + 1] - off1[p],
-                                2.0 * prm->voxel_size, rs[p] ? rs[p] : Tinit + (int64_t)p * 16, &jobs[p], stream));
-    }
-    DGR_HIP_CHECK(hipStreamSynchronize(stream));
-    for (int p = 0; p < npairs; ++p)
-      if (rs[p])
-        for (int i = 0; i < 16; ++i) T_out[p * 16 + i] = (float)rsh[(size_t)p * DGR_RANSAC_RESULT_DOUBLES + i];
-    if (prm->use_icp) {
-      std::vector<char> ran(npairs, 0);
-      for (int p = 0; p < npairs; ++p) {
-        if (jobs[p].ncell < 1 || jobs[p].ncell > (4 << 20)) {   // no finite target point: the estimate stands
-          status_out[p] = DGR_STATUS_ICP_SKIPPED;
-          continue;
+    auto tail = [&]() -> int {
+      if (prm->safeguard)
+        for (int p = 0; p < npairs; ++p) {
+          if (res[p].status != DGR_STATUS_LOW_CONFIDENCE) continue;
+          // Case 1 (:302-315): RANSAC over the putative correspondences xyz0[i] <-> xyz1[idx1[i]]
+          const int64_t m0 = off0[p + 1] - off0[p];
+          float *Y;
+          DGR_ALLOC(Y, A, float, m0 * 3);
+          gather_rows3_kernel<<<(int)dgr_ceil_div(m0, 256), 256, 0, stream>>>(xyz1, idx1 + off0[p], m0, Y);
+          DGR_CHECK(dgr_ransac_begin(ctx, xyz0 + off0[p] * 3, Y, m0, 2.0 * prm->voxel_size,
+                                     prm->ransac_hypotheses > 0 ? prm->ransac_hypotheses : 4000000, prm->ransac_seed, &rs[p],
+                                     stream));
+          DGR_HIP_CHECK(hipMemcpyAsync(&rsh[(size_t)p * DGR_RANSAC_RESULT_DOUBLES], rs[p],
+                                       DGR_RANSAC_RESULT_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, stream));
+          status_out[p] = DGR_STATUS_SAFEGUARD;
         }
-        DGR_CHECK(dgr_icp_run(ctx, &jobs[p], 30, 1e-6, 1e-6, stream));
-        ran[p] = 1;
+      if (prm->use_icp) {   // :317-322: max correspondence distance 2 voxel, Open3D defaults (1e-6, 1e-6, 30)
+        double *Tinit;
+        DGR_ALLOC(Tinit, A, double, (int64_t)npairs * 16);
+        for (int i = 0; i < npairs * 16; ++i) Th[i] = T_out[i];
+        DGR_HIP_CHECK(hipMemcpyAsync(Tinit, Th.data(), Th.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+        for (int p = 0; p < npairs; ++p)
+          DGR_CHECK(dgr_icp_begin(ctx, xyz0 + off0[p] * 3, off0[p + 1] - off0[p], xyz1 + off1[p] * 3, off1[p + 1] - off1[p],
+                                  2.0 * prm->voxel_size, rs[p] ? rs[p] : Tinit + (int64_t)p * 16, &jobs[p], stream));
       }
       DGR_HIP_CHECK(hipStreamSynchronize(stream));
-      for (int p = 0; p < npairs; ++p) {
-        if (!ran[p]) continue;
-        double Td[16];
-        dgr_icp_finish(&jobs[p], Td, nullptr);
-        for (int i = 0; i < 16; ++i) T_out[p * 16 + i] = (float)Td[i];
+      for (int p = 0; p < npairs; ++p)
+        if (rs[p])
+          for (int i = 0; i < 16; ++i) T_out[p * 16 + i] = (float)rsh[(size_t)p * DGR_RANSAC_RESULT_DOUBLES + i];
+      if (prm->use_icp) {
+        std::vector<char> ran(npairs, 0);
+        for (int p = 0; p < npairs; ++p) {
+          if (jobs[p].ncell < 1 || jobs[p].ncell > (4 << 20)) {
+            // no finite target point: the estimate stands, the code keeps saying where it came from
+            status_out[p] |= DGR_STATUS_FLAG_ICP_SKIPPED;
+            continue;
+          }
+          DGR_CHECK(dgr_icp_run(ctx, &jobs[p], 30, 1e-6, 1e-6, stream));
+          ran[p] = 1;
+        }
+        DGR_HIP_CHECK(hipStreamSynchronize(stream));
+        for (int p = 0; p < npairs; ++p) {
+          if (!ran[p]) continue;
+          double Td[16];
+          dgr_icp_finish(&jobs[p], Td, nullptr);
+          for (int i = 0; i < 16; ++i) T_out[p * 16 + i] = (float)Td[i];
+        }
       }
-    }
-    A.rewind(mk);   // the stream was synchronised above
+      return DGR_OK;
+    };
+    const int rc = tail();
+    if (rc != DGR_OK) (void)hipStreamSynchronize(stream);   // nothing may still be copying into rsh / jobs[] / Th
+    A.rewind(mk);   // the stream is synchronised on both paths
+    if (rc != DGR_OK) return rc;
   }
   DGR_CHECK(tm.rec(8, 1));
   if (ctx->profiling) {

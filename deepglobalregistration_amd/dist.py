@@ -10,9 +10,20 @@ on the data path.  Exactly two collectives exist:
 * `gather_results`      -- per batch, `T [n,4,4]`, `status [n]`, `stats [n,4]` are gathered on rank 0
   (a few KB).
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
+
+
+def _skip_collectives():
+    """No process group, or a single rank: nothing to exchange -- unless DGR_DIST_FORCE_COLLECTIVES=1 asks for the
+    collectives anyway (bench.py with DGR_BENCH_FORCE_PG=1: a 1-GPU box executes the RCCL broadcast / all-gather /
+    all-reduce of the multi-GPU path on a one-rank communicator, tests/test_gpu_bench_ranks.py)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return True
+    return dist.get_world_size() == 1 and os.environ.get('DGR_DIST_FORCE_COLLECTIVES') != '1'
 
 
 def shard_range(n_items, rank, world_size):
@@ -41,9 +52,10 @@ def _unflatten_state(metas, flat):
 def broadcast_checkpoint(ckpt, src=0, device=None):
     """Broadcast a checkpoint dict {'config','state_dict','state_dict_inlier'} from `src`.
     Non-source ranks pass ckpt=None.  The tensors travel as ONE flat float32 buffer per network."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if _skip_collectives():
         return ckpt
     rank = dist.get_rank()
+    roundtrip = dist.get_world_size() == 1   # forced one-rank run: use what came back out of the broadcast buffer
     backend = dist.get_backend()
     if device is None:
         device = torch.device('cuda', torch.cuda.current_device()) if backend == 'nccl' else torch.device('cpu')
@@ -65,7 +77,7 @@ def broadcast_checkpoint(ckpt, src=0, device=None):
         else:
             buf = torch.empty(n, dtype=torch.float32, device=device)
         dist.broadcast(buf, src=src)
-        out[name] = ckpt[name] if rank == src else _unflatten_state(metas, buf.cpu().numpy())
+        out[name] = ckpt[name] if rank == src and not roundtrip else _unflatten_state(metas, buf.cpu().numpy())
         del buf
     return out
 
@@ -76,7 +88,7 @@ def gather_results(T, status, stats, dst=0, device=None):
     T = np.asarray(T, np.float64).reshape(-1, 16)
     status = np.asarray(status, np.int32).reshape(-1)
     stats = np.asarray(stats, np.float32).reshape(-1, 4)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if _skip_collectives():
         return T.reshape(-1, 4, 4), status, stats
     world, rank = dist.get_world_size(), dist.get_rank()
     backend = dist.get_backend()
@@ -119,7 +131,7 @@ def all_gather_vector(values, total, lo, device=None):
     full [total] float64 vector on every rank (one small all-reduce of a zero-padded vector)."""
     full = np.zeros(total, np.float64)
     full[lo:lo + len(values)] = np.asarray(values, np.float64)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if _skip_collectives():
         return full
     if device is None:
         device = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else torch.device('cpu')

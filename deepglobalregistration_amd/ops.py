@@ -398,10 +398,11 @@ def set_profiling(device, enable):
 
 
 def stage_times(device):
-    t = (C.c_float * 9)()
-    check(_lib.load().dgr_ctx_stage_times(get_ctx(device), t))
+    t = (C.c_float * 16)()
+    n = C.c_int(0)
+    check(_lib.load().dgr_ctx_stage_times(get_ctx(device), t, 16, C.byref(n)))
     names = ['fcgf', 'knn', 'inlier_inputs', 'inlier_net', 'registration', 'maps_3d', 'maps_6d', 'conv_kernels', 'o3d_steps']
-    out = dict(zip(names, [float(v) for v in t]))
+    out = dict(zip(names, [float(v) for v in t[:n.value]]))
     out['conv_launches'] = int(_lib.load().dgr_ctx_conv_launches(get_ctx(device)))
     return out
 

@@ -47,8 +47,9 @@ enum {
 /* per-pair status of the confidence gate, core/deep_global_registration.py:276-281 */
 enum { DGR_STATUS_OK = 0, DGR_STATUS_LOW_CONFIDENCE = 1, DGR_STATUS_SVD_FAILED = 2,
        DGR_STATUS_SAFEGUARD = 3 /* gate failed, T from the safeguard RANSAC (dgr_params.safeguard) */,
-       DGR_STATUS_ICP_SKIPPED = 4 /* dgr_params.use_icp: the final ICP could not run on this pair (no finite target point);
-                                     T is the estimate before ICP */ };
+       /* flag, OR-ed onto one of the codes above (status & DGR_STATUS_MASK): dgr_params.use_icp, but the final ICP could
+          not run on this pair (no finite target point); T is the estimate the code names, before ICP */
+       DGR_STATUS_FLAG_ICP_SKIPPED = 0x100, DGR_STATUS_MASK = 0xff };
 
 const char *dgr_last_error(void);
 const char *dgr_version(void);
@@ -229,7 +230,11 @@ int dgr_register_batch_output(dgr_ctx *ctx, int which, void *dst_dev, int64_t ca
  * enabled with dgr_ctx_set_profiling(ctx, 1): [fcgf, knn, inlier_inputs, inlier_net, registration,
  * maps_3d, maps_6d, conv_kernels_total, safeguard RANSAC + ICP steps (dgr_params.safeguard / use_icp)].  Synchronises. */
 int dgr_ctx_set_profiling(dgr_ctx *ctx, int enable);
-int dgr_ctx_stage_times(dgr_ctx *ctx, float times_ms[9]);
+#define DGR_NUM_STAGE_TIMES 9
+/* writes min(capacity, DGR_NUM_STAGE_TIMES) values and the number written to *n (nullable).  (Versions before 0.2 took a
+ * bare float[8] / float[9]: the explicit capacity is what keeps a caller built against an older header from being
+ * overrun when the list grows.) */
+int dgr_ctx_stage_times(dgr_ctx *ctx, float *times_ms, int capacity, int *n);
 /* number of sparse-conv kernel launches covered by times_ms[7] */
 int64_t dgr_ctx_conv_launches(dgr_ctx *ctx);
 /* duration (ms) of every sparse-conv layer launch of the last profiled batch, in launch order (FCGF layers

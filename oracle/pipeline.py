@@ -1,15 +1,15 @@
-"""CPU restatement of `DeepGlobalRegistration.register()` up to (R, t).
+"""CPU restatement of `DeepGlobalRegistration.register()`: raw points -> 4x4 float64.
 
-TEST INFRASTRUCTURE (see oracle/__init__.py).  Follows
-`core/deep_global_registration.py:134-217,238-300` stage by stage; the Open3D
-safeguard RANSAC (`:302-315`) and ICP (`:317-322`) are out of scope (SURVEY.md
-section 8f) and are not restated.
+TEST INFRASTRUCTURE (see oracle/__init__.py).  Follows `core/deep_global_registration.py:134-217,238-324`
+stage by stage, including the two Open3D steps: the safeguard RANSAC over the putative correspondences
+(`:50-64, 302-315`) and the final point-to-point ICP (`:317-322`), both through `oracle/open3d_reg.py`
+(restated Open3D 0.17 algorithms -- parity unpinned, see that module).
 """
 import numpy as np
 import torch
 
 from . import me_semantics as me
-from . import resunet, knn, registration
+from . import resunet, knn, registration, open3d_reg
 
 
 def preprocess(xyz, voxel_size):
@@ -48,10 +48,16 @@ def confidence_gate(logit, clip_weight_thresh=0.05):
     return w.numpy(), wsum, max(200, len(w) * 0.05)
 
 
-def register(ckpt, xyz0, xyz1, clip_weight_thresh=0.05, forced_logit_fn=None):
-    """Full restated path.  `ckpt` = {'config', 'state_dict', 'state_dict_inlier'} in the
-    reference's checkpoint layout (core/trainer.py:527-549).  Returns a dict with every
-    intermediate so that tests can compare stage by stage."""
+def register(ckpt, xyz0, xyz1, clip_weight_thresh=0.05, forced_logit_fn=None, idx1_fn=None, use_icp=True,
+             safeguard=True, ransac_hypotheses=4000000, ransac_seed=0):
+    """`register()` (`:238-324`) restated.  `ckpt` = {'config', 'state_dict', 'state_dict_inlier'} in the
+    reference's checkpoint layout (core/trainer.py:527-549).  Returns a dict with every intermediate so that tests can
+    compare stage by stage; `T` is the 4x4 float64 the reference returns.
+
+    Harness hooks (None = the reference's behaviour): `idx1_fn(p0, p1, F0, F1, idx1) -> idx1` replaces matches after
+    the search ran, `forced_logit_fn(x0[idx0], x1[idx1], logit) -> logit` replaces the logits after the inlier net ran
+    (untrained weights give meaningless matches / confidences).  `ransac_hypotheses`: the reference hard-codes
+    4 000 000 (`:61`); tests pass fewer, to both sides."""
     cfg = ckpt['config']
     voxel = cfg['voxel_size']
     out = {}
@@ -65,6 +71,9 @@ def register(ckpt, xyz0, xyz1, clip_weight_thresh=0.05, forced_logit_fn=None):
     assert F0.shape[1] == n_out
     out.update(F0=F0, F1=F1)
     idx1 = knn.find_knn(F0, F1, nn_max_n=cfg.get('nn_max_n', 250)).reshape(-1)
+    out['idx1_searched'] = idx1
+    if idx1_fn is not None:
+        idx1 = np.asarray(idx1_fn(p0, p1, F0, F1, idx1)).reshape(-1)
     idx0 = np.arange(len(idx1))
     out.update(idx0=idx0, idx1=idx1)
     ftype = cfg.get('inlier_feature_type', 'coords')
@@ -72,19 +81,28 @@ def register(ckpt, xyz0, xyz1, clip_weight_thresh=0.05, forced_logit_fn=None):
     out.update(coords6=coords6, feats6=feats6)
     logit = resunet.resunet_forward(ckpt['state_dict_inlier'], coords6, feats6, 6,
                                     cfg['inlier_conv1_kernel_size'], False)
+    out['logit_net'] = logit
     if forced_logit_fn is not None:
         logit = forced_logit_fn(p0[idx0], p1[idx1], logit)
     w, wsum, thr = confidence_gate(logit, clip_weight_thresh)
     out.update(logit=logit, weights=w, wsum=wsum, wsum_threshold=thr)
     T = np.identity(4)
-    if wsum >= thr:
+    if wsum >= thr:                                     # :283-300
         R, t, stats = registration.global_registration(
             p0[idx0], p1[idx1], w, break_threshold_ratio=1e-4,
             quantization_size=2 * voxel)
         T[:3, :3] = R
         T[:3, 3] = t.reshape(3)
-        out.update(R=R, t=t, stats=stats, confident=True)
-    else:
-        out.update(confident=False)
+        out.update(R=R, t=t, stats=stats, confident=True, status='ok')
+    else:                                               # :302-315
+        out.update(confident=False, status='low_confidence')
+        if safeguard:
+            T, h, count, rmse = open3d_reg.ransac_correspondence(p0[idx0], p1[idx1], 2 * voxel, ransac_hypotheses,
+                                                                 seed=ransac_seed)
+            out.update(status='safeguard', ransac={'hypothesis': h, 'inliers': count, 'rmse': rmse})
+    out['T_before_icp'] = T.copy()
+    if use_icp:                                         # :317-322
+        T, fitness, rmse, iters = open3d_reg.icp_point_to_point(p0, p1, 2 * voxel, init=T)
+        out['icp'] = {'fitness': fitness, 'inlier_rmse': rmse, 'iterations': iters}
     out['T'] = T
     return out

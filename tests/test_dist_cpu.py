@@ -82,3 +82,31 @@ def test_single_process_passthrough():
     assert ddist.broadcast_checkpoint(ck) is ck
     T, s, st = ddist.gather_results(np.eye(4)[None], [0], np.zeros((1, 4)))
     assert T.shape == (1, 4, 4) and s.tolist() == [0]
+
+
+def _forced_worker(rank, world, port, tmpdir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['DGR_DIST_FORCE_COLLECTIVES'] = '1'
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from deepglobalregistration_amd import dist as ddist, synth
+    ck = synth.synth_checkpoint(seed=5, feat_conv1_kernel_size=3, with_inlier=False)
+    got = ddist.broadcast_checkpoint(ck, src=0)
+    assert got is not ck and got['config'] == ck['config']      # rebuilt from the broadcast buffer, not passed through
+    for k, v in ck['state_dict'].items():
+        if not k.endswith('num_batches_tracked'):
+            np.testing.assert_array_equal(np.asarray(got['state_dict'][k]), np.asarray(v, np.float32))
+    T, s, st = ddist.gather_results(np.eye(4)[None] * 3, [2], np.full((1, 4), 7.0))
+    assert T.shape == (1, 4, 4) and T[0, 0, 0] == 3 and s.tolist() == [2] and st[0, 1] == 7
+    v = ddist.all_gather_vector([1.5, 2.5], 4, 1)
+    np.testing.assert_array_equal(v, [0, 1.5, 2.5, 0])
+    open(os.path.join(tmpdir, 'ok'), 'w').write('ok')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_rank_group_runs_the_collectives_when_forced(tmp_path):
+    """bench.py's DGR_BENCH_FORCE_PG mode (tests/test_gpu_bench_ranks.py runs it over RCCL): with a one-rank group and
+    DGR_DIST_FORCE_COLLECTIVES=1 every helper goes through its collective instead of the single-process shortcut."""
+    mp.spawn(_forced_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    assert (tmp_path / 'ok').exists()

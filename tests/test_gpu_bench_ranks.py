@@ -23,21 +23,30 @@ COMMON = ['--steps', '2', '--warmup', '1', '--total-pairs', '6', '--pairs-per-st
           '--conv1-ks', '5', '--no-parity']
 
 
-def _bench(tmp, gpus):
+def _bench(tmp, gpus, tag='', **extra_env):
     env = dict(os.environ, DGR_BENCH_BACKEND='gloo', DGR_BENCH_ONE_GPU='1')
-    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'DGR_BENCH_FORCE_PG', 'DGR_DIST_FORCE_COLLECTIVES'):
         env.pop(k, None)
-    out = os.path.join(tmp, f'res{gpus}.npz')
+    env.update(extra_env)
+    for k in [k for k, v in env.items() if v is None]:
+        env.pop(k)
+    out = os.path.join(tmp, f'res{gpus}{tag}.npz')
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(gpus), '--dump-results', out, *COMMON],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
-    return line, np.load(out)
+    return line, np.load(out), r.stderr
 
 
-def test_two_ranks_cover_every_pair_once_and_match_one_rank(tmp_path):
-    one, r1 = _bench(str(tmp_path), 1)
-    two, r2 = _bench(str(tmp_path), 2)
+@pytest.fixture(scope='module')
+def plain_run(tmp_path_factory):
+    """The plain one-rank run (no process group) both tests compare with."""
+    return _bench(str(tmp_path_factory.mktemp('plain')), 1)
+
+
+def test_two_ranks_cover_every_pair_once_and_match_one_rank(tmp_path, plain_run):
+    one, r1, _ = plain_run
+    two, r2, _ = _bench(str(tmp_path), 2)
     assert one['n_gpus'] == 1 and two['n_gpus'] == 2 and two['scaling'] == 'strong'
     assert two['config']['pairs_per_step'] == 6 and two['value'] > 0
     assert sorted(r1['ids'].tolist()) == list(range(6)) and sorted(r2['ids'].tolist()) == list(range(6))
@@ -46,3 +55,20 @@ def test_two_ranks_cover_every_pair_once_and_match_one_rank(tmp_path):
     np.testing.assert_array_equal(r1['T'][o1], r2['T'][o2])
     np.testing.assert_array_equal(r1['stats'][o1], r2['stats'][o2])    # iterations, loss, break count, sum of weights
     assert two['host_cpu_s_per_step_per_rank'] > 0
+
+
+def test_rccl_collectives_on_a_one_rank_group_match_the_plain_run(tmp_path, plain_run):
+    """The RCCL half of the multi-GPU path on the hardware a 1-GPU box has: DGR_BENCH_FORCE_PG=1 makes the one-rank run
+    call init_process_group('nccl', device_id=...), broadcast_object_list, the flat weight broadcast (the networks are
+    then built from what came back OUT of the broadcast buffer), the cost all-reduce of the strong mode, barriers, the
+    result all-gather and the MAX all-reduce of the step time -- every collective `bench.py --gpus 8` issues
+    (SURVEY.md 8e), on device memory, through RCCL.  Results must equal the plain one-rank run bit for bit."""
+    plain, r1, _ = plain_run
+    forced, r2, err = _bench(str(tmp_path), 1, tag='pg', DGR_BENCH_BACKEND=None, DGR_BENCH_FORCE_PG='1')
+    assert 'nccl process group up' in err, err[-2000:]
+    assert forced['n_gpus'] == 1 and forced['config']['pairs_per_step'] == 6
+    o1, o2 = np.argsort(r1['ids']), np.argsort(r2['ids'])
+    assert sorted(r2['ids'].tolist()) == list(range(6))
+    np.testing.assert_array_equal(r1['status'][o1], r2['status'][o2])
+    np.testing.assert_array_equal(r1['T'][o1], r2['T'][o2])
+    np.testing.assert_array_equal(r1['stats'][o1], r2['stats'][o2])

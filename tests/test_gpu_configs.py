@@ -109,6 +109,7 @@ def test_config4_dense_pair_refinement_on_off():
     assert status.tolist() == [0] and int(stats[0, 0]) > 0
     F0 = ops.batch_output('cuda', 'F0').reshape(-1, 32).cpu().numpy()     # before any other library call on the context
     F1 = ops.batch_output('cuda', 'F1').reshape(-1, 32).cpu().numpy()
+    logit = ops.batch_output('cuda', 'logit').cpu().numpy().reshape(-1)
     st = {'iterations': int(stats[0, 0]), 'loss': float(stats[0, 1]), 'break_count': int(stats[0, 2])}
     assert_refine_parity(X0, Y, ow, T_on[0, :3, :3], T_on[0, :3, 3], st, break_threshold_ratio=1e-4, quantization_size=2 * voxel)
     assert_iteration_matched(X0, Y, ow, break_threshold_ratio=1e-4, quantization_size=2 * voxel)
@@ -128,3 +129,12 @@ def test_config4_dense_pair_refinement_on_off():
     oc0 = w['ca'].cpu().numpy()
     oF0 = oresunet.resunet_forward(ck['state_dict'], oc0, np.ones((n0, 1), np.float32), 3, ks, True)
     assert np.abs(F0 - oF0).max() < TOL
+    # ... and the 6-D logits of all ~100k correspondences (the inlier net at its largest BASELINE size: one forward of the
+    # oracle over ~100k 6-D rows, K = 729)
+    oc1 = w['cb'].cpu().numpy()
+    c6, f6 = opipe.inlier_inputs(X0, X1, oc0, oc1, np.arange(n0), w['idx1'])
+    ologit = oresunet.resunet_forward(ck['state_dict_inlier'], c6, f6, 6, 3, False).reshape(-1)
+    assert logit.shape == ologit.shape
+    err = rel_err(logit, ologit)
+    print(f'configs[4]: {n0} 6-D rows, max |dlogit| / max |logit| = {err:.1e}')
+    assert err < TOL
