@@ -73,16 +73,9 @@ __device__ __forceinline__ f32x4 dgr_y_load(const float *p) {
 //   * MFMA operands are swapped (D = W^T . In^T): a lane owns one pair and 4 x 4 consecutive output
 //     channels, so product rows leave as 16-byte stores.
 //   * row indices travel through a 4-slot LDS ring, loaded two tiles ahead.
-// Timing ablations for tools/layer_bench.py (results in DESIGN.md 4.2; outputs are garbage): -DDGR_ABL_NOGATHER,
-// -DDGR_ABL_BONCE (weight operands loaded once), -DDGR_ABL_STORE0 (product rows to an L2-resident slab),
-// -DDGR_ABL_NOBARRIER, -DDGR_ABL_NOMFMA; -DDGR_WIDE_CK=64 -DDGR_WIDE_WAVES=3 builds the widest configuration for 3 waves/SIMD.
 // ------------------------------------------------------------------------------------------
-#ifndef DGR_WIDE_CK
 #define DGR_WIDE_CK 128     // phase width (input channels) of the widest configuration
-#endif
-#ifndef DGR_WIDE_WAVES
-#define DGR_WIDE_WAVES 2    // waves per SIMD the widest configuration is compiled for
-#endif
+#define DGR_WIDE_WAVES 2    // waves per SIMD the widest configuration is compiled for (64 / 3 measured within +-1 %)
 constexpr int conv_phase_width(int cp, int acc_blocks) {
   const int cap = acc_blocks >= 4 ? DGR_WIDE_CK : 128;
   return cp > cap ? cap : cp;
@@ -163,11 +156,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (MB * NB >= 4 ? DGR_WIDE_WAVES :
       if (VEC) {
         const int rr = max(row, 0);
         const int cc = min(c, a.cin - 4);
-#ifdef DGR_ABL_NOGATHER   // timing ablation: no gather traffic, same landing code
-        G[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#else
         G[i] = *reinterpret_cast<const f32x4 *>(a.in + (int64_t)rr * a.in_ld + cc);
-#endif
         g_ok |= (row >= 0 && c < a.cin) ? (1u << i) : 0u;
       } else {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -250,13 +239,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (MB * NB >= 4 ? DGR_WIDE_WAVES :
 #pragma unroll
     for (int s = 0; s < SK; ++s) {
       if (s0 + s + RING - 1 < S) {
-#ifdef DGR_ABL_BONCE
-#pragma unroll
-        for (int j = 0; j < NB; ++j) b[(s + RING - 1) % RING][j] = b[s % RING][j];
-#else
 #pragma unroll
         for (int j = 0; j < NB; ++j) b[(s + RING - 1) % RING][j] = wk[((int64_t)(s0 + s + RING - 1) * NBLK + j) * 64];
-#endif
       }
       // pin the prefetch HERE: without it the scheduler sinks each load next to its first use
       // (load-to-use distance 0, full L2 latency exposed on every K-step; seen in the ISA)
@@ -264,12 +248,6 @@ __global__ void __launch_bounds__(64 * WM * WN, (MB * NB >= 4 ? DGR_WIDE_WAVES :
       f32x4 av[MB];
 #pragma unroll
       for (int i = 0; i < MB; ++i) av[i] = *reinterpret_cast<const f32x4 *>(arow + i * 32 * LDA + s * 8);
-#ifdef DGR_ABL_NOMFMA   // timing ablation: the skeleton (gather, landing, LDS reads, weight loads, stores) without the matrix work
-#pragma unroll
-      for (int i = 0; i < MB; ++i)
-#pragma unroll
-        for (int j = 0; j < NB; ++j) acc[i][j][0] += b[s % RING][j][0] * av[i][0] + b[s % RING][j][3] * av[i][3];
-#else
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -277,7 +255,6 @@ __global__ void __launch_bounds__(64 * WM * WN, (MB * NB >= 4 ? DGR_WIDE_WAVES :
 #pragma unroll
           for (int j = 0; j < NB; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[s % RING][j][c], av[i][c], acc[i][j], 0, 0, 0);
-#endif
     }
     if (h == PPT - 1) {
       // ---- tile finished: request the next tile's first B operands BEFORE this tile's stores
@@ -317,11 +294,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (MB * NB >= 4 ? DGR_WIDE_WAVES :
           for (int e = 0; e < 16; ++e) acc[i][0][e] = acc[i][0][e] / den;
         }
         if (r < cnt) {
-#ifdef DGR_ABL_STORE0
-          float *dst = a.y + (int64_t)(r + 64 * (blockIdx.x & 1023)) * a.y_ld;  // timing ablation: L2-resident product rows
-#else
           float *dst = identity ? a.out + (int64_t)(pst + r) * a.out_ld : a.y + (int64_t)(pst + r) * a.y_ld;
-#endif
 #pragma unroll
           for (int j = 0; j < NB; ++j) {
 #pragma unroll
@@ -345,9 +318,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (MB * NB >= 4 ? DGR_WIDE_WAVES :
         }
       }
     }
-#ifndef DGR_ABL_NOBARRIER
     __syncthreads();  // buffer q&1 is free again; buffer (q+1)&1 and the index ring are visible
-#endif
   }
 }
 
@@ -374,6 +345,117 @@ static int launch_v2(const ConvKArgs &ka, int64_t tile_bound, int num_cus, hipSt
   return DGR_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Kernel-volume-1 convs (conv1_tr, final: MinkowskiConvolution with kernel_size 1 = a dense [N, Cin] x [Cin, Cout]
+// product over the rows of ONE map, model/resunet.py:565-596): a streaming kernel.  No kernel map, no index ring, no
+// LDS: a wave takes 32 consecutive rows, every lane requests its 16-byte pieces of them straight into the B-operand
+// registers of v_mfma_f32_32x32x2_f32 (lane = row (lane & 31), input channels 8 j + 4 (lane >> 5) .. + 3 -- the layout
+// the rule-major kernel builds in LDS), all CP / 8 requests of a tile in flight at once; the layer's weights stay in
+// registers for all the tiles of the wave.  Same operands in the same order as sparse_conv_mfma_v2 on an identity map:
+// bit-identical results, HBM-bound instead of latency-bound (195 k rows, 96 -> 64: 51 -> ~25 us).
+// ------------------------------------------------------------------------------------------
+template <int CP, int NBLK>
+__global__ void __launch_bounds__(256) identity_conv_kernel(ConvKArgs a) {
+  constexpr int S = CP / 8;
+  const int lane = threadIdx.x & 63;
+  const int n_rows = *a.n_rows_dev;
+  const int n_tiles = (n_rows + 31) >> 5;
+  const int wave_id = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), n_waves = (int)((gridDim.x * blockDim.x) >> 6);
+  f32x4 w[S][NBLK];
+  {
+    const f32x4 *wp = reinterpret_cast<const f32x4 *>(a.w) + lane;
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+      for (int j = 0; j < NBLK; ++j) w[s][j] = wp[(s * NBLK + j) * 64];
+  }
+  const int relu_lo = a.in_relu ? 0 : (int)0x80000000;   // pending ReLU of the producer as one integer max per value
+  auto request = [&](int t, f32x4 (&x)[S]) {
+    const int64_t row = min((int64_t)t * 32 + (lane & 31), (int64_t)n_rows - 1);   // rows past the end: the last row again
+    const float *src = a.in + row * a.in_ld + 4 * (lane >> 5);
+#pragma unroll
+    for (int s = 0; s < S; ++s) x[s] = *reinterpret_cast<const f32x4 *>(src + 8 * s);
+  };
+  f32x4 xa[S], xb[S];
+  auto tile = [&](int t, f32x4 (&x)[S]) {
+    f32x16 acc[NBLK];
+#pragma unroll
+    for (int j = 0; j < NBLK; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      i32x4 v = __builtin_bit_cast(i32x4, x[s]);
+      v.x = max(v.x, relu_lo); v.y = max(v.y, relu_lo); v.z = max(v.z, relu_lo); v.w = max(v.w, relu_lo);
+      const f32x4 xv = __builtin_bit_cast(f32x4, v);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < NBLK; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[s][j][c], xv[c], acc[j], 0, 0, 0);
+    }
+    // D column (row of the tile) = lane & 31, D row (channel) = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+    const int64_t row = (int64_t)t * 32 + (lane & 31);
+    if (a.l2_normalize) {
+      // the feature row of the `final` conv leaves unit-norm (model/resunet.py:643-647): a row's <= 32 channels sit in
+      // lanes l and l ^ 32 -- shift first, one cross-lane add, one division per value
+      float ss = 0.f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int col = 8 * g + 4 * (lane >> 5) + u;
+          float v = acc[0][4 * g + u] + ((a.shift && col < a.cout) ? a.shift[col] : 0.f);
+          if (col >= a.cout) v = 0.f;
+          acc[0][4 * g + u] = v;
+          ss += v * v;
+        }
+      ss += __shfl_xor(ss, 32, 64);
+      const float den = sqrtf(ss) + 1e-8f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[0][e] = acc[0][e] / den;
+    }
+    if (row < n_rows) {
+      float *dst = a.out + row * a.out_ld;
+#pragma unroll
+      for (int j = 0; j < NBLK; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int col = 32 * j + 8 * g + 4 * (lane >> 5);
+          f32x4 v = {acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
+          if (col + 3 < a.cout && (a.out_ld & 3) == 0) {
+            if (a.shift && !a.l2_normalize) v += *reinterpret_cast<const f32x4 *>(a.shift + col);
+            *reinterpret_cast<f32x4 *>(dst + col) = v;
+          } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              if (col + u < a.cout) dst[col + u] = v[u] + ((a.shift && !a.l2_normalize) ? a.shift[col + u] : 0.f);
+          }
+        }
+    }
+  };
+  // two tiles in flight: the next tile's rows are requested before this tile is multiplied
+  int t = wave_id;
+  if (t < n_tiles) request(t, xa);
+  for (; t < n_tiles; t += 2 * n_waves) {
+    const int t1 = t + n_waves;
+    if (t1 < n_tiles) request(t1, xb);
+    tile(t, xa);
+    if (t1 < n_tiles) {
+      if (t1 + n_waves < n_tiles) request(t1 + n_waves, xa);
+      tile(t1, xb);
+    }
+  }
+}
+
+template <int CP, int NBLK>
+static int launch_identity(const ConvKArgs &ka, int64_t rows_cap, int num_cus, hipStream_t stream) {
+  // enough waves to keep every CU's memory pipe full, at least two tiles each where the tensor allows it
+  int64_t blocks = std::min<int64_t>((int64_t)num_cus * 4, std::max<int64_t>(1, dgr_ceil_div(rows_cap, 32 * 4 * 2)));
+  identity_conv_kernel<CP, NBLK><<<(int)blocks, 256, 0, stream>>>(ka);
+  DGR_LAUNCH_CHECK();
+  return DGR_OK;
+}
+
 int dgr_conv_launch(const DgrConvLaunch &a, int num_cus, hipStream_t stream, const char **kernel_name) {
   ConvKArgs ka;
   ka.in = a.in; ka.out = a.out; ka.w = a.w; ka.y = a.y; ka.shift = a.shift; ka.y_ld = a.cout;
@@ -388,6 +470,15 @@ int dgr_conv_launch(const DgrConvLaunch &a, int num_cus, hipStream_t stream, con
   const int64_t tile_bound = a.tile_bound > 0 ? a.tile_bound : (int64_t)num_cus * 4;
   // specialised (compile-time Cin, pipelined) instantiations for every layer shape of ResUNetBN2C
   const bool vec = ((a.cin | a.in_ld) & 3) == 0;
+  if (a.pair_in == nullptr && vec && a.cin == a.cin_pad && a.tile_bound > 0) {   // kernel-volume-1 conv: streaming kernel
+#define DGR_ID(CPV, NBV)                                                                          \
+  if (a.cin_pad == CPV && a.cout_pad == 32 * NBV) {                                               \
+    if (kernel_name) *kernel_name = "identity_conv_kernel<" #CPV ", " #NBV ">";                   \
+    return launch_identity<CPV, NBV>(ka, a.tile_bound * DGR_TILE_M, num_cus, stream);             \
+  }
+    DGR_ID(64, 1) DGR_ID(64, 2) DGR_ID(96, 2)
+#undef DGR_ID
+  }
 #define DGR_V2(CPV, WMV, WNV, MBV, NBV)                                                                        \
   if (a.cin_pad == CPV) {                                                                                       \
     if (kernel_name)                                                                                            \
@@ -579,17 +670,30 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
       for (int u = 0; u < 8; ++u) acc += y[u];
     }
-    for (; j < end; ++j) {
-      const int pos = out_pos[j];
-      const int row = pair_in[pos];
-      const float *wk = w + (int64_t)pair_k[pos] * 256;
-      float y = 0.f;
-      for (int ci = 0; ci < cin; ++ci) {
-        float x = in[(int64_t)row * in_ld + ci];
-        if (in_relu) x = fmaxf(x, 0.f);
-        y = fmaf(x, wk[(32 * (ci >> 2) + co) * 4 + (ci & 3)], y);   // same k-ordered fma chain as the MFMA
+    // the remaining 1 .. 7 pairs (most rows of a 6-D stride-1 map have one to three pairs in all): four at a time, the
+    // index chains of the four issued together (clamped to the row's last pair), the additions predicated and in order
+    // -- one pair at a time, a row paid four dependent memory latencies per pair
+    for (; j < end; j += 4) {
+      int pos[4], row[4], kk[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) pos[u] = out_pos[min(j + u, end - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { row[u] = pair_in[pos[u]]; kk[u] = pair_k[pos[u]]; }
+      float y[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float *wk = w + (int64_t)kk[u] * 256;
+        float t = 0.f;
+        for (int ci = 0; ci < cin; ++ci) {
+          float x = in[(int64_t)row[u] * in_ld + ci];
+          if (in_relu) x = fmaxf(x, 0.f);
+          t = fmaf(x, wk[(32 * (ci >> 2) + co) * 4 + (ci & 3)], t);   // same k-ordered fma chain as the MFMA
+        }
+        y[u] = t;
       }
-      acc += y;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (j + u < end) acc += y[u];
     }
     out[o * out_ld + co] = acc;
   }
@@ -619,7 +723,7 @@ __global__ void __launch_bounds__(256)
     conv1_probe_kernel(const int32_t *__restrict__ coords, const int32_t *n_dev, const int32_t *__restrict__ table,
                        uint32_t mask, int ks, const float *__restrict__ in, int in_ld, int cin,
                        const float *__restrict__ w, const float *__restrict__ shift, float *__restrict__ out,
-                       int out_ld, int32_t *pair_count, const int32_t *skip_flag) {
+                       int out_ld, int32_t *pair_count, const int32_t *skip_flag, uint32_t *__restrict__ out_amax) {
   if (skip_flag && *skip_flag) return;   // the dense-grid kernel did the layer
   const int n = *n_dev;
   const int lane = threadIdx.x & 63;
@@ -667,6 +771,12 @@ __global__ void __launch_bounds__(256)
       }
     }
     if (lane < 32) out[o * out_ld + co] = acc;
+    if (out_amax) {   // (both half-waves hold the same 32 channels)
+      uint32_t mx = __builtin_bit_cast(uint32_t, acc) & 0x7fffffffu;
+#pragma unroll
+      for (int d = 16; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+      if (lane == 0) atomicMax(out_amax + o, mx);
+    }
   }
   if (lane == 0 && pair_count) atomicAdd(pair_count, pairs);
 }
@@ -694,9 +804,9 @@ struct DgrGridMeta {
   long long base[GRID_MAXB];
 };
 
-__global__ void grid_init_kernel(DgrGridMeta *m) {
+__global__ void grid_init_kernel(DgrGridMeta *m, int32_t *pair_count) {
   const int b = threadIdx.x;
-  if (b == 0) { m->ok = 0; m->bad = 0; m->total = 0; }
+  if (b == 0) { m->ok = 0; m->bad = 0; m->total = 0; if (pair_count) *pair_count = 0; }
   if (b < GRID_MAXB) {
     for (int d = 0; d < 3; ++d) { m->mn[b][d] = INT32_MAX; m->mx[b][d] = INT32_MIN; m->dim[b][d] = 0; }
     m->base[b] = 0;
@@ -822,7 +932,7 @@ __global__ void __launch_bounds__(256)
     conv1_grid_kernel(const int32_t *__restrict__ coords, const int32_t *n_dev, const DgrGridMeta *__restrict__ m,
                       const int32_t *__restrict__ cells, int ks, const float *__restrict__ in, int in_ld, int cin,
                       const float *__restrict__ w, const float *__restrict__ shift, float *__restrict__ out,
-                      int out_ld, int32_t *pair_count) {
+                      int out_ld, int32_t *pair_count, uint32_t *__restrict__ out_amax) {
   __shared__ int2 lists[256 / 64][2][C1_MAXK + 1];
   if (!m->ok) return;
   const int n = *n_dev;
@@ -898,6 +1008,12 @@ __global__ void __launch_bounds__(256)
     }
     const int64_t o = o0 + vsel;
     if (o < n) out[o * out_ld + co] = acc;
+    if (out_amax) {   // a voxel's 32 channels are the 32 lanes of a half-wave
+      uint32_t mx = o < n ? (__builtin_bit_cast(uint32_t, acc) & 0x7fffffffu) : 0u;
+#pragma unroll
+      for (int d = 16; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+      if (co == 0 && o < n) atomicMax(out_amax + o, mx);
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();   // the lists are rewritten by the next pair of voxels
   }
@@ -924,7 +1040,7 @@ template <int KS>
 __global__ void __launch_bounds__(256)
     conv1_grid_mfma(const int32_t *__restrict__ coords, const int32_t *n_dev, const DgrGridMeta *__restrict__ m,
                     const int32_t *__restrict__ cells, const float *__restrict__ wt, const float *__restrict__ shift,
-                    float *__restrict__ out, int out_ld, int32_t *pair_count) {
+                    float *__restrict__ out, int out_ld, int32_t *pair_count, uint32_t *__restrict__ out_amax) {
   constexpr int KS2 = KS * KS, HALF = KS / 2;
   constexpr int RS = (KS2 + 3) / 4 * 4;          // slab length padded to MFMA k-steps
   constexpr int LDG = RS + 1;
@@ -1002,13 +1118,22 @@ __global__ void __launch_bounds__(256)
       if (kz + 1 < KS) fill((kz + 1) & 1);
     }
     const int64_t o = v0 + (lane & 15);
+    uint32_t mx = 0;
     if (o < n) {
 #pragma unroll
       for (int jb = 0; jb < 2; ++jb) {
         f32x4 v = acc[jb];
         if (shift) v += *reinterpret_cast<const f32x4 *>(shift + 16 * jb + 4 * (lane >> 4));
         *reinterpret_cast<f32x4 *>(out + o * out_ld + 16 * jb + 4 * (lane >> 4)) = v;
+        const i32x4 b = __builtin_bit_cast(i32x4, v);
+        mx = max(mx, max(max((uint32_t)b.x & 0x7fffffffu, (uint32_t)b.y & 0x7fffffffu), max((uint32_t)b.z & 0x7fffffffu, (uint32_t)b.w & 0x7fffffffu)));
       }
+    }
+    if (out_amax) {   // the row's largest |x| for its split-operand consumers (conv_os.hip / conv_dense.hip): a voxel's
+                      // channels sit in the four lanes (lane & 15) + 16 q
+      mx = max(mx, (uint32_t)__shfl_xor((int)mx, 16, 64));
+      mx = max(mx, (uint32_t)__shfl_xor((int)mx, 32, 64));
+      if (lane < 16 && o < n) atomicMax(out_amax + o, mx);
     }
   }
   if (pair_count) {   // (statistics: one atomic per workgroup)
@@ -1021,9 +1146,9 @@ __global__ void __launch_bounds__(256)
 
 int dgr_conv1_probe(DgrArena &arena, const DgrCoordMap &cm, int ks, const float *in, int in_ld, int cin,
                     const float *w_tiled, const float *shift, float *out, int out_ld, int32_t *pair_count,
-                    hipStream_t stream, const float *w_compact, const char **kernel_name) {
+                    hipStream_t stream, const float *w_compact, const char **kernel_name, uint32_t *out_amax) {
   DGR_REQUIRE(cin >= 1 && cin <= 8 && ks % 2 == 1, "conv1 probe: cin=%d ks=%d", cin, ks);
-  if (pair_count) DGR_HIP_CHECK(hipMemsetAsync(pair_count, 0, sizeof(int32_t), stream));
+  if (pair_count && ks > 7) DGR_HIP_CHECK(hipMemsetAsync(pair_count, 0, sizeof(int32_t), stream));   // (else: grid_init_kernel)
   const int32_t *grid_done = nullptr;
   if (ks <= 7) {
     // dense grid: up to 64 M cells (256 MB) of transient arena memory
@@ -1033,7 +1158,7 @@ int dgr_conv1_probe(DgrArena &arena, const DgrCoordMap &cm, int ks, const float 
     int32_t *cells;
     DGR_ALLOC(meta, arena, DgrGridMeta, 1);
     DGR_ALLOC(cells, arena, int32_t, cap + 4);
-    grid_init_kernel<<<1, 64, 0, stream>>>(meta);
+    grid_init_kernel<<<1, 64, 0, stream>>>(meta, pair_count);
     grid_bbox_kernel<<<(int)dgr_ceil_div(cm.n_cap, 256), 256, 0, stream>>>(cm.coords, cm.n_dev, meta);
     grid_layout_kernel<<<1, 64, 0, stream>>>(meta, ks >> 1, cap);
     grid_clear_kernel<<<2048, 256, 0, stream>>>(meta, cells);
@@ -1052,15 +1177,15 @@ int dgr_conv1_probe(DgrArena &arena, const DgrCoordMap &cm, int ks, const float 
     }
     if (mfma) {
       const int wgs = (int)dgr_ceil_div(cm.n_cap, 64);
-      if (ks == 7) conv1_grid_mfma<7><<<wgs, 256, 0, stream>>>(cm.coords, cm.n_dev, meta, cells, w_compact, shift, out, out_ld, pair_count);
-      else if (ks == 5) conv1_grid_mfma<5><<<wgs, 256, 0, stream>>>(cm.coords, cm.n_dev, meta, cells, w_compact, shift, out, out_ld, pair_count);
-      else conv1_grid_mfma<3><<<wgs, 256, 0, stream>>>(cm.coords, cm.n_dev, meta, cells, w_compact, shift, out, out_ld, pair_count);
+      if (ks == 7) conv1_grid_mfma<7><<<wgs, 256, 0, stream>>>(cm.coords, cm.n_dev, meta, cells, w_compact, shift, out, out_ld, pair_count, out_amax);
+      else if (ks == 5) conv1_grid_mfma<5><<<wgs, 256, 0, stream>>>(cm.coords, cm.n_dev, meta, cells, w_compact, shift, out, out_ld, pair_count, out_amax);
+      else conv1_grid_mfma<3><<<wgs, 256, 0, stream>>>(cm.coords, cm.n_dev, meta, cells, w_compact, shift, out, out_ld, pair_count, out_amax);
       if (kernel_name) *kernel_name = ks == 7 ? "conv1_grid_mfma<7>" : ks == 5 ? "conv1_grid_mfma<5>" : "conv1_grid_mfma<3>";
     } else {
     int64_t blocks = dgr_ceil_div(cm.n_cap, 8);
     if (blocks > resident) blocks = (int64_t)resident * std::min<int64_t>(4, blocks / resident);
     conv1_grid_kernel<<<(int)blocks, 256, 0, stream>>>(cm.coords, cm.n_dev, meta, cells, ks, in, in_ld, cin, w_tiled, shift,
-                                                       out, out_ld, pair_count);
+                                                       out, out_ld, pair_count, out_amax);
     if (kernel_name) *kernel_name = "conv1_grid_kernel";
     }
     DGR_LAUNCH_CHECK();
@@ -1068,10 +1193,11 @@ int dgr_conv1_probe(DgrArena &arena, const DgrCoordMap &cm, int ks, const float 
     arena.rewind(mk);   // stream order keeps the grid alive until the kernels above are done
   }
   {
+    // (grid-stride; it returns at once when the dense-grid kernel did the layer: a modest grid keeps that case cheap)
     int64_t blocks = dgr_ceil_div(cm.n_cap, 4);
-    if (blocks > 16384) blocks = 16384;
+    if (blocks > 4096) blocks = 4096;
     conv1_probe_kernel<<<(int)blocks, 256, 0, stream>>>(cm.coords, cm.n_dev, cm.table, cm.table_mask, ks, in, in_ld, cin,
-                                                        w_tiled, shift, out, out_ld, pair_count, grid_done);
+                                                        w_tiled, shift, out, out_ld, pair_count, grid_done, out_amax);
   }
   DGR_LAUNCH_CHECK();
   return DGR_OK;

@@ -4,10 +4,14 @@
 // batch-norm shift, the residual and the pending ReLUs; per (output row, offset) one product row, added in ascending
 // offset order), but WITHOUT pair lists:
 //
-//   * a wave owns RG x 16 consecutive output rows and ALL output channels; a lane owns one row of each 16-row group
-//     (lane & 15) and the 8-channel chunk (lane >> 4) of every 32-channel k-step -- exactly the B operand of
-//     v_mfma_f32_16x16x32_f16 -- so the gathered neighbour row goes from global memory straight into MFMA operand
-//     registers (split into its two f16 pieces on the way): no LDS tile, no compaction, no slot lists;
+//   * a wave owns RG x 16 consecutive output rows and ALL output channels.  Per offset it gathers the rows' neighbours
+//     in a QUAD-COALESCED request layout (lane 4 r + c reads 16 bytes of row r: a quad of lanes = 64 contiguous bytes of
+//     one row, one request of the vector-memory path; requesting in MFMA operand order, lane = 16 chunk + row, makes
+//     every lane of a quad touch another row: 38 instead of 65 B/ns/CU when L2-resident), through bounds-checked buffer
+//     loads (a missing neighbour is an offset past the tensor: zeros without a memory access, no branch), splits them
+//     into the two f16 pieces in registers and brings them into the B-operand order of v_mfma_f32_16x16x32_f16 (lane =
+//     row (lane & 15), 8-channel chunk (lane >> 4)) with ds_bpermute (the LDS crossbar, no LDS memory): no LDS tile, no
+//     compaction, no slot lists;
 //   * a missing neighbour is a zero operand: 27 dense tiles per row group.  On 3DMatch-shaped clouds 45 % (stride 1)
 //     to 60 % (stride 2, 4) of the table is filled, so the matrix pipe does 1.7 .. 2.2 x the useful work -- on a pipe the
 //     list-based kernel keeps 8 - 16 % busy, in exchange for its three dependent LDS look-ups per slot, its LDS
@@ -17,8 +21,16 @@
 //     one barrier per offset) and read by every wave as MFMA A operands: each 16-byte fragment serves RG row groups;
 //   * accumulators stay in registers for the whole layer: per offset a zero-initialised tile `tmp`, folded as
 //     total += tmp * 2^-e(row, k) / weight scale -- the same two roundings per (row, offset) as conv_os.hip, in the
-//     same ascending-k order on top of shift + residual: results are bit-identical to that kernel's and do not
-//     depend on scheduling.
+//     same ascending-k order on top of shift + residual.  Results do not depend on scheduling; they agree with the
+//     list-based kernel to a few f32 ulps of the tensor's scale, NOT bitwise: the quad-coalesced gather hands the
+//     channels of a 32-channel step to the matrix unit in another order (4 lq .. + 3 and 16 + 4 lq .. + 3 per lane),
+//     so the f32 sums inside one MFMA round differently (tests/test_gpu_dense_conv.py: 2e-6 of the unit-norm output).
+//   * input rows carry their largest |x| (bits, written by their producer's epilogue: out_amax below and in
+//     conv_os.hip / conv.hip) -- the row's power-of-two scale is dgr_row_scale_of of it; no separate scale pass.
+//
+// What bounds it (tools/ab_fcgf.py ablations on the 195 k-row 64 -> 64 layers, 203 us; round 3): no gather 113, no
+// MFMA 215, no split 183, no weight staging 166, gather only 152 -- gathering 2.4 M random 256-byte rows out of a 50-MB
+// tensor, at the rate of the memory system for random rows beyond the 4-MB L2 of an XCD (3.6 - 5.2 TB/s, vmem_bw).
 //
 // Weight layout: the split pieces of conv_os.hip, WB[piece][k][s][jb][lane] = 8 halves =
 // W_folded[k][32 s + 8 (lane >> 4) + e][16 jb + (lane & 15)] (net.hip).
@@ -42,7 +54,8 @@ struct ConvDenseArgs {
   const int32_t *nbr, *n_out_dev;
   int64_t n_pad;
   int in_ld, in_relu, out_ld, out_relu, res_ld, res_relu;
-  const float *row_scale;  // power-of-two scale per input row (dgr_row_scale)
+  const uint32_t *row_amax;   // bits of every input row's largest |x| after the pending ReLU (from the row's producer)
+  uint32_t *out_amax, *out_amax2;   // (nullable) the same for the rows written here: atomicMax per row
   float w_unscale;         // inverse of the layer's weight scale
   uint32_t in_bytes;       // size of the input tensor (row capacity x row stride): bound of the buffer loads
 };
@@ -129,7 +142,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) sparse_conv_dense_f16x2(ConvDen
   // gathered rows of the NEXT offset: requested here, consumed (split into pieces) at the top of the next iteration
   const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in), 0, a.in_bytes, 0x00020000);
   // the gathered rows of one offset (raw f32, requested DEPTH offsets ahead), their row scales and table entries
-  struct RowSet { f32x4 raw[RG][S][2]; float sc[RG]; int nv[RG]; };
+  struct RowSet { f32x4 raw[RG][S][2]; uint32_t mx[RG]; int nv[RG]; };
   // Request layout: lane L = 4 r + c reads 16 bytes of row r of the group so that every QUAD of lanes reads 64
   // contiguous bytes of one row -- one request of the vector-memory path per quad.  (Requesting straight in MFMA
   // operand layout, lane = 16 chunk + row, makes every lane of a quad touch a different row: four requests per quad,
@@ -142,32 +155,23 @@ __global__ void __launch_bounds__(64 * WAVES, 2) sparse_conv_dense_f16x2(ConvDen
     for (int rg = 0; rg < RG; ++rg) {
       const int n = nbr_s[k][(wave * RG + rg) * 16 + (lane >> 2)];
       const int ne = max(n, 0);
-#ifdef DGR_DENSE_ABL_NOGATHER   // timing ablations (outputs are garbage): tools/ab_fcgf.py with DGR_HIP_LIB
-      const float sv = 1.f;
-#pragma unroll
-      for (int s = 0; s < S; ++s) g.raw[rg][s][0] = g.raw[rg][s][1] = f32x4{(float)ne, 1.f, 2.f, 3.f};
-#else
       // buffer loads: a missing neighbour gets an offset past the tensor -- the bounds check returns zeros without a
       // memory access, and the request stays branch-free
       const uint32_t off = n >= 0 ? (uint32_t)n * (uint32_t)(a.in_ld * 4) + 16u * (lane & 3) : a.in_bytes;
-      const float sv = a.row_scale[ne];
+      const uint32_t mv = a.row_amax[ne];
 #pragma unroll
       for (int s = 0; s < S; ++s) {
         g.raw[rg][s][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off + 128 * s, 0, 0));
         g.raw[rg][s][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off + 128 * s + 64, 0, 0));
       }
-#endif
-      g.sc[rg] = sv;   // (selected against `nv` when it is consumed: nothing here may wait for the request)
+      g.mx[rg] = mv;   // (turned into the scale, and selected against `nv`, when it is consumed: nothing here may wait for the request)
       g.nv[rg] = n;
     }
   };
-#ifndef DGR_DENSE_DEPTH
-#define DGR_DENSE_DEPTH 1
-#endif
   // offsets the row requests run ahead (one register set each).  Measured on the 195 k-row 64 -> 64 layers: depth 2
   // (230 VGPRs) 202 us, depth 1 (176 VGPRs) 205 us -- the gather is bounded by the memory system's rate for random
   // 256-byte rows beyond the L2 (tools/microbench/vmem_bw.hip), not by latency
-  constexpr int DEPTH = DGR_DENSE_DEPTH;
+  constexpr int DEPTH = 1;
   static_assert(DEPTH == 1 || DEPTH == 2, "prefetch depth");
   RowSet gA, gB;
   gather(0, gA);
@@ -183,7 +187,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) sparse_conv_dense_f16x2(ConvDen
     const int from = 4 * (4 * (lane & 15) + (lane >> 4));
 #pragma unroll
     for (int rg = 0; rg < RG; ++rg) {
-      const float sx = g.nv[rg] >= 0 ? g.sc[rg] : 0.f;
+      const float sx = g.nv[rg] >= 0 ? dgr_row_scale_of(g.mx[rg]) : 0.f;
       const float fl = sx != 0.f ? dgr_inv_pow2(sx) * a.w_unscale : 0.f;
       fold[rg] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(16 * (lane & 15), __builtin_bit_cast(int, fl)));
 #pragma unroll
@@ -191,10 +195,6 @@ __global__ void __launch_bounds__(64 * WAVES, 2) sparse_conv_dense_f16x2(ConvDen
         i32x4 hw, mw;   // four dwords = eight halves each: elements 0..3 from the first request, 4..7 from the second
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-#ifdef DGR_DENSE_ABL_NOCONV
-          const i32x4 v = __builtin_bit_cast(i32x4, g.raw[rg][s][h]);
-          hw[2 * h] = v[0]; hw[2 * h + 1] = v[1]; mw[2 * h] = v[2]; mw[2 * h + 1] = v[3];
-#else
           const i32x4 v = __builtin_bit_cast(i32x4, g.raw[rg][s][h]);
 #pragma unroll
           for (int u = 0; u < 4; u += 2) {
@@ -204,7 +204,6 @@ __global__ void __launch_bounds__(64 * WAVES, 2) sparse_conv_dense_f16x2(ConvDen
             hw[2 * h + u / 2] = __builtin_bit_cast(int, hh);
             mw[2 * h + u / 2] = __builtin_bit_cast(int, mm);
           }
-#endif
         }
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
@@ -222,10 +221,8 @@ __global__ void __launch_bounds__(64 * WAVES, 2) sparse_conv_dense_f16x2(ConvDen
     //      the offset after next's weights requested; everything arrives during this offset's MFMAs
     // (the weights are requested BEFORE the rows: the memory counter is in order, and the next wstore must not have to
     // wait for row requests that are younger than its weights)
-#ifndef DGR_DENSE_ABL_NOW
     wstore((k + 1) & 1, wr);   // (after the last offset: into the buffer nobody reads any more)
     wload(min(k + 2, KV - 1), wr);
-#endif
     gather(min(k + DEPTH, KV - 1), g);   // refills the set just consumed
     __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks these requests below the MFMAs: no time in flight)
     // ---- this offset's tile: tmp = W[k]^T x (zero for missing neighbours)
@@ -243,9 +240,6 @@ __global__ void __launch_bounds__(64 * WAVES, 2) sparse_conv_dense_f16x2(ConvDen
         const f16x8 wm = __builtin_bit_cast(f16x8, wl[WP + (s * NCB + cb) * 64 + lane]);
 #pragma unroll
         for (int rg = 0; rg < RG; ++rg) {
-#ifdef DGR_DENSE_ABL_NOMFMA
-          if (wh[0] != (_Float16)123.f) continue;
-#endif
           tmp[rg][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm, bh[rg][s], tmp[rg][cb], 0, 0, 0);
           tmp[rg][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bm[rg][s], tmp[rg][cb], 0, 0, 0);
           tmp[rg][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bh[rg][s], tmp[rg][cb], 0, 0, 0);
@@ -256,9 +250,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) sparse_conv_dense_f16x2(ConvDen
     for (int rg = 0; rg < RG; ++rg)
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) total[rg][cb] += tmp[rg][cb] * fold[rg];
-#ifndef DGR_DENSE_ABL_NOBAR
     __syncthreads();   // buffer k & 1 is free again; buffer (k + 1) & 1 is complete
-#endif
   };
   if (DEPTH == 1) {
 #pragma unroll 1
@@ -273,16 +265,29 @@ __global__ void __launch_bounds__(64 * WAVES, 2) sparse_conv_dense_f16x2(ConvDen
   }
 
   // ---- the rows are written once (ReLU applied here when the tensor carries one)
+  //      ... and their largest |x| is left behind for the split-operand consumers of this tensor: a row's channels sit
+  //      in the four lanes lr + 16 lq of this wave
   const float out_lo = a.out_relu ? 0.f : -__builtin_inff();
 #pragma unroll
   for (int rg = 0; rg < RG; ++rg) {
     const int64_t row = row0 + (wave * RG + rg) * 16 + lr;
+    uint32_t mx = 0;
     if (row < n_out) {
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) {
         f32x4 v = total[rg][cb];
         v.x = fmaxf(v.x, out_lo); v.y = fmaxf(v.y, out_lo); v.z = fmaxf(v.z, out_lo); v.w = fmaxf(v.w, out_lo);
         *reinterpret_cast<f32x4 *>(a.out + row * a.out_ld + 16 * cb + 4 * lq) = v;
+        const i32x4 b = __builtin_bit_cast(i32x4, v);
+        mx = max(mx, max(max((uint32_t)b.x & 0x7fffffffu, (uint32_t)b.y & 0x7fffffffu), max((uint32_t)b.z & 0x7fffffffu, (uint32_t)b.w & 0x7fffffffu)));
+      }
+    }
+    if (a.out_amax || a.out_amax2) {   // (kernel-uniform)
+      mx = max(mx, (uint32_t)__shfl_xor((int)mx, 16, 64));
+      mx = max(mx, (uint32_t)__shfl_xor((int)mx, 32, 64));
+      if (lq == 0 && row < n_out) {
+        if (a.out_amax) atomicMax(a.out_amax + row, mx);
+        if (a.out_amax2) atomicMax(a.out_amax2 + row, mx);
       }
     }
   }
@@ -294,13 +299,8 @@ bool dgr_conv_dense_supported(int cin, int cin_pad, int cout) {
 
 template <int CIN, int COUT>
 static int launch_dense(const ConvDenseArgs &ka, int64_t n_out_cap, hipStream_t stream) {
-#ifndef DGR_DENSE_RG
-#define DGR_DENSE_RG 2
-#endif
-#ifndef DGR_DENSE_WAVES
-#define DGR_DENSE_WAVES 4
-#endif
-  constexpr int RG = DGR_DENSE_RG, WAVES = DGR_DENSE_WAVES, MB = WAVES * RG * 16;
+  // (8 waves per workgroup / 16 rows per wave measured 2.56 / 2.50 ms FCGF conv time against 2.51 with this shape)
+  constexpr int RG = 2, WAVES = 4, MB = WAVES * RG * 16;
   int64_t blocks = dgr_ceil_div(n_out_cap, MB);
   blocks = (blocks + 7) / 8 * 8;
   sparse_conv_dense_f16x2<CIN, COUT, RG, WAVES><<<(unsigned)blocks, 64 * WAVES, 0, stream>>>(ka);
@@ -311,7 +311,7 @@ static int launch_dense(const ConvDenseArgs &ka, int64_t n_out_cap, hipStream_t 
 int dgr_conv_dense_launch(const DgrConvOsLaunch &a, hipStream_t stream, const char **kernel_name) {
   DGR_REQUIRE(a.nbr && a.nbr->built && a.nbr->K == 27, "dense-tile conv: no neighbour table");
   DGR_REQUIRE(dgr_conv_dense_supported(a.cin, a.cin_pad, a.cout), "dense-tile conv: Cin = %d, Cout = %d not built", a.cin, a.cout);
-  DGR_REQUIRE(a.wb3 && a.row_scale, "dense-tile conv: needs the split weights and the input's row scales");
+  DGR_REQUIRE(a.wb3 && a.row_amax, "dense-tile conv: needs the split weights and the input rows' maxima");
   DGR_REQUIRE((a.in_ld & 3) == 0 && (a.out_ld & 3) == 0 && (a.res == nullptr || (a.res_ld & 3) == 0),
               "dense-tile conv: row strides must be multiples of 4");
   ConvDenseArgs ka;
@@ -320,7 +320,8 @@ int dgr_conv_dense_launch(const DgrConvOsLaunch &a, hipStream_t stream, const ch
   ka.nbr = a.nbr->nbr; ka.n_out_dev = a.n_out_dev; ka.n_pad = a.nbr->n_pad;
   ka.in_ld = a.in_ld; ka.in_relu = a.in_relu; ka.out_ld = a.out_ld; ka.out_relu = a.out_relu;
   ka.res_ld = a.res_ld; ka.res_relu = a.res_relu;
-  ka.row_scale = a.row_scale; ka.w_unscale = a.w_unscale;
+  ka.row_amax = a.row_amax; ka.w_unscale = a.w_unscale;
+  ka.out_amax = a.out_amax; ka.out_amax2 = a.out_amax2;
   DGR_REQUIRE(a.n_in_cap > 0 && a.n_in_cap * (int64_t)a.in_ld * 4 < (1ll << 31), "dense-tile conv: input tensor beyond 2 GB");
   ka.in_bytes = (uint32_t)(a.n_in_cap * (int64_t)a.in_ld * 4);
 #define DGR_DENSE(CI, CO)                                                                   \

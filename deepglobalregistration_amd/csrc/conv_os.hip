@@ -31,6 +31,7 @@
 #include <type_traits>
 
 #include "dgr_internal.h"
+#include "split.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -49,8 +50,10 @@ struct ConvOsArgs {
   int64_t n_pad;
   int in_ld, in_relu, out_ld, out_relu, res_ld, res_relu;
   int cin, cout, nb16;   // nb16 = cout / 16
-  const float *row_scale;  // PM = 2: power-of-two scale per input row (dgr_row_scale)
-  float w_unscale;         // PM = 2: inverse of the layer's weight scale
+  const uint32_t *row_amax;  // PM = 2: bits of every input row's largest |x| (after the pending ReLU), left behind by
+                             // the row's producer; the row's power-of-two scale is dgr_row_scale_of of it
+  float w_unscale;           // PM = 2: inverse of the layer's weight scale
+  uint32_t *out_amax, *out_amax2;   // (nullable) the same for the rows this layer writes: atomicMax per row
 };
 
 // CP = input channels (multiple of 32), CS = output-channel slice of a workgroup (32 | 64), MB = output rows
@@ -132,7 +135,7 @@ __global__ void __launch_bounds__(CS * 4 * (TM / 16 / GW)) sparse_conv_os(ConvOs
           const int pos = __popcll(m & ((1ull << lane) - 1ull));
           in_idx[k][pos] = v[u];
           out_loc[k][pos] = (unsigned char)lane;
-          if constexpr (PM == 2) in_scale[k][pos] = a.row_scale[v[u]];
+          if constexpr (PM == 2) in_scale[k][pos] = dgr_row_scale_of(a.row_amax[v[u]]);
         }
         if (lane == 0) cnt[k] = __popcll(m);
       }
@@ -188,11 +191,7 @@ __global__ void __launch_bounds__(CS * 4 * (TM / 16 / GW)) sparse_conv_os(ConvOs
       const int info = grp[GP * t + (r >> 4)];
       const int row = in_idx[info & 255][((info >> 8) & 255) + (r & 15)];
       const uint32_t off = (uint32_t)(((r & 15) < (info >> 16)) ? row : 0) * (uint32_t)a.in_ld + (uint32_t)c;
-#ifdef DGR_OS_ABL_NOGATHER   // timing ablations (outputs are garbage): tools/ab_fcgf.py with DGR_HIP_LIB
-      Gr[i] = f32x4{(float)off, 0.f, 0.f, 0.f};
-#else
       Gr[i] = *reinterpret_cast<const f32x4 *>(a.in + off);
-#endif
     }
   };
   // pending ReLU of the producer as ONE integer max per value (negative floats are negative integers; no
@@ -237,11 +236,7 @@ __global__ void __launch_bounds__(CS * 4 * (TM / 16 / GW)) sparse_conv_os(ConvOs
   struct WSet { uint4 v[WREGS]; };
   auto wstep = [&](int qq, int u, WSet &w) {   // weights of this wave's u-th group in phase qq (clamped)
     const int q = min(qq, NQ - 1);
-#ifdef DGR_OS_ABL_WONCE   // timing ablation: every group reads offset 0's slice (L1-resident)
-    const int k = 0;
-#else
     const int k = __builtin_amdgcn_readfirstlane(grp[GP * (q / PPT) + rb0 + u]) & 255;
-#endif
     if constexpr (!BF3) {
       const uint4 *p = reinterpret_cast<const uint4 *>(a.w16) + (int64_t)jb * 64 + lane + (int64_t)(k * GT + (q % PPT) * G) * a.nb16 * 64;
 #pragma unroll
@@ -260,9 +255,6 @@ __global__ void __launch_bounds__(CS * 4 * (TM / 16 / GW)) sparse_conv_os(ConvOs
   // the wave's u-th 16-row group on its accumulator
   auto mfma_group = [&](int u, int buf) {
     const int rb = rb0 + u;
-#ifdef DGR_OS_ABL_NOMFMA
-    if (w[u].v[0].x != 0x12345678u) return;
-#endif
     if constexpr (!BF3) {
       const float *arow = &As[buf][lane & 15][4 * (lane >> 4)];
 #pragma unroll
@@ -318,11 +310,7 @@ __global__ void __launch_bounds__(CS * 4 * (TM / 16 / GW)) sparse_conv_os(ConvOs
 #pragma unroll
       for (int u = 0; u < GW; ++u) {
         const int info = grp[GP * t + rb0 + u];
-#ifdef DGR_OS_ABL_NORMW
-        if ((lane & 15) < (info >> 16) && acc[u].x == 123.456f) {
-#else
         if ((lane & 15) < (info >> 16)) {
-#endif
           const int e = ((info >> 8) & 255) + (lane & 15);
           float *p = &acc_s[out_loc[info & 255][e]][16 * cw + 4 * (lane >> 4)];
           f32x4 v = *reinterpret_cast<f32x4 *>(p);
@@ -340,13 +328,29 @@ __global__ void __launch_bounds__(CS * 4 * (TM / 16 / GW)) sparse_conv_os(ConvOs
   }
   // ---- 5. write the block's rows once (ReLU applied here when the tensor carries one: consumers that
   //         re-apply it see an idempotent max)
+  //         ... and leave the rows' largest |x| behind for the split-operand consumers of this tensor (one integer
+  //         atomicMax per row and channel slice; the CS / 4 lanes of a row are consecutive lanes of one wave)
   const float out_lo = a.out_relu ? 0.f : -__builtin_inff();
-  for (int e = tid; e < MB * (CS / 4); e += THREADS) {
-    const int r = e / (CS / 4), c = (e % (CS / 4)) * 4;
-    if (row0 + r < n_out) {
+  static_assert(MB * (CS / 4) % THREADS == 0 || THREADS % (CS / 4) == 0, "row lanes stay inside a wave");
+  for (int e0 = 0; e0 < MB * (CS / 4); e0 += THREADS) {
+    const int e = e0 + tid;
+    const bool live = e < MB * (CS / 4);
+    const int r = live ? e / (CS / 4) : 0, c = (e % (CS / 4)) * 4;
+    uint32_t mx = 0;
+    if (live && row0 + r < n_out) {
       f32x4 v = *reinterpret_cast<const f32x4 *>(&acc_s[r][c]);
       v.x = fmaxf(v.x, out_lo); v.y = fmaxf(v.y, out_lo); v.z = fmaxf(v.z, out_lo); v.w = fmaxf(v.w, out_lo);
       *reinterpret_cast<f32x4 *>(a.out + (row0 + r) * a.out_ld + slice * CS + c) = v;
+      const i32x4 b = __builtin_bit_cast(i32x4, v);
+      mx = max(max((uint32_t)b.x & 0x7fffffffu, (uint32_t)b.y & 0x7fffffffu), max((uint32_t)b.z & 0x7fffffffu, (uint32_t)b.w & 0x7fffffffu));
+    }
+    if (a.out_amax || a.out_amax2) {   // (kernel-uniform)
+#pragma unroll
+      for (int d = CS / 8; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+      if (live && (e % (CS / 4)) == 0 && row0 + r < n_out) {
+        if (a.out_amax) atomicMax(a.out_amax + row0 + r, mx);
+        if (a.out_amax2) atomicMax(a.out_amax2 + row0 + r, mx);
+      }
     }
   }
 }
@@ -361,7 +365,7 @@ static int launch_os(const ConvOsArgs &ka, int64_t n_out_cap, hipStream_t stream
   blocks = (blocks + 7) / 8 * 8;
   dim3 grid((unsigned)blocks, (unsigned)(ka.cout / CS));
   constexpr int threads = CS * 4 * (TM / 16 / GW);
-  if (ka.wb3 && ka.row_scale)
+  if (ka.wb3 && ka.row_amax)
     sparse_conv_os<CP, CS, MB, CK, TM, 2, GW><<<grid, threads, 0, stream>>>(ka);
   else
     sparse_conv_os<CP, CS, MB, CK, TM, 0, GW><<<grid, threads, 0, stream>>>(ka);
@@ -383,25 +387,22 @@ int dgr_conv_os_launch(const DgrConvOsLaunch &a, hipStream_t stream, const char 
   ka.in = a.in; ka.out = a.out; ka.w16 = a.w16; ka.shift = a.shift; ka.res = a.res;
   ka.wb3 = os_f32 ? nullptr : static_cast<const uint4 *>(a.wb3);
   ka.piece_stride = a.piece_stride;
-  ka.row_scale = ka.wb3 ? a.row_scale : nullptr;
+  ka.row_amax = ka.wb3 ? a.row_amax : nullptr;
   ka.w_unscale = a.w_unscale;
-  DGR_REQUIRE(!ka.wb3 || ka.row_scale, "output-stationary conv: the split weights need the input's row scales");
+  ka.out_amax = a.out_amax; ka.out_amax2 = a.out_amax2;
+  DGR_REQUIRE(!ka.wb3 || ka.row_amax, "output-stationary conv: the split weights need the input rows' maxima");
   ka.nbr = a.nbr->nbr; ka.n_out_dev = a.n_out_dev; ka.n_pad = a.nbr->n_pad;
   ka.in_ld = a.in_ld; ka.in_relu = a.in_relu; ka.out_ld = a.out_ld; ka.out_relu = a.out_relu;
   ka.res_ld = a.res_ld; ka.res_relu = a.res_relu;
   ka.cin = a.cin; ka.cout = a.cout; ka.nb16 = a.cout / 16;
-#ifndef DGR_OS_TM
-#define DGR_OS_TM 32
-#endif
-#ifndef DGR_OS_MBBIG
-#define DGR_OS_MBBIG 64
-#endif
+#define DGR_OS_TM 32      // pair slots per tile (64: more idle group slots, 2.60 -> 2.82 ms FCGF conv time)
+#define DGR_OS_MBBIG 64   // output rows per workgroup at the two finest levels
 #define DGR_STR2(x) #x
 #define DGR_STR(x) DGR_STR2(x)
 #define DGR_OS(CPV, CSV, MBV, CKV)                                                                      \
   do {                                                                                                  \
     constexpr int tm = (MBV) < DGR_OS_TM ? ((MBV) < 32 ? 32 : (MBV)) : DGR_OS_TM;                       \
-    if (kernel_name) *kernel_name = ka.row_scale ? "sparse_conv_os<" #CPV ", " #CSV ", " DGR_STR(MBV) ", " DGR_STR(CKV) ", f16x2>"  \
+    if (kernel_name) *kernel_name = ka.row_amax ? "sparse_conv_os<" #CPV ", " #CSV ", " DGR_STR(MBV) ", " DGR_STR(CKV) ", f16x2>"  \
                                                  : "sparse_conv_os<" #CPV ", " #CSV ", " DGR_STR(MBV) ", " DGR_STR(CKV) ", f32>"; \
     return launch_os<CPV, CSV, MBV, CKV, tm>(ka, a.n_out_cap, stream);                                  \
   } while (0)
@@ -416,9 +417,7 @@ int dgr_conv_os_launch(const DgrConvOsLaunch &a, hipStream_t stream, const char 
     else if (mb == 32) { DGR_OS(CPV, 64, 32, CKV); }                        \
     else { DGR_OS(CPV, 64, 16, CKV); }                                      \
   } while (0)
-#ifndef DGR_OS_CK
-#define DGR_OS_CK 64
-#endif
+#define DGR_OS_CK 64      // input channels per pipeline phase
   switch (a.cin_pad) {
     case 32: DGR_OS_MB(32, 32);
     case 64: DGR_OS_MB(64, DGR_OS_CK);

@@ -24,24 +24,29 @@
 // Structure.  A tile is <= 64 pairs of ONE kernel offset (rule-major order, kmap.hip); a persistent 512-thread workgroup
 // per CU walks an XCD-aware share of the tiles (block b runs on XCD b % 8; an XCD gets a contiguous range of offsets, so
 // a weight slice lives in one L2).  Work is split by latency domain, because s_waitcnt vmcnt retires loads AND stores
-// in order:
-//   * waves 0..3 (compute): their only memory operations are weight fragments -- a 4-deep register ring, four 16-byte
-//     loads per k-step, unconditional, every wait count static -- then 12 v_mfma_f32_32x32x16_f16 per k-step on the
-//     landed planes (the next k-step's operands are prefetched from LDS, across the phase barrier too), raw accumulators
-//     into an LDS stage at the end of a tile.
-//   * waves 4..7 (movers): no arithmetic beyond addresses.  Split rows go global -> LDS by LDS-DMA
-//     (global_load_lds_dwordx4: the per-lane SOURCE address carries the gather and the bank swizzle, the destination is
-//     lane-linear), four 64-channel phases ahead of the multiply into a five-deep ring of 16-KB phase buffers; the
-//     tiles' row indices and row scales arrive the same way (4-byte DMA, every mover wave fetches its own copy, so no
-//     cross-wave hand-off is needed for them); the finished tile's product rows leave the LDS stage as whole rows,
-//     a FIXED number of streaming stores per phase (rows past a tile's end go to a scratch row).  Nothing a mover issues
-//     returns into a register, so the compiler inserts no vmcnt wait of its own: the one hand-counted
-//     `s_waitcnt vmcnt(N)` per phase retires exactly the DMA of the phase the compute waves prefetch from next.
-// One raw s_barrier per phase (all eight waves); 153 KB of LDS at Cout = 256.
+// in order -- a wave that gathers, loads weights and stores waits for all three whenever it waits for one:
+//   * waves 0..3 (compute): their only memory operations are weight fragments -- a register ring WD k-steps deep (2;
+//     4 for the 64-channel-output shape, whose k-steps are three MFMAs long), NB x 2 16-byte loads per k-step,
+//     unconditional, every wait count static -- then 3 MB NB v_mfma_f32_32x32x16_f16 per k-step on the landed planes
+//     (the next k-step's operands are prefetched from LDS, across the phase barrier too).  Two accumulator sets
+//     alternate: while tile t + 1 is multiplied, the finished tile t leaves its registers for an LDS stage, a few
+//     16-byte pieces per k-step, in the shadow of the MFMAs.  Wave w computes rows 32 MB (w / WN) .. and output
+//     channels 32 NB (w % WN) ..: WM = 1 (four column waves, 64 rows each) for C_out >= 128, WM = 2 (two row halves x
+//     two column waves) for C_out = 64.
+//   * waves 4, 5 (requesters): gather the split rows with plain 16-byte loads, NSET = 4 64-channel phases in flight
+//     through four register sets, into a ring of NBUF = 3 LDS phase buffers; they also keep the index ring (eight tiles
+//     ahead) and the scale ring.  (LDS-DMA gathers were measured here: ~200 cycles of issue per 1-KB piece, and one wave
+//     mixing DMA with ordinary loads drains vmcnt(0).)
+//   * waves 6, 7 (storers): the staged product rows to HBM as whole rows, non-temporal, RPH rows per phase so that the
+//     store stream is even; scaled back by the row's and the layer's inverse powers of two on the way.
+// One raw s_waitcnt lgkmcnt(0) + s_barrier per phase (all eight waves); 130 KB of LDS at C_out = 256.
+// What bounds it: the three streams through the CU's vector-memory path -- 4 bytes of weights per
+// MAC-column (L2), the gathered rows (beyond L2) and the product rows -- not the matrix pipe (MFMA busy 0.43).
 //
 // LDS phase buffer: [64 rows][16 slots of 16 bytes]; logical chunk c of a row (c = 8 piece + channel / 8) sits in slot
 // c ^ (row & 15): a 16-lane group of ds_read_b128 (rows distinct mod 16, same chunk) touches 16 distinct slots of the
-// 256-byte bank row -- conflict-free -- and a DMA instruction (4 rows x 16 slots) still reads whole 256-byte pieces.
+// 256-byte bank row -- conflict-free (measured: 0 bank conflicts) -- and a requester's load instruction (4 rows x 16
+// slots) still reads whole 256-byte pieces.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -62,9 +67,6 @@ struct ConvWideArgs {
   const int32_t *pair_in, *tile_ptr;
   int cout, K;
   float w_unscale;               // inverse of the layer's weight scale
-#ifdef DGR_WIDE_TIMING
-  unsigned long long *dbg;       // [blocks][8 waves][4] cycle sums (instrumented harness builds only)
-#endif
 };
 
 #define DGR_LDS_PTR(off) ((__attribute__((address_space(3))) void *)(lds + (off)))
@@ -89,19 +91,11 @@ __host__ __device__ constexpr int dgr_wide_pass_base(int h, int npass, int nsp) 
   return b;
 }
 
-#ifdef DGR_WIDE_TIMING
-#define DGR_T(x) const unsigned long long x = __builtin_amdgcn_s_memtime()
-#define DGR_TACC(i, a, b) tsum[i] += (b) - (a)
-#define DGR_TOUT() if (lane == 0) { for (int i_ = 0; i_ < 4; ++i_) a.dbg[((size_t)blockIdx.x * 8 + wave) * 4 + i_] = tsum[i_]; }
-#else
-#define DGR_T(x)
-#define DGR_TACC(i, a, b)
-#define DGR_TOUT()
-#endif
-
-template <int CP, int NB>
+template <int CP, int NB, int WM>
 __global__ void __launch_bounds__(512, 1) sparse_conv_wide_f16x2(ConvWideArgs a, const int4 *__restrict__ tdesc) {
-  constexpr int NP = 2, MB = 2, WN = 4, PW = 4, TM = 64, CK = 64, SK = CK / 16;
+  constexpr int NCW = 4;                 // compute waves
+  constexpr int NP = 2, MB = 2 / WM, WN = NCW / WM, PW = 4, TM = 64, CK = 64, SK = CK / 16;
+  static_assert(WM == 1 || WM == 2, "row split of the compute waves");
   static_assert(TM == DGR_TILE_M && CP % CK == 0, "shape");
   constexpr int PPT = CP / CK, S = CP / 16, NBLK = NB * WN, COUT = 32 * NBLK;
   static_assert(PPT == 1 || PPT == 2 || PPT == 4, "a round of NSET phases is a whole number of tiles");
@@ -113,16 +107,16 @@ __global__ void __launch_bounds__(512, 1) sparse_conv_wide_f16x2(ConvWideArgs a,
   constexpr int RING = 16;               // tiles in the index / scale rings
   constexpr int AH_I = 8, AH_S = 4;      // tile t + AH_I's indices and tile t + AH_S's scales are requested at tile t
   static_assert(RING >= 2 * AH_I && AH_I > LEAD && AH_S >= 3 && AH_S < AH_I, "ring distances");
-#ifndef DGR_WIDE_WD
-#define DGR_WIDE_WD 2   // (4: same speed in tools/microbench/wide_check, 5 spilled registers at Cout = 256)
-#endif
-  constexpr int WD = DGR_WIDE_WD;        // weight ring: k-step g + WD - 1 is requested at step g
+  // weight ring: k-step g + WD - 1 is requested at step g.  Two steps for the 12-MFMA k-steps of the C_out >= 128 shapes
+  // (four: same speed in tools/microbench/wide_check, five spilled registers at C_out = 256); the C_out = 64 shape has
+  // three MFMAs per k-step, so a whole tile of weights (four steps) stays in flight
+  constexpr int WD = MB * NB >= 2 ? 2 : 4;
   static_assert(SK % WD == 0, "the weight ring turns a whole number of times per phase (static register indexing)");
   constexpr int LDS_ST = COUT + 4;       // stage row stride (floats)
   constexpr int NSTG = PPT == 1 ? 2 : 1; // one-phase tiles: a tile is staged while the previous one is still going out
   constexpr int HB = PPT / 2;            // phase of the next tile in which rows 32 .. 63 of a finished tile are staged
   constexpr int RPH = TM / PPT;          // product rows that leave per phase
-  constexpr int PD = 2;                  // mover waves that request (LDS-DMA); the other PW - PD store
+  constexpr int PD = 2;                  // mover waves that request; the other PW - PD store
   constexpr int PTH = 64 * (PW - PD);    // storing threads
   constexpr int CPR = COUT / 4;          // 16-byte pieces per product row
   constexpr int RPP = PTH / CPR;         // rows per store pass of the storing threads
@@ -133,7 +127,6 @@ __global__ void __launch_bounds__(512, 1) sparse_conv_wide_f16x2(ConvWideArgs a,
   constexpr int OFF_SC = OFF_IDX + RING * TM * 4;
   constexpr int LDS_BYTES = OFF_SC + RING * TM * 4;
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-  // ONE LDS object: a second one makes hipcc drain vmcnt before LDS reads next to LDS-DMA (cdna_hip_programming.md)
   __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
 
   const int tid = threadIdx.x;
@@ -149,9 +142,6 @@ __global__ void __launch_bounds__(512, 1) sparse_conv_wide_f16x2(ConvWideArgs a,
   const int n_my = (t_end - t_first + nj - 1) / nj;  // tiles of this block: t_first + i * nj
   // The product rows of tile t leave during tiles t + 1 and t + 2 (below): every role walks n_my + 2 tiles of phases
   const int n_loop = n_my + 2;
-#ifdef DGR_WIDE_TIMING
-  unsigned long long tsum[4] = {0, 0, 0, 0};
-#endif
   // (k, first pair, count) of the block's i-th tile, clamped to its last one; tdesc = the tile descriptors as a
   // restrict-qualified kernel argument, so that the uniform read is a scalar load (its own counter)
   auto desc = [&](int i) -> int4 { return tdesc[t_first + min(max(i, 0), n_my - 1) * nj]; };
@@ -162,24 +152,19 @@ __global__ void __launch_bounds__(512, 1) sparse_conv_wide_f16x2(ConvWideArgs a,
   //   staging (compute waves, between the MFMAs of tile t + 1): rows 0 .. 31 in phase 0, rows 32 .. 63 in phase HB;
   //   leaving (storing waves): rows [(h - 1) RPH, h RPH) in phase h = 1 .. PPT - 1 of tile t + 1, the last RPH rows in
   //   phase 0 of tile t + 2 -- RPH rows every phase, so the stores flow evenly (they, i.e. the HBM write rate, bound
-  //   this kernel together with the matrix pipe).  PPT = 1: both halves are staged in the one phase of tile t + 1 and
-  //   leave in the one phase of tile t + 2, through two stages.
+  //   this kernel together with the other two streams).  PPT = 1: both halves are staged in the one phase of tile t + 1
+  //   and leave in the one phase of tile t + 2, through two stages.
 
-  if (wave >= WN) {
+  if (wave >= NCW) {
     // ================================================================ movers
-    // waves 4, 5 request (LDS-DMA), waves 6, 7 store: vmcnt retires in order, so a wave that did both would see its
-    // DMA "land" only when every older store has been acknowledged
-    const int pw = wave - WN;
-#ifdef DGR_WIDE_PRIO_MOVERS
-    __builtin_amdgcn_s_setprio(DGR_WIDE_PRIO_MOVERS);
-#endif
+    // waves 4, 5 request, waves 6, 7 store: vmcnt retires in order, so a wave that did both would see its
+    // loads "land" only when every older store has been acknowledged
+    const int pw = wave - NCW;
     if (pw < PD) {
       // ------------------------------------------------------------ requesters
       // Plain loads into registers (NSET phases in flight), then 16-byte LDS writes: the lane-linear destination of a
-      // load instruction (4 rows x 16 slots) carries the bank swizzle through the per-lane SOURCE chunk.  (LDS-DMA was
-      // measured here too: ~200 cycles of issue per 1-KB piece, 16 pieces per phase -- slower than the matrix work.)
-      // The index ring is filled by the storing waves (their DMA + wait + a phase barrier), so this wave's vmcnt queue
-      // holds nothing but its own unconditional loads and the compiler's counted waits are exact.
+      // load instruction (4 rows x 16 slots) carries the bank swizzle through the per-lane SOURCE chunk.
+      // This wave's vmcnt queue holds nothing but its own unconditional loads: the compiler's counted waits are exact.
       constexpr int RW = TM / PD, NI = RW / 4;   // rows / load instructions per wave per phase
       f32x4 G[NSET][NI];
       const unsigned char *rb[NI];
@@ -188,11 +173,7 @@ __global__ void __launch_bounds__(512, 1) sparse_conv_wide_f16x2(ConvWideArgs a,
 #pragma unroll
         for (int jj = 0; jj < NI; ++jj) {
           const int r = RW * pw + 4 * jj + (lane >> 4);
-#ifdef DGR_WIDE_ABL_NOGATHER   // every tile gathers rows 0 .. 63: L1 / L2 resident
-          rb[jj] = a.planes + (int64_t)(idx[r] & 63) * ROWB + 16 * ((lane & 15) ^ (r & 15));
-#else
           rb[jj] = a.planes + (int64_t)idx[r] * ROWB + 16 * ((lane & 15) ^ (r & 15));
-#endif
         }
       };
       auto request = [&](int p, f32x4 *Gs) {   // phase p (tile p / PPT; past the last tile: the last tile again)
@@ -236,14 +217,9 @@ __global__ void __launch_bounds__(512, 1) sparse_conv_wide_f16x2(ConvWideArgs a,
       // ---- phase q: land phase q + 2 (requested four phases ago), request phase q + LEAD into the freed set
       auto phase = [&](int q, f32x4 *Gs) {
         if (q % PPT == 0) rings(q / PPT);
-        DGR_T(ta);
         land(q + 2, Gs);
-        DGR_T(tb);
         request(q + LEAD, Gs);
-        DGR_T(tc);
         dgr_phase_barrier();
-        DGR_T(td);
-        DGR_TACC(0, ta, tb); DGR_TACC(1, tb, tc); DGR_TACC(2, tc, td);
       };
       for (int q = 0; q < n_loop * PPT; q += NSET) {   // set of phase p = p % NSET: static register indexing
         phase(q, G[2]);
@@ -251,11 +227,10 @@ __global__ void __launch_bounds__(512, 1) sparse_conv_wide_f16x2(ConvWideArgs a,
         if (q + 2 < n_loop * PPT) phase(q + 2, G[0]);
         if (q + 3 < n_loop * PPT) phase(q + 3, G[1]);
       }
-      DGR_TOUT();
       return;
     }
     // -------------------------------------------------------------- storers
-    const int ptid = tid - 64 * (WN + PD);
+    const int ptid = tid - 64 * (NCW + PD);
     // rows [r0, r0 + RPH) of finished tile u: LDS stage -> HBM, whole rows, scaled back.  Streaming stores: a product
     // row is read exactly once, by reduce_rows.
     auto store_rows = [&](int u, int r0) {
@@ -274,9 +249,6 @@ __global__ void __launch_bounds__(512, 1) sparse_conv_wide_f16x2(ConvWideArgs a,
 #pragma unroll
       for (int i = 0; i < NPS; ++i) {
         const int r = r0 + i * RPP + ptid / CPR;
-#ifdef DGR_WIDE_ABL_NOSTORE
-        if (v[i].x == 123.456f)
-#endif
         if (r < d.z) __builtin_nontemporal_store(v[i], reinterpret_cast<f32x4 *>(a.y + (int64_t)(d.y + r) * COUT + c4));
       }
     };
@@ -284,13 +256,9 @@ __global__ void __launch_bounds__(512, 1) sparse_conv_wide_f16x2(ConvWideArgs a,
     dgr_phase_barrier();   // P1
     auto sphase = [&](int t, auto hc) {
       constexpr int h = decltype(hc)::value;
-      DGR_T(ta);
       if constexpr (h == 0) store_rows(t - 2, (PPT - 1) * RPH);
       else store_rows(t - 1, (h - 1) * RPH);
-      DGR_T(tb);
       dgr_phase_barrier();
-      DGR_T(tc);
-      DGR_TACC(0, ta, tb); DGR_TACC(2, tb, tc);
     };
     for (int t = 0; t < n_loop; ++t) {
       sphase(t, std::integral_constant<int, 0>());
@@ -300,47 +268,30 @@ __global__ void __launch_bounds__(512, 1) sparse_conv_wide_f16x2(ConvWideArgs a,
         sphase(t, std::integral_constant<int, 3>());
       }
     }
-    DGR_TOUT();
     return;
   }
 
   // ================================================================== compute waves
-#ifdef DGR_WIDE_PRIO_COMPUTE
-  __builtin_amdgcn_s_setprio(DGR_WIDE_PRIO_COMPUTE);
-#endif
-  const int wn = wave;
+  const int wn = wave % WN, wm = wave / WN;   // output-channel block / row half of this wave
   int4 dc = desc(0), dn = desc(1);   // this tile's and the next tile's descriptor
   uint4 w[WD][NB][NP];
   auto wload = [&](int k, int s, uint4 (*ws)[NP]) {
-#ifdef DGR_WIDE_ABL_BONCE   // timing ablations (outputs are garbage): weights L1-resident, no L2 weight stream
-    const uint4 *p = a.wb + ((int64_t)(0 * S + (s & 1)) * NBLK + wn * NB) * 64 + lane;
-#else
     const uint4 *p = a.wb + ((int64_t)(k * S + s) * NBLK + wn * NB) * 64 + lane;
-#endif
-#if defined(DGR_WIDE_ABL_HALFW)   // only the h piece is loaded (half the weight traffic)
-#pragma unroll
-    for (int j = 0; j < NB; ++j) { ws[j][0] = p[j * 64]; ws[j][1] = ws[j][0]; }
-#elif defined(DGR_WIDE_ABL_NOW)   // no weight traffic at all
-    if (k == 0x7fffffff) { ws[0][0] = p[0]; }
-#else
 #pragma unroll
     for (int j = 0; j < NB; ++j)
 #pragma unroll
       for (int pc = 0; pc < NP; ++pc) ws[j][pc] = p[(int64_t)pc * a.piece_stride + j * 64];
-#endif
   };
-#ifdef DGR_WIDE_ABL_NOW
-  for (int g = 0; g < WD; ++g) for (int j = 0; j < NB; ++j) for (int pc = 0; pc < NP; ++pc) w[g][j][pc] = a.wb[lane + 64 * (g + j + pc)];
-#endif
 #pragma unroll
   for (int g = 0; g < WD - 1; ++g) wload(dc.x, g % S, w[g]);
   dgr_phase_barrier();   // P0
   dgr_phase_barrier();   // P1
-  // operands of k-step s out of phase buffer b: row = 32 i + (lane & 31), chunk = 2 s + (lane >> 5) of piece h (+ 8: m)
+  // operands of k-step s out of phase buffer b: row = 32 (MB wm + i) + (lane & 31), chunk = 2 s + (lane >> 5) of piece h
+  // (+ 8: m)
   uint4 op[2][MB][NP];
-  // byte offset of this lane's h chunk of k-step 0 in row (lane & 31); k-step s: ^ (32 s) (chunk 2 s + (lane >> 5) =
-  // 2 s ^ (lane >> 5)); the m chunk: ^ 128
-  const int lofs0 = (lane & 31) * 256 + 16 * ((lane >> 5) ^ (lane & 15));
+  // byte offset of this lane's h chunk of k-step 0 in its first row; k-step s: ^ (32 s) (chunk 2 s + (lane >> 5) =
+  // 2 s ^ (lane >> 5)); the m chunk: ^ 128.  (The row term is a multiple of 256: it does not meet the xor bits.)
+  const int lofs0 = (32 * MB * wm + (lane & 31)) * 256 + 16 * ((lane >> 5) ^ (lane & 15));
   auto oload = [&](int b, int s, uint4 (*o)[NP]) {
     const unsigned char *p = lds + b * BUFB + (lofs0 ^ (32 * s));
     const unsigned char *pm = lds + b * BUFB + (lofs0 ^ (32 * s) ^ 128);
@@ -352,15 +303,18 @@ __global__ void __launch_bounds__(512, 1) sparse_conv_wide_f16x2(ConvWideArgs a,
   };
   oload(0, 0, op[0]);
   int buf = 0;
-  // raw accumulators of row half i -> LDS stage, the NB 16-byte pieces number s NB .. of the half's 4 NB:
+  // raw accumulators of this wave's row group i -> LDS stage, NPC 16-byte pieces per k-step (of the group's 4 NB):
   // D column (pair) = lane & 31, D row (channel) = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+  constexpr int NPC = (4 * NB + SK - 1) / SK;
   auto stage_pieces = [&](float *st, const f32x16 (&ac)[MB][NB], int i, int s) {
-    float *dst = st + (32 * i + (lane & 31)) * LDS_ST;
+    float *dst = st + (32 * (MB * wm + i) + (lane & 31)) * LDS_ST;
 #pragma unroll
-    for (int u = 0; u < NB; ++u) {
-      const int wq = s * NB + u, j = wq / 4, g = wq % 4;
-      const int col = 32 * (wn * NB + j) + 8 * g + 4 * (lane >> 5);
-      *reinterpret_cast<f32x4 *>(dst + col) = f32x4{ac[i][j][4 * g], ac[i][j][4 * g + 1], ac[i][j][4 * g + 2], ac[i][j][4 * g + 3]};
+    for (int u = 0; u < NPC; ++u) {
+      const int wq = s * NPC + u, j = wq / 4, g = wq % 4;
+      if (wq < 4 * NB) {
+        const int col = 32 * (wn * NB + j) + 8 * g + 4 * (lane >> 5);
+        *reinterpret_cast<f32x4 *>(dst + col) = f32x4{ac[i][j][4 * g], ac[i][j][4 * g + 1], ac[i][j][4 * g + 2], ac[i][j][4 * g + 3]};
+      }
     }
   };
   // One tile of phases: multiply tile t into `ac` (if it exists), stage the finished tile t - 1 out of `ad` on the way
@@ -381,52 +335,43 @@ __global__ void __launch_bounds__(512, 1) sparse_conv_wide_f16x2(ConvWideArgs a,
       }
       const int nbuf = buf == NBUF - 1 ? 0 : buf + 1;
       const int s0 = h * SK;
-      DGR_T(ta);
 #pragma unroll
       for (int s = 0; s < SK; ++s) {
-        {
-          {   // unconditional (past the last tile: the last tile's descriptor again), so the wait counts are static
-            const int sg = s0 + s + WD - 1;
-            wload(sg < S ? dc.x : dn.x, sg < S ? sg : sg - S, w[(s + WD - 1) % WD]);
-          }
-          // next k-step's operands; the next phase's buffer has been complete since the last barrier
-          if (s + 1 < SK) oload(buf, s + 1, op[(s + 1) & 1]);
-          else oload(nbuf, 0, op[0]);
-          // pin the prefetches ahead of the MFMA block (left to the compiler, or interleaved one per MFMA gap with
-          // sched_group_barrier, the loads are waited for early: 2.36 / 2.19 ms against 1.95 ms, tools/microbench/wide_check)
-          __builtin_amdgcn_sched_barrier(0);
-          uint4 (*wc)[NP] = w[s % WD];
-          uint4 (*oc)[NP] = op[s & 1];
-#ifdef DGR_WIDE_ABL_NOMFMA
-          if (oc[0][0].x == 0x12345678u)
-#endif
-          {
+        {   // unconditional (past the last tile: the last tile's descriptor again), so the wait counts are static
+          const int sg = s0 + s + WD - 1;
+          wload(sg < S ? dc.x : dn.x, sg < S ? sg : sg - S, w[(s + WD - 1) % WD]);
+        }
+        // next k-step's operands; the next phase's buffer has been complete since the last barrier
+        if (s + 1 < SK) oload(buf, s + 1, op[(s + 1) & 1]);
+        else oload(nbuf, 0, op[0]);
+        // pin the prefetches ahead of the MFMA block (left to the compiler, or interleaved one per MFMA gap with
+        // sched_group_barrier, the loads are waited for early: 2.36 / 2.19 ms against 1.95 ms, tools/microbench/wide_check)
+        __builtin_amdgcn_sched_barrier(0);
+        uint4 (*wc)[NP] = w[s % WD];
+        uint4 (*oc)[NP] = op[s & 1];
 #define DGR_WIDE_TERM(WP, OP)                                                                                         \
   _Pragma("unroll") for (int i = 0; i < MB; ++i) _Pragma("unroll") for (int j = 0; j < NB; ++j)                       \
       ac[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wc[j][WP]),                          \
                                                         __builtin_bit_cast(f16x8, oc[i][OP]), ac[i][j], 0, 0, 0);
-          DGR_WIDE_TERM(1, 0)   // wm . xh
-          DGR_WIDE_TERM(0, 1)   // wh . xm
-          DGR_WIDE_TERM(0, 0)   // wh . xh
+        DGR_WIDE_TERM(1, 0)   // wm . xh
+        DGR_WIDE_TERM(0, 1)   // wh . xm
+        DGR_WIDE_TERM(0, 0)   // wh . xh
 #undef DGR_WIDE_TERM
-          }
-        }
         // the finished tile's accumulators leave for the stage a few pieces per k-step, in the shadow of the MFMAs
+        // (MB = 2: row group 0 in phase 0, row group 1 in phase HB; MB = 1: the wave's one row group in phase 0)
         if (stage_prev) {
           if (h == 0) stage_pieces(st, ad, 0, s);
-          if (h == HB) stage_pieces(st, ad, 1, s);
+          if constexpr (MB > 1) {
+            if (h == HB) stage_pieces(st, ad, 1, s);
+          }
         }
       }
-      DGR_T(tb);
       if (h == PPT - 1) {
         dc = dn;
         dn = desc(t + 2);
       }
       buf = nbuf;
-      DGR_T(tc);
       dgr_phase_barrier();
-      DGR_T(td);
-      DGR_TACC(0, ta, tb); DGR_TACC(1, tb, tc); DGR_TACC(2, tc, td);
     }
   };
   f32x16 accA[MB][NB], accB[MB][NB];
@@ -434,23 +379,23 @@ __global__ void __launch_bounds__(512, 1) sparse_conv_wide_f16x2(ConvWideArgs a,
     ctile(t, accA, accB);
     if (t + 1 < n_loop) ctile(t + 1, accB, accA);
   }
-  DGR_TOUT();
 }
 
-template <int CP, int NB>
+template <int CP, int NB, int WM>
 static int launch_wide(const ConvWideArgs &ka, const int4 *tile_desc, int64_t tile_bound, int num_cus, hipStream_t stream) {
   int64_t grid = num_cus;
   if (tile_bound < grid) grid = tile_bound;
   grid = (grid + 7) / 8 * 8;
   if (grid < 8) grid = 8;
-  sparse_conv_wide_f16x2<CP, NB><<<(int)grid, 512, 0, stream>>>(ka, tile_desc);
+  sparse_conv_wide_f16x2<CP, NB, WM><<<(int)grid, 512, 0, stream>>>(ka, tile_desc);
   DGR_LAUNCH_CHECK();
   return DGR_OK;
 }
 
 bool dgr_conv_wide_supported(int cin_pad, int cin, int cout) {
   if (cin != cin_pad) return false;
-  return (cout == 128 && (cin == 64 || cin == 128 || cin == 256)) || (cout == 256 && (cin == 128 || cin == 256));
+  return (cout == 64 && cin == 64) || (cout == 128 && (cin == 64 || cin == 128 || cin == 256)) ||
+         (cout == 256 && (cin == 128 || cin == 256));
 }
 
 int dgr_conv_wide_launch(const DgrConvLaunch &a, const DgrSplitRows &in, const void *wb, int64_t piece_stride,
@@ -463,29 +408,27 @@ int dgr_conv_wide_launch(const DgrConvLaunch &a, const DgrSplitRows &in, const v
   ka.planes = in.planes; ka.row_scale = in.scale; ka.y = a.y;
   ka.wb = static_cast<const uint4 *>(wb); ka.piece_stride = piece_stride;
   ka.pair_in = a.pair_in; ka.tile_ptr = a.tile_ptr; ka.cout = a.cout; ka.K = a.K; ka.w_unscale = w_unscale;
-#ifdef DGR_WIDE_TIMING
-  ka.dbg = g_dbg;
-#endif
   const int64_t tile_bound = a.tile_bound > 0 ? a.tile_bound : (int64_t)num_cus * 4;
-#define DGR_WIDE(CPV, NBV)                                                             \
-  do {                                                                                 \
-    if (kernel_name) *kernel_name = "sparse_conv_wide_f16x2<" #CPV ", " #NBV ">";      \
-    return launch_wide<CPV, NBV>(ka, a.tile_desc, tile_bound, num_cus, stream);        \
+#define DGR_WIDE(CPV, NBV, WMV)                                                                 \
+  do {                                                                                          \
+    if (kernel_name) *kernel_name = "sparse_conv_wide_f16x2<" #CPV ", " #NBV ", " #WMV ">";     \
+    return launch_wide<CPV, NBV, WMV>(ka, a.tile_desc, tile_bound, num_cus, stream);            \
   } while (0)
-  if (a.cout == 128 && a.cin == 64) DGR_WIDE(64, 1);
-  if (a.cout == 128 && a.cin == 128) DGR_WIDE(128, 1);
-  if (a.cout == 128 && a.cin == 256) DGR_WIDE(256, 1);
-  if (a.cout == 256 && a.cin == 128) DGR_WIDE(128, 2);
-  if (a.cout == 256 && a.cin == 256) DGR_WIDE(256, 2);
+  if (a.cout == 64 && a.cin == 64) DGR_WIDE(64, 1, 2);
+  if (a.cout == 128 && a.cin == 64) DGR_WIDE(64, 1, 1);
+  if (a.cout == 128 && a.cin == 128) DGR_WIDE(128, 1, 1);
+  if (a.cout == 128 && a.cin == 256) DGR_WIDE(256, 1, 1);
+  if (a.cout == 256 && a.cin == 128) DGR_WIDE(128, 2, 1);
+  if (a.cout == 256 && a.cin == 256) DGR_WIDE(256, 2, 1);
 #undef DGR_WIDE
   dgr_set_error("wide conv: no kernel for Cin %d, Cout %d", a.cin, a.cout);
   return DGR_EINVAL;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Row scales / split rows of an EXISTING f32 tensor.  On the network path the producers write both themselves
-// (reduce_rows, conv.hip); dgr_row_scale serves the output-stationary 3-D kernel (conv_os.hip), dgr_split_rows the
-// single-layer debug entry point and inputs that did not come out of a reduction.
+// Row maxima / split rows of an EXISTING f32 tensor.  On the network path the producers leave both behind themselves
+// (reduce_rows in conv.hip; the epilogues of conv_os.hip / conv_dense.hip / the conv1 kernels); these serve the
+// single-layer debug entry point and inputs that did not come out of one of those kernels.
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
@@ -494,7 +437,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 template <int LPR, bool SPLIT>
 __global__ void __launch_bounds__(256) row_scale_kernel(const float *__restrict__ in, int in_ld, int cin, int relu,
                                                         const int32_t *__restrict__ n_dev, float *__restrict__ out,
-                                                        unsigned char *__restrict__ planes) {
+                                                        unsigned char *__restrict__ planes, uint32_t *__restrict__ amax_out) {
   constexpr int RPW = 64 / LPR;   // rows per wave
   const int lane = threadIdx.x & 63;
   const int sub = lane / LPR, l = lane % LPR;
@@ -515,7 +458,10 @@ __global__ void __launch_bounds__(256) row_scale_kernel(const float *__restrict_
 #pragma unroll
     for (int d = LPR / 2; d >= 1; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
     const float sx = dgr_row_scale_of(mx);
-    if (l == 0 && r < n) out[r] = sx;
+    if (l == 0 && r < n) {
+      if (out) out[r] = sx;
+      if (amax_out) amax_out[r] = mx;
+    }
     if constexpr (SPLIT) {
       if (r < n) {
         const float *row = in + r * in_ld;
@@ -538,7 +484,7 @@ __global__ void __launch_bounds__(256) row_scale_kernel(const float *__restrict_
 }
 
 static int row_scale_launch(const float *in, int in_ld, int cin, int relu, const int32_t *n_dev, int64_t n_cap, float *out,
-                            unsigned char *planes, hipStream_t stream) {
+                            unsigned char *planes, uint32_t *amax_out, hipStream_t stream) {
   DGR_REQUIRE((cin & 3) == 0 && (in_ld & 3) == 0 && cin >= 4, "row scale: channel count and row stride must be multiples of 4");
   const int lpr = cin >= 256 ? 64 : cin >= 128 ? 32 : cin >= 64 ? 16 : cin >= 32 ? 8 : 4;   // power of two: shuffle tree
   int64_t grid = dgr_ceil_div(n_cap, 4 * (64 / lpr));
@@ -546,8 +492,8 @@ static int row_scale_launch(const float *in, int in_ld, int cin, int relu, const
   if (grid < 1) grid = 1;
 #define DGR_RS(L)                                                                                                   \
   do {                                                                                                              \
-    if (planes) row_scale_kernel<L, true><<<(int)grid, 256, 0, stream>>>(in, in_ld, cin, relu, n_dev, out, planes); \
-    else row_scale_kernel<L, false><<<(int)grid, 256, 0, stream>>>(in, in_ld, cin, relu, n_dev, out, nullptr);      \
+    if (planes) row_scale_kernel<L, true><<<(int)grid, 256, 0, stream>>>(in, in_ld, cin, relu, n_dev, out, planes, amax_out); \
+    else row_scale_kernel<L, false><<<(int)grid, 256, 0, stream>>>(in, in_ld, cin, relu, n_dev, out, nullptr, amax_out);      \
   } while (0)
   switch (lpr) {
     case 64: DGR_RS(64); break;
@@ -561,13 +507,13 @@ static int row_scale_launch(const float *in, int in_ld, int cin, int relu, const
   return DGR_OK;
 }
 
-int dgr_row_scale(const float *in, int in_ld, int cin, int relu, const int32_t *n_dev, int64_t n_cap, float *out,
-                  hipStream_t stream) {
-  return row_scale_launch(in, in_ld, cin, relu, n_dev, n_cap, out, nullptr, stream);
+int dgr_row_amax(const float *in, int in_ld, int cin, int relu, const int32_t *n_dev, int64_t n_cap, uint32_t *out,
+                 hipStream_t stream) {
+  return row_scale_launch(in, in_ld, cin, relu, n_dev, n_cap, nullptr, nullptr, out, stream);
 }
 
 int dgr_split_rows(const float *in, int in_ld, int relu, const int32_t *n_dev, int64_t n_cap, const DgrSplitRows &out,
                    hipStream_t stream) {
   DGR_REQUIRE(out.planes && out.scale && out.channels % 64 == 0, "split rows: need planes, scales and a multiple of 64 channels");
-  return row_scale_launch(in, in_ld, out.channels, relu, n_dev, n_cap, out.scale, out.planes, stream);
+  return row_scale_launch(in, in_ld, out.channels, relu, n_dev, n_cap, out.scale, out.planes, nullptr, stream);
 }

@@ -156,7 +156,8 @@ int dgr_nbr_counts(const DgrNbrTable &t, const int32_t *n_out_dev, int64_t count
 // conv1 fused with its neighbour search (D = 3, Cin <= 8, Cout = 32): no kernel map for the ks^3 offsets
 int dgr_conv1_probe(DgrArena &arena, const DgrCoordMap &cm, int ks, const float *in, int in_ld, int cin,
                     const float *w_tiled, const float *shift, float *out, int out_ld, int32_t *pair_count,
-                    hipStream_t stream, const float *w_compact = nullptr, const char **kernel_name = nullptr);
+                    hipStream_t stream, const float *w_compact = nullptr, const char **kernel_name = nullptr,
+                    uint32_t *out_amax = nullptr);
 // voxelise helper (coordmap.hip)
 int dgr_unique_rows(DgrArena &arena, const int32_t *keys, int64_t n, int nc, int32_t *first_flag,
                     int32_t *rank, int32_t *n_unique_dev, int32_t **table_out, uint32_t *mask_out,
@@ -201,10 +202,11 @@ struct DgrSplitRows {
 bool dgr_conv_wide_supported(int cin_pad, int cin, int cout);
 int dgr_conv_wide_launch(const DgrConvLaunch &a, const DgrSplitRows &in, const void *wb, int64_t piece_stride,
                          float w_unscale, int num_cus, hipStream_t stream, const char **kernel_name = nullptr);
-// out[r] = 2^(14 - floor(log2 max_c |in[r][c]|)) (after the pending ReLU): the row's largest entry lands in
-// [2^14, 2^15) when multiplied by it; 1 for rows of zeros
-int dgr_row_scale(const float *in, int in_ld, int cin, int relu, const int32_t *n_dev, int64_t n_cap, float *out,
-                  hipStream_t stream);
+// out[r] = the bit pattern of max_c |in[r][c]| (after the pending ReLU): dgr_row_scale_of(out[r]) is the power of two
+// that moves the row's largest entry into [2^14, 2^15).  For tensors that did not come out of one of the conv kernels
+// (their epilogues leave the same value behind: DgrConvOsLaunch::out_amax).
+int dgr_row_amax(const float *in, int in_ld, int cin, int relu, const int32_t *n_dev, int64_t n_cap, uint32_t *out,
+                 hipStream_t stream);
 // the same + the rows' two f16 planes (a tensor that did not come out of dgr_reduce_rows)
 int dgr_split_rows(const float *in, int in_ld, int relu, const int32_t *n_dev, int64_t n_cap, const DgrSplitRows &out,
                    hipStream_t stream);
@@ -224,7 +226,12 @@ struct DgrConvOsLaunch {
   float *out; int out_ld, out_relu;
   const float *w16, *shift;
   const void *wb3; int64_t piece_stride;   // split weights: two f16 pieces (16-byte units per piece), or null
-  const float *row_scale = nullptr; float w_unscale = 1.f;   // ... with the input's row scales and the layer's inverse weight scale
+  // ... with, per input row, the bits of its largest |x| after the pending ReLU (the row's power-of-two scale is
+  // dgr_row_scale_of of it; written by the row's PRODUCER, see out_amax) and the layer's inverse weight scale
+  const uint32_t *row_amax = nullptr; float w_unscale = 1.f;
+  // producer side: atomicMax of every written row's largest |x| (after out_relu) into up to two zero-initialised
+  // arrays -- the tensor's own and, for a tensor that is a column range of a concatenation, the concatenation's
+  uint32_t *out_amax = nullptr, *out_amax2 = nullptr;
   int64_t n_in_cap = 0;                    // row capacity of the input tensor (32-bit gather offsets)
   const float *res; int res_ld, res_relu;
   int rows_per_block;   // 64 | 32 | 16 output rows per workgroup

@@ -232,18 +232,33 @@ __global__ void __launch_bounds__(KM_THREADS)
 // kernel's replay of an overflowed wave places the pair.
 struct PrunedArgs {
   const int32_t *out_coords, *n_out_dev;
-  DgrHalfBuckets hb;
+  const int4 *out_order;   // the OUTPUT map's rows in the order of its own first-half buckets: (x1, y1, z1, row)
+  int64_t n_cap;           // row capacity of the output map (thread t = ja * n_cap + position in out_order)
+  DgrHalfBuckets hb;       // first-half buckets of the INPUT map
   int ts_in, symmetric;
+  int row_major;           // EXPERIMENT (DGR_KMAP_ROWMAJOR): t = p * NJ + ja
 };
+// Thread t = (first-half offset ja, position p in the output map's bucket order): the 64 lanes of a wave are 64
+// consecutive rows of (mostly) ONE first-half bucket under the SAME first-half offset, so they scan the same neighbour
+// bucket in lock step -- every load of the loop below is one address for the whole wave -- and a wave's records are
+// spread over 64 rows instead of all offsets of 4.6 rows (rows with hundreds of neighbours overflowed a region alone).
 template <class Emit>
 __device__ __forceinline__ void pruned_search6(const PrunedArgs &a, int64_t t, Emit &&emit) {
   const int NJ = a.symmetric ? 14 : 27;
   const int ts_in = a.ts_in;
-  const int64_t o = t / NJ;
-  const int ja = (int)(t - o * NJ);
+  const int ja = a.row_major == 1 ? (int)(t % NJ) : (int)(t / a.n_cap);
+  const int64_t p = a.row_major == 1 ? t / NJ : t - (int64_t)ja * a.n_cap;
   int b = -1;
-  const int32_t *co = a.out_coords + o * 7;
-  if (o < *a.n_out_dev) {
+  int64_t o = 0;
+  int c4 = 0, c5 = 0, c6 = 0;
+  if (ja < NJ && p < *a.n_out_dev) {
+    int4 me = a.out_order[p];
+    if (a.row_major == 2) {   // EXPERIMENT: rows in row order
+      const int32_t *cc = a.out_coords + p * 7;
+      me = make_int4(cc[4], cc[5], cc[6], (int)p);
+    }
+    o = me.w; c4 = me.x; c5 = me.y; c6 = me.z;
+    const int32_t *co = a.out_coords + o * 7;
     int32_t q[4];
     q[0] = co[0];
     q[1] = co[1] + ((ja % 3) - 1) * ts_in;
@@ -251,7 +266,6 @@ __device__ __forceinline__ void pruned_search6(const PrunedArgs &a, int64_t t, E
     q[3] = co[3] + ((ja / 9) - 1) * ts_in;
     b = dgr_lookup<4>(a.hb.table, a.hb.mask, a.hb.bkeys, q);
   }
-  const int c4 = b >= 0 ? co[4] : 0, c5 = b >= 0 ? co[5] : 0, c6 = b >= 0 ? co[6] : 0;
   const int beg = b >= 0 ? a.hb.start[b] : 0, end = b >= 0 ? a.hb.start[b + 1] : 0;
   // four bucket entries per trip, fetched together
   for (int p0 = beg; p0 < end; p0 += 4) {
@@ -597,6 +611,7 @@ static int build_kernel_map3(DgrArena &arena, const DgrCoordMap &in, const DgrCo
 struct Kmap6Job {
   const DgrCoordMap *in, *out;
   const DgrHalfBuckets *hb;     // first-half buckets of `in`
+  const DgrHalfBuckets *hb_out; // ... of `out` (the order the search walks the output rows in)
   bool need_in_csr, want_pair_out, want_pair_k;
   DgrKernelMap *km;
 };
@@ -605,6 +620,8 @@ static int build_kernel_maps6(DgrArena &arena, const Kmap6Job *jobs, int nj, int
   constexpr int K = 729, KW = (K + 31) / 32;
   DGR_REQUIRE(nj >= 1 && nj <= KM_MAXJOBS, "6-D kernel maps: %d jobs", nj);
   static const bool generic8 = getenv("DGR_KMAP_GENERIC8") != nullptr;   // A/B: the stride-8 map by 364 hash probes per row
+  static const int row_major = getenv("DGR_KMAP_ROWMAJOR") ? atoi(getenv("DGR_KMAP_ROWMAJOR")) : 0;    // EXPERIMENT
+  static const int region8 = getenv("DGR_KMAP_REGION8") ? atoi(getenv("DGR_KMAP_REGION8")) : 2 * KM_REGION;   // EXPERIMENT
   struct Tr {   // transients of one job
     int RB, symmetric;
     bool pruned;
@@ -644,7 +661,7 @@ static int build_kernel_maps6(DgrArena &arena, const Kmap6Job *jobs, int nj, int
     r.RB = (int)dgr_ceil_div(r.n_cap, KM_THREADS);
     // same-stride maps (in and out are the SAME coordinate set) are symmetric: search half the offsets
     r.symmetric = (J.in->coords == J.out->coords && !J.need_in_csr) ? 1 : 0;
-    r.pruned = J.hb && J.hb->built && !(generic8 && J.in->ts == 8 && r.symmetric);
+    r.pruned = J.hb && J.hb->built && J.hb_out && J.hb_out->built && !(generic8 && J.in->ts == 8 && r.symmetric);
     DGR_ALLOC(r.counts, arena, int32_t, (int64_t)K * r.RB);
     DGR_ALLOC(r.base, arena, int32_t, (int64_t)K * r.RB);
     DGR_ALLOC(r.total, arena, int32_t, 1);
@@ -653,11 +670,14 @@ static int build_kernel_maps6(DgrArena &arena, const Kmap6Job *jobs, int nj, int
     DGR_ALLOC(r.cell, arena, int4, (int64_t)r.RB * (KM_THREADS / 64) * K);
     // hit list: one region per wave of the search (pruned: KM_REGION records, overflow -> replay; generic: the most 64
     // of its threads can produce)
+    // (pruned: thread = (first-half offset, row): whole row blocks per offset, so that a wave never mixes offsets)
     const int64_t search_blocks = r.pruned ? dgr_ceil_div(r.n_cap * (r.symmetric ? 14 : 27), KM_THREADS)
                                            : (int64_t)r.RB * dgr_ceil_div(r.symmetric ? K / 2 : K, KM_PROBES);
     r.hit_waves = search_blocks * (KM_THREADS / 64);
-    // (fine levels: 2 .. 7 neighbours per row, a wave records a few dozen hits; stride 4 / 8: up to a few hundred)
-    r.hl.region = r.pruned ? (J.in->ts >= 4 ? KM_REGION : KM_REGION / 2) : 64 * (KM_PROBES * (r.symmetric ? 2 : 1) + 1);
+    // (a wave = 64 rows under one first-half offset: a dozen records at the fine levels and in the strided maps, ~180 in
+    // the stride-8 map with its 39 neighbours per row, several times that in its dense corners)
+    r.hl.region = r.pruned ? ((J.in->ts >= 8 && r.symmetric) ? region8 : KM_REGION / 2)
+                           : 64 * (KM_PROBES * (r.symmetric ? 2 : 1) + 1);
     DGR_REQUIRE(r.hit_waves < (1ll << 31), "6-D kernel map: too many search waves");
     DGR_ALLOC(r.hl.recs, arena, unsigned long long, r.hit_waves * r.hl.region);
     DGR_ALLOC(r.hl.wave_count, arena, int32_t, r.hit_waves);
@@ -670,7 +690,7 @@ static int build_kernel_maps6(DgrArena &arena, const Kmap6Job *jobs, int nj, int
     const Kmap6Job &J = jobs[m];
     Tr &r = t[m];
     if (r.pruned) {
-      const PrunedArgs pa{J.out->coords, J.out->n_dev, *J.hb, J.in->ts, r.symmetric};
+      const PrunedArgs pa{J.out->coords, J.out->n_dev, J.hb_out->second, r.n_cap, *J.hb, J.in->ts, r.symmetric, row_major};
       kmap_bits_pruned6<<<(int)(r.hit_waves / (KM_THREADS / 64)), KM_THREADS, 0, stream>>>(pa, KW, r.mask_out, r.mask_in, r.hl);
     } else {
       const int n_probe = r.symmetric ? K / 2 : K;
@@ -712,8 +732,8 @@ static int build_kernel_maps6(DgrArena &arena, const Kmap6Job *jobs, int nj, int
     DgrKernelMap *km = J.km;
     const PlaceArgs pl{K, KW, r.RB, r.mask_out, km->out_ptr, r.cell, r.base, km->pair_in, km->pair_out, km->pair_k, km->out_pos,
                        km->pair_cap, overflow, r.mask_in, km->in_ptr, km->in_pos, r.wpre_out, r.wpre_in};
-    PrunedArgs pa{J.out->coords, J.out->n_dev, DgrHalfBuckets(), J.in->ts, r.symmetric};
-    if (r.pruned) pa.hb = *J.hb;
+    PrunedArgs pa{J.out->coords, J.out->n_dev, nullptr, r.n_cap, DgrHalfBuckets(), J.in->ts, r.symmetric, row_major};
+    if (r.pruned) { pa.hb = *J.hb; pa.out_order = J.hb_out->second; }
     const int blocks = (int)std::min<int64_t>(dgr_ceil_div(r.hit_waves, KM_THREADS / 64), 16384);
     kmap_place_hits<<<blocks, KM_THREADS, 0, stream>>>(r.hl, (int)r.hit_waves, pl, pa);
     km->built = true;
@@ -838,9 +858,9 @@ int dgr_build_maps(DgrArena &arena, const int32_t *coords, int64_t N, int D, int
     // first-half buckets of every level: the pruned search of all seven maps (since round 4 also at tensor stride 8)
     for (int l = 0; l < 4; ++l) DGR_CHECK(dgr_build_half_buckets(arena, ms->cm[l], &ms->hb[l], stream));
     Kmap6Job jobs[7];
-    for (int l = 0; l < 4; ++l) jobs[l] = {&ms->cm[l], &ms->cm[l], &ms->hb[l], false, !lean, !lean || l == 0, &ms->same[l]};
+    for (int l = 0; l < 4; ++l) jobs[l] = {&ms->cm[l], &ms->cm[l], &ms->hb[l], &ms->hb[l], false, !lean, !lean || l == 0, &ms->same[l]};
     // strided maps are also used swapped by the transposed convs: the in-major CSR too
-    for (int l = 0; l < 3; ++l) jobs[4 + l] = {&ms->cm[l], &ms->cm[l + 1], &ms->hb[l], true, true, !lean, &ms->down[l]};
+    for (int l = 0; l < 3; ++l) jobs[4 + l] = {&ms->cm[l], &ms->cm[l + 1], &ms->hb[l], &ms->hb[l + 1], true, true, !lean, &ms->down[l]};
     DGR_CHECK(build_kernel_maps6(arena, jobs, 7, cap_row, ms->overflow, stream));
     ms->conv1 = ms->same[0];
     return DGR_OK;

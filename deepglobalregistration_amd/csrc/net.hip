@@ -327,6 +327,10 @@ struct Tensor {
   int relu;  // consumers must apply ReLU when reading
   DgrSplitRows split;   // set for tensors a wide layer gathers: written by the tensor's producer (ReLU applied)
   bool split_only = false;   // ... and nobody reads the f32 rows (a block's middle tensor): they are not written
+  // 3-D net: per row the bits of its largest |x| (after the pending ReLU), left behind by the tensor's producer for the
+  // split-operand consumers (conv_os.hip / conv_dense.hip); amax2: the same array of the concatenation this tensor is a
+  // column range of.  Zero-initialised, filled by atomicMax.
+  uint32_t *amax = nullptr, *amax2 = nullptr;
 };
 
 struct Fwd {
@@ -393,11 +397,15 @@ struct Fwd {
       o.w_unscale = L.w_unscale; o.n_in_cap = cin_map.n_cap;
       static const bool os_f32 = getenv("DGR_EXACT_F32") != nullptr;   // (conv_os.hip reads the same switch)
       if (L.w16b && !os_f32) {
-        float *rs;
-        DGR_ALLOC(rs, ctx->arena, float, cin_map.n_cap);
-        DGR_CHECK(dgr_row_scale(in.ptr, in.ld, L.cin, in.relu, cin_map.n_dev, cin_map.n_cap, rs, stream));
-        o.row_scale = rs;
+        o.row_amax = in.amax;
+        if (!o.row_amax) {   // a tensor that did not come out of one of the conv kernels (the single-layer debug entry)
+          uint32_t *mx;
+          DGR_ALLOC(mx, ctx->arena, uint32_t, cin_map.n_cap);
+          DGR_CHECK(dgr_row_amax(in.ptr, in.ld, L.cin, in.relu, cin_map.n_dev, cin_map.n_cap, mx, stream));
+          o.row_amax = mx;
+        }
       }
+      o.out_amax = out.amax; o.out_amax2 = out.amax2;
       o.res = res ? res->ptr : nullptr; o.res_ld = res ? res->ld : 0; o.res_relu = res ? res->relu : 0;
       o.nbr = t; o.n_out_dev = cout_map.n_dev; o.n_out_cap = cout_map.n_cap;
       o.cin = L.cin; o.cin_pad = L.cin_pad; o.cout = L.cout;
@@ -406,7 +414,7 @@ struct Fwd {
       bool same_stride = false;
       for (int l = 0; l < 4; ++l) same_stride = same_stride || t == &ms.nsame[l];
       // (its buffer loads address the input with 32-bit byte offsets: tensors of 2 GB and more stay on the list kernel)
-      o.dense = same_stride && o.row_scale && !os_lists && dgr_conv_dense_supported(L.cin, L.cin_pad, L.cout) &&
+      o.dense = same_stride && o.row_amax && !os_lists && dgr_conv_dense_supported(L.cin, L.cin_pad, L.cout) &&
                 cin_map.n_cap * (int64_t)in.ld * 4 < (1ll << 31);
       const char *kname = "sparse_conv_os";
       DGR_CHECK(dgr_conv_os_launch(o, stream, &kname));
@@ -522,20 +530,24 @@ int dgr_resunet_forward_impl(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, 
     return DGR_ENOMEM;
 
   const Tensor X{const_cast<float *>(feats), net->cin, 0};
-  const Tensor T1{t1, 32, 0}, Y1{y1, 32, 1}, S1{cat1 + 64, 96, 1};
-  const Tensor T2{t2, 64, 0}, Y2{y2, 64, 1};
+  Tensor T1{t1, 32, 0}, Y1{y1, 32, 1}, S1{cat1 + 64, 96, 1};
+  Tensor T2{t2, 64, 0}, Y2{y2, 64, 1};
   Tensor S2{cat2 + 64, 128, 1};
   Tensor T4{t4, 128, 0}, Y4{y4, 128, 1}, S4{cat4 + 128, 256, 1};
   Tensor T8{t8, 256, 0}, Y8{y8, 256, 1}, S8{s8, 256, 1};
   Tensor U4{u4, 128, 0}, V4{v4, 128, 1};
-  const Tensor S4T{cat4, 256, 1};
+  Tensor U2{u2, 64, 0}, V2{v2, 64, 1};
+  Tensor U1{u1, 64, 0}, V1{v1, 64, 1};
+  Tensor S4T{cat4, 256, 1};
   // tensors that a wide layer (conv_wide.hip) gathers are also written as split rows by their producer
   {
     // (middle: the tensor between the two convs of a residual block -- its only reader is the block's second conv)
     struct { Tensor *t; int consumer, channels; int64_t rows; bool middle; } sp[] = {
+        {&T2, 4, 64, n2, false}, {&Y2, 5, 64, n2, true},
         {&S2, 6, 64, n2, false}, {&T4, 7, 128, n4, false}, {&Y4, 8, 128, n4, true}, {&S4, 9, 128, n4, false},
         {&T8, 10, 256, n8, false}, {&Y8, 11, 256, n8, true}, {&S8, 12, 256, n8, false}, {&U4, 13, 128, n4, false},
-        {&V4, 14, 128, n4, true}};
+        {&V4, 14, 128, n4, true}, {&U2, 16, 64, n2, false}, {&V2, 17, 64, n2, true}, {&U1, 19, 64, n1, false},
+        {&V1, 20, 64, n1, true}};
     for (auto &e : sp) {
       if (!net->layers[e.consumer].wb) continue;
       e.t->split.channels = e.channels;
@@ -544,9 +556,25 @@ int dgr_resunet_forward_impl(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, 
       DGR_ALLOC(e.t->split.scale, A, float, e.rows);
     }
   }
-  const Tensor U2{u2, 64, 0}, V2{v2, 64, 1}, S2T{cat2, 128, 1};
-  const Tensor U1{u1, 64, 0}, V1{v1, 64, 1}, S1T{cat1, 96, 1};
+  Tensor S2T{cat2, 128, 1};
+  const Tensor S1T{cat1, 96, 1};
   const Tensor H{h, 64, 1}, FIN{fin, net->cout, 0};
+  Tensor CAT4{cat4, 256, 1}, CAT2{cat2, 128, 1};
+  if (use_nbr) {
+    // row maxima of every tensor a split-operand 3-D conv reads, from ONE cleared allocation: the producers' epilogues
+    // fill them (round 3 ran a row-scale pass per consuming layer: 20 launches per forward)
+    const int64_t words = 5 * n1 + 6 * n2 + 6 * n4 + 3 * n8;
+    uint32_t *pool;
+    DGR_ALLOC(pool, A, uint32_t, words);
+    DGR_HIP_CHECK(hipMemsetAsync(pool, 0, (size_t)words * sizeof(uint32_t), stream));
+    auto take = [&](int64_t n) { uint32_t *p = pool; pool += n; return p; };
+    for (Tensor *t : {&T1, &Y1, &S1, &U1, &V1}) t->amax = take(n1);
+    for (Tensor *t : {&T2, &Y2, &S2, &CAT2, &U2, &V2}) t->amax = take(n2);
+    for (Tensor *t : {&T4, &Y4, &S4, &CAT4, &U4, &V4}) t->amax = take(n4);
+    for (Tensor *t : {&T8, &Y8, &S8}) t->amax = take(n8);
+    S2.amax2 = CAT2.amax; S2T.amax2 = CAT2.amax;   // both halves of a concatenation feed its row maxima
+    S4.amax2 = CAT4.amax; S4T.amax2 = CAT4.amax;
+  }
 
   int li = 0;
   // encoder
@@ -561,7 +589,7 @@ int dgr_resunet_forward_impl(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, 
     }
     const char *k1name = "conv1_grid_kernel";
     DGR_CHECK(dgr_conv1_probe(A, ms.cm[0], net->conv1_ks, feats, net->cin, net->cin, L0.w, L0.shift, t1, 32, pc, stream,
-                              L0.wc, &k1name));
+                              L0.wc, &k1name, T1.amax));
     if (f.prof) {
       DGR_HIP_CHECK(hipEventRecord(e1, stream));
       ctx->conv_spans.push_back({e0, e1});
@@ -592,11 +620,9 @@ int dgr_resunet_forward_impl(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, 
   DGR_CHECK(f.conv(li++, S8, &ms.down[2], true, 3, 2, U4, nullptr));   // conv4_tr + norm4_tr
   DGR_CHECK(f.conv(li++, U4, &ms.same[2], false, 2, 2, V4, nullptr));  // block4_tr
   DGR_CHECK(f.conv(li++, V4, &ms.same[2], false, 2, 2, S4T, &U4));     // -> cat4[:, :128]
-  const Tensor CAT4{cat4, 256, 1};
   DGR_CHECK(f.conv(li++, CAT4, &ms.down[1], true, 2, 1, U2, nullptr));  // conv3_tr
   DGR_CHECK(f.conv(li++, U2, &ms.same[1], false, 1, 1, V2, nullptr));   // block3_tr
   DGR_CHECK(f.conv(li++, V2, &ms.same[1], false, 1, 1, S2T, &U2));
-  const Tensor CAT2{cat2, 128, 1};
   DGR_CHECK(f.conv(li++, CAT2, &ms.down[0], true, 1, 0, U1, nullptr));  // conv2_tr
   DGR_CHECK(f.conv(li++, U1, &ms.same[0], false, 0, 0, V1, nullptr));   // block2_tr
   DGR_CHECK(f.conv(li++, V1, &ms.same[0], false, 0, 0, S1T, &U1));

@@ -82,7 +82,7 @@ def compare(tag, dumps, prefix, truth):
 
 def test_modes_ran_their_own_kernels(dumps):
     ks, kf = dumps['split']['kinds'].tolist(), dumps['f32']['kinds'].tolist()
-    assert any(k.startswith('sparse_conv_wide_f16x2<256, 2>') for k in ks) and not any('f16x2' in k for k in kf)
+    assert any(k.startswith('sparse_conv_wide_f16x2<256, 2, 1>') for k in ks) and not any('f16x2' in k for k in kf)
 
 
 def test_full_size_pair_against_f64(dumps):
@@ -140,7 +140,7 @@ def test_single_layers_on_adversarial_rows(dumps, which):
             tiny = rb <= 1e-30
             if tiny.any():
                 assert np.abs(y - truth)[tiny].max() <= 1e-36, mode   # denormal neighbourhoods: absolutely negligible
-        kern = 'sparse_conv_wide_f16x2<256, 2>' if which == '6' else 'sparse_conv_dense_f16x2<64, 64>'
+        kern = 'sparse_conv_wide_f16x2<256, 2, 1>' if which == '6' else 'sparse_conv_dense_f16x2<64, 64>'
         report(f'{kern:34s} relu={relu} max over rows of max|y - f64| / max sum|x||w|:  split {res["split"]:.2e}   '
                f'exact-f32 {res["f32"]:.2e}   ratio {res["split"] / max(res["f32"], 1e-300):.2f}')
         assert res['split'] <= max(1.5 * res['f32'], 2e-7), (which, relu, res)

@@ -4,9 +4,6 @@
 // 6-D block4 layers of the benchmark (75 k rows, 729 offsets, 3.57 M pairs).
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I../../include -DCHK_CIN=256 -DCHK_COUT=256 -o wide_check wide_check.hip
 //   ./wide_check [pairs_for_timing (0 = skip)] [reps]
-#ifdef DGR_WIDE_TIMING
-static unsigned long long *g_dbg = nullptr;
-#endif
 #include "../../deepglobalregistration_amd/csrc/conv_wide.hip"
 #include <string.h>
 #include <algorithm>
@@ -40,9 +37,6 @@ int main(int argc, char **argv) {
   const int cin = CHK_CIN, cout = CHK_COUT;
   const long timing_pairs = argc > 1 ? atol(argv[1]) : 3570000;
   const int reps = argc > 2 ? atoi(argv[2]) : 5;
-#ifdef DGR_WIDE_TIMING
-  CK(hipMalloc(&g_dbg, (size_t)NUMCUS * 8 * 4 * 8));
-#endif
   // ------------------------------------------------------------------ (1) accuracy
   {
     const int K = 6, N = 1000;
@@ -165,9 +159,6 @@ int main(int argc, char **argv) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const char *name = "";
     float best = 1e30f, sum = 0.f;
-#ifdef DGR_WIDE_TIMING
-    CK(hipMemset(g_dbg, 0, (size_t)NUMCUS * 8 * 4 * 8));
-#endif
     for (int i = 0; i < reps + 1; ++i) {
       CK(hipEventRecord(e0, nullptr));
       if (dgr_conv_wide_launch(a, sr, dwb, piece, 1.f, NUMCUS, nullptr, &name) != DGR_OK) { printf("launch failed\n"); return 1; }
@@ -175,25 +166,6 @@ int main(int argc, char **argv) {
       float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
       if (i > 0) { best = fminf(best, ms); sum += ms; }
     }
-#ifdef DGR_WIDE_TIMING
-    {
-      std::vector<unsigned long long> d((size_t)NUMCUS * 8 * 4);
-      CK(hipMemcpy(d.data(), g_dbg, d.size() * 8, hipMemcpyDeviceToHost));
-      const char *role[3] = {"compute  [k-steps | stage write | barrier]", "requester[dma issue | vmcnt wait | barrier]", "storer   [stores | - | barrier]"};
-      for (int r = 0; r < 3; ++r) {
-        double s[3] = {0, 0, 0}; int n = 0;
-        for (int b = 0; b < NUMCUS; ++b)
-          for (int w = 0; w < 8; ++w) {
-            const int rr = w < 4 ? 0 : (w < 6 ? 1 : 2);
-            if (rr != r) continue;
-            for (int i = 0; i < 3; ++i) s[i] += (double)d[((size_t)b * 8 + w) * 4 + i];
-            ++n;
-          }
-        const double ph = (double)m.desc.size() * (cin / 64) / NUMCUS;   // phases per block
-        printf("CYCLES per phase, %s: %.0f | %.0f | %.0f  (s_memtime ticks; %.0f phases per block)\n", role[r], s[0] / n / ph, s[1] / n / ph, s[2] / n / ph, ph);
-      }
-    }
-#endif
     const double flop = 2.0 * P * cin * cout;
     printf("TIMING %s P=%zu tiles=%zu: mean %.3f ms, best %.3f ms = %.1f TFLOP/s algorithmic (x3 issued: %.3f of 2500)\n", name, P, m.desc.size(),
            sum / reps, best, flop / (sum / reps * 1e-3) / 1e12, 3 * flop / (sum / reps * 1e-3) / 1e12 / 2500.0);
