@@ -670,39 +670,85 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
       for (int u = 0; u < 8; ++u) acc += y[u];
     }
-    // the remaining 1 .. 7 pairs (most rows of a 6-D stride-1 map have one to three pairs in all): four at a time, the
-    // index chains of the four issued together (clamped to the row's last pair), the additions predicated and in order
-    // -- one pair at a time, a row paid four dependent memory latencies per pair
-    for (; j < end; j += 4) {
-      int pos[4], row[4], kk[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) pos[u] = out_pos[min(j + u, end - 1)];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { row[u] = pair_in[pos[u]]; kk[u] = pair_k[pos[u]]; }
-      float y[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float *wk = w + (int64_t)kk[u] * 256;
-        float t = 0.f;
-        for (int ci = 0; ci < cin; ++ci) {
-          float x = in[(int64_t)row[u] * in_ld + ci];
-          if (in_relu) x = fmaxf(x, 0.f);
-          t = fmaf(x, wk[(32 * (ci >> 2) + co) * 4 + (ci & 3)], t);   // same k-ordered fma chain as the MFMA
-        }
-        y[u] = t;
+    for (; j < end; ++j) {
+      const int pos = out_pos[j];
+      const int row = pair_in[pos];
+      const float *wk = w + (int64_t)pair_k[pos] * 256;
+      float y = 0.f;
+      for (int ci = 0; ci < cin; ++ci) {
+        float x = in[(int64_t)row * in_ld + ci];
+        if (in_relu) x = fmaxf(x, 0.f);
+        y = fmaf(x, wk[(32 * (ci >> 2) + co) * 4 + (ci & 3)], y);   // same k-ordered fma chain as the MFMA
       }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (j + u < end) acc += y[u];
+      acc += y;
     }
     out[o * out_ld + co] = acc;
   }
+}
+
+// The same layer with ONE THREAD per output voxel (all 32 output channels in its registers).  The 6-D inlier net's conv1
+// has 1.8 pairs per row (the centre offset and, for half the rows, one or two neighbours): with 32 lanes per voxel the
+// kernel is 55 k waves that each walk a chain of four dependent loads per pair (row pointer -> slot -> pair -> input
+// row / weights), 81 us for 110 k rows; with a thread per voxel it is 1.7 k waves, all resident at once, and the chains
+// of 64 voxels run side by side.  Same fma chain per pair, pairs added in ascending-k order: bit-identical results.
+template <int CIN>
+__global__ void __launch_bounds__(256)
+    conv_small_cin_row_kernel(const float *__restrict__ in, int in_ld, int in_relu, const float *__restrict__ w,
+                              const float *__restrict__ shift, const int32_t *__restrict__ out_ptr,
+                              const int32_t *__restrict__ out_pos, const int32_t *__restrict__ pair_in,
+                              const uint16_t *__restrict__ pair_k, const int32_t *n_out_dev, float *__restrict__ out,
+                              int out_ld) {
+  const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= *n_out_dev) return;
+  float acc[32];
+#pragma unroll
+  for (int co = 0; co < 32; ++co) acc[co] = shift ? shift[co] : 0.f;
+  const int end = out_ptr[o + 1];
+  for (int j = out_ptr[o]; j < end; ++j) {
+    const int pos = out_pos[j];
+    const int row = pair_in[pos];
+    const f32x4 *wk = reinterpret_cast<const f32x4 *>(w + (int64_t)pair_k[pos] * 256);
+    float x[CIN];
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci) {
+      x[ci] = in[(int64_t)row * in_ld + ci];
+      if (in_relu) x[ci] = fmaxf(x[ci], 0.f);
+    }
+#pragma unroll
+    for (int co = 0; co < 32; ++co) {
+      // W[k][ci][co] sits at ((k * 64 + 32 * (ci / 4) + co) * 4 + ci % 4): two 16-byte loads per output channel
+      const f32x4 w0 = wk[co];
+      float t = 0.f;
+#pragma unroll
+      for (int ci = 0; ci < (CIN < 4 ? CIN : 4); ++ci) t = fmaf(x[ci], w0[ci], t);
+      if constexpr (CIN > 4) {
+        const f32x4 w1 = wk[32 + co];
+#pragma unroll
+        for (int ci = 4; ci < CIN; ++ci) t = fmaf(x[ci], w1[ci - 4], t);
+      }
+      acc[co] += t;
+    }
+  }
+  f32x4 *dst = reinterpret_cast<f32x4 *>(out + o * out_ld);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) dst[q] = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
 }
 
 int dgr_conv_small_cin(const float *in, int in_ld, int in_relu, int cin, const float *w_tiled, const float *shift,
                        const DgrKernelMap &km, const int32_t *n_out_dev, int64_t n_out_cap, float *out, int out_ld,
                        hipStream_t stream) {
   DGR_REQUIRE(cin >= 1 && cin <= 8, "small-Cin conv: cin=%d", cin);
+  if ((out_ld & 3) == 0 && (cin == 6 || cin == 1)) {   // the inlier net's input widths ('coords' / 'ones' features)
+    const int rb = (int)dgr_ceil_div(n_out_cap, 256);
+    if (cin == 6)
+      conv_small_cin_row_kernel<6><<<rb, 256, 0, stream>>>(in, in_ld, in_relu, w_tiled, shift, km.out_ptr, km.out_pos, km.pair_in,
+                                                         km.pair_k, n_out_dev, out, out_ld);
+    else
+      conv_small_cin_row_kernel<1><<<rb, 256, 0, stream>>>(in, in_ld, in_relu, w_tiled, shift, km.out_ptr, km.out_pos, km.pair_in,
+                                                         km.pair_k, n_out_dev, out, out_ld);
+    DGR_LAUNCH_CHECK();
+    return DGR_OK;
+  }
   int64_t blocks = dgr_ceil_div(n_out_cap, 8);
   if (blocks > 16384) blocks = 16384;
   conv_small_cin_kernel<<<(int)blocks, 256, 0, stream>>>(in, in_ld, in_relu, cin, w_tiled, shift, km.out_ptr,

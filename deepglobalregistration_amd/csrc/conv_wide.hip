@@ -107,10 +107,10 @@ __global__ void __launch_bounds__(512, 1) sparse_conv_wide_f16x2(ConvWideArgs a,
   constexpr int RING = 16;               // tiles in the index / scale rings
   constexpr int AH_I = 8, AH_S = 4;      // tile t + AH_I's indices and tile t + AH_S's scales are requested at tile t
   static_assert(RING >= 2 * AH_I && AH_I > LEAD && AH_S >= 3 && AH_S < AH_I, "ring distances");
-  // weight ring: k-step g + WD - 1 is requested at step g.  Two steps for the 12-MFMA k-steps of the C_out >= 128 shapes
-  // (four: same speed in tools/microbench/wide_check, five spilled registers at C_out = 256); the C_out = 64 shape has
-  // three MFMAs per k-step, so a whole tile of weights (four steps) stays in flight
-  constexpr int WD = MB * NB >= 2 ? 2 : 4;
+  // weight ring: k-step g + WD - 1 is requested at step g.  Two steps for the 12-MFMA k-steps of the C_out = 256 shapes
+  // (four: same speed in tools/microbench/wide_check, five spilled registers); the C_out <= 128 shapes have six or three
+  // MFMAs per k-step -- 200 / 100 cycles, a fraction of an L2 round trip -- so four steps of weights stay in flight
+  constexpr int WD = NB >= 2 ? 2 : 4;
   static_assert(SK % WD == 0, "the weight ring turns a whole number of times per phase (static register indexing)");
   constexpr int LDS_ST = COUT + 4;       // stage row stride (floats)
   constexpr int NSTG = PPT == 1 ? 2 : 1; // one-phase tiles: a tile is staged while the previous one is still going out

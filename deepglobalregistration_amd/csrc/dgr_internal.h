@@ -79,8 +79,7 @@ struct DgrArena {
 // ------------------------------------------------------------------------------------------
 // coordinate maps / kernel maps (coordmap.hip, kmap.hip)
 // ------------------------------------------------------------------------------------------
-constexpr int DGR_TILE_M = 64;    // pairs per MFMA tile of the sparse conv
-constexpr int DGR_TILE_M2 = 128;  // ... of the widest 6-D layers (conv_wide.hip: one weight fragment serves 128 pairs)
+constexpr int DGR_TILE_M = 64;  // pairs per MFMA tile of the sparse conv
 
 struct DgrCoordMap {
   int32_t *coords = nullptr;  // [n_cap, nc] row-major, nc = 1 + D
@@ -107,8 +106,6 @@ struct DgrKernelMap {
   int32_t *rule_ptr = nullptr;  // [K+1] exclusive prefix of pairs per offset
   int32_t *tile_ptr = nullptr;  // [K+1] exclusive prefix of DGR_TILE_M-tiles per offset
   int4 *tile_desc = nullptr;    // [tile_cap] (k, first pair, pair count, 0) of every tile
-  int32_t *tile_ptr2 = nullptr; // the same tiling in DGR_TILE_M2-pair tiles
-  int4 *tile_desc2 = nullptr;
   int64_t tile_cap = 0;
   int32_t *pair_in = nullptr;   // [pair_cap]
   int32_t *pair_out = nullptr;  // [pair_cap]

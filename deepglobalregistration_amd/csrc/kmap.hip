@@ -107,13 +107,15 @@ __device__ __forceinline__ int mask_rank_pre(const uint32_t *__restrict__ m, con
 //            also used swapped).  Same-stride maps are symmetric -- (o, k) -> i  <=>  (i, K-1-k) -> o
 //            -- so only offsets below the centre are searched and every hit sets both bits.
 //            Every hit is also APPENDED as a record (offset, row, input row) to a hit list -- in no particular
-//            order: one wave-aggregated atomic per call and wave (round 3; the records replace the re-probe of every
-//            set bit in the placing pass, which cost 0.64 of the 2.44 ms of a batch's seven maps).
+//            order, into the searching wave's own region (HitList below: no global counter); the records replace a
+//            re-probe of every set bit in the placing pass.
 //   colmask  transposes the bit matrix per 64-row group (one ballot per offset), counts the pairs of every
 //            (offset, 256-row block) cell -> exclusive scan = cell bases -- and of every row (CSR row pointers).
 //   place    one thread per hit record: ranks the pair inside its row (CSR slot) and inside its cell (rule-major
 //            position) with popcounts.  The positions depend on the bit matrix only, not on the order of the list.
 // Result identical to the generic path: pairs sorted by (k, out), CSR slots in ascending k.
+// All seven maps of a sparse tensor go through these phases TOGETHER (build_kernel_maps6): one clear, one multi-array
+// scan, one finalisation and one tile-descriptor launch for all of them.
 
 // hit record: offset k (10 bits) | output row (27 bits) | input row (27 bits)
 __device__ __forceinline__ unsigned long long hit_pack(int k, int64_t o, int64_t in) {
@@ -236,7 +238,6 @@ struct PrunedArgs {
   int64_t n_cap;           // row capacity of the output map (thread t = ja * n_cap + position in out_order)
   DgrHalfBuckets hb;       // first-half buckets of the INPUT map
   int ts_in, symmetric;
-  int row_major;           // EXPERIMENT (DGR_KMAP_ROWMAJOR): t = p * NJ + ja
 };
 // Thread t = (first-half offset ja, position p in the output map's bucket order): the 64 lanes of a wave are 64
 // consecutive rows of (mostly) ONE first-half bucket under the SAME first-half offset, so they scan the same neighbour
@@ -246,17 +247,13 @@ template <class Emit>
 __device__ __forceinline__ void pruned_search6(const PrunedArgs &a, int64_t t, Emit &&emit) {
   const int NJ = a.symmetric ? 14 : 27;
   const int ts_in = a.ts_in;
-  const int ja = a.row_major == 1 ? (int)(t % NJ) : (int)(t / a.n_cap);
-  const int64_t p = a.row_major == 1 ? t / NJ : t - (int64_t)ja * a.n_cap;
+  const int ja = (int)(t / a.n_cap);
+  const int64_t p = t - (int64_t)ja * a.n_cap;
   int b = -1;
   int64_t o = 0;
   int c4 = 0, c5 = 0, c6 = 0;
   if (ja < NJ && p < *a.n_out_dev) {
-    int4 me = a.out_order[p];
-    if (a.row_major == 2) {   // EXPERIMENT: rows in row order
-      const int32_t *cc = a.out_coords + p * 7;
-      me = make_int4(cc[4], cc[5], cc[6], (int)p);
-    }
+    const int4 me = a.out_order[p];
     o = me.w; c4 = me.x; c5 = me.y; c6 = me.z;
     const int32_t *co = a.out_coords + o * 7;
     int32_t q[4];
@@ -463,15 +460,15 @@ __global__ void __launch_bounds__(KM_THREADS)
 constexpr int KM_MAXJOBS = 8;
 struct FinalizeJobs {
   const int32_t *base[KM_MAXJOBS], *total[KM_MAXJOBS];
-  int32_t *rule_ptr[KM_MAXJOBS], *tile_ptr[KM_MAXJOBS], *tile_ptr2[KM_MAXJOBS];
-  int4 *desc[KM_MAXJOBS], *desc2[KM_MAXJOBS];
+  int32_t *rule_ptr[KM_MAXJOBS], *tile_ptr[KM_MAXJOBS];
+  int4 *desc[KM_MAXJOBS];
   long long tile_cap[KM_MAXJOBS];
   int K[KM_MAXJOBS], RB[KM_MAXJOBS];
 };
-// rule_ptr[k] = block_base[k * RB], rule_ptr[K] = total; tile_ptr / tile_ptr2 = exclusive scans of
-// ceil(P_k / DGR_TILE_M) and ceil(P_k / DGR_TILE_M2).  One block per map, K <= 1024.
+// rule_ptr[k] = block_base[k * RB], rule_ptr[K] = total; tile_ptr = exclusive scan of ceil(P_k / DGR_TILE_M).
+// One block per map, K <= 1024.
 __global__ void __launch_bounds__(1024) kmap_finalize(FinalizeJobs j) {
-  __shared__ int s[1024], s2[1024];
+  __shared__ int s[1024];
   const int m = blockIdx.x, K = j.K[m], RB = j.RB[m];
   const int32_t *block_base = j.base[m];
   const int k = threadIdx.x;
@@ -482,17 +479,17 @@ __global__ void __launch_bounds__(1024) kmap_finalize(FinalizeJobs j) {
     j.rule_ptr[m][k] = start;
     if (k == K - 1) j.rule_ptr[m][K] = end;
   }
-  const int tiles = (end - start + DGR_TILE_M - 1) / DGR_TILE_M, tiles2 = (end - start + DGR_TILE_M2 - 1) / DGR_TILE_M2;
-  s[k] = tiles; s2[k] = tiles2;
+  const int tiles = (end - start + DGR_TILE_M - 1) / DGR_TILE_M;
+  s[k] = tiles;
   __syncthreads();
   for (int d = 1; d < 1024; d <<= 1) {
-    const int v = (k >= d) ? s[k - d] : 0, v2 = (k >= d) ? s2[k - d] : 0;
+    const int v = (k >= d) ? s[k - d] : 0;
     __syncthreads();
-    s[k] += v; s2[k] += v2;
+    s[k] += v;
     __syncthreads();
   }
-  if (k < K) { j.tile_ptr[m][k] = s[k] - tiles; j.tile_ptr2[m][k] = s2[k] - tiles2; }
-  if (k == K - 1) { j.tile_ptr[m][K] = s[k]; j.tile_ptr2[m][K] = s2[k]; }
+  if (k < K) j.tile_ptr[m][k] = s[k] - tiles;
+  if (k == K - 1) j.tile_ptr[m][K] = s[k];
 }
 
 // one thread per tile: (k, first pair, pair count) so that the conv kernels fetch a tile with ONE
@@ -512,7 +509,6 @@ __global__ void tile_desc_kernel(FinalizeJobs j) {
   const int m = blockIdx.y;
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   tile_desc_one(j.tile_ptr[m], j.rule_ptr[m], j.K[m], j.desc[m], j.tile_cap[m], t, DGR_TILE_M);
-  tile_desc_one(j.tile_ptr2[m], j.rule_ptr[m], j.K[m], j.desc2[m], j.tile_cap[m], t, DGR_TILE_M2);
 }
 
 // the parts of a kernel map that outlive the build
@@ -525,13 +521,11 @@ static int alloc_kernel_map(DgrArena &arena, int K, int64_t n_cap, int64_t n_in_
   DGR_REQUIRE(km->pair_cap < (1ll << 31), "kernel map too large (%lld pairs)", (long long)km->pair_cap);
   DGR_ALLOC(km->rule_ptr, arena, int32_t, K + 1);
   DGR_ALLOC(km->tile_ptr, arena, int32_t, K + 1);
-  DGR_ALLOC(km->tile_ptr2, arena, int32_t, K + 1);
   DGR_ALLOC(km->pair_in, arena, int32_t, km->pair_cap);
   km->pair_out = nullptr;
   if (want_pair_out) DGR_ALLOC(km->pair_out, arena, int32_t, km->pair_cap);
   km->tile_cap = km->pair_cap / DGR_TILE_M + K;
   DGR_ALLOC(km->tile_desc, arena, int4, km->tile_cap);
-  DGR_ALLOC(km->tile_desc2, arena, int4, km->tile_cap);
   DGR_ALLOC(km->out_ptr, arena, int32_t, n_cap + 1);
   DGR_ALLOC(km->out_pos, arena, int32_t, km->pair_cap);
   km->pair_k = nullptr;
@@ -545,8 +539,8 @@ static int alloc_kernel_map(DgrArena &arena, int K, int64_t n_cap, int64_t n_in_
 
 static void finalize_job(FinalizeJobs &fj, int m, const int32_t *base, const int32_t *total, int K, int RB, DgrKernelMap *km) {
   fj.base[m] = base; fj.total[m] = total; fj.K[m] = K; fj.RB[m] = RB;
-  fj.rule_ptr[m] = km->rule_ptr; fj.tile_ptr[m] = km->tile_ptr; fj.tile_ptr2[m] = km->tile_ptr2;
-  fj.desc[m] = km->tile_desc; fj.desc2[m] = km->tile_desc2; fj.tile_cap[m] = km->tile_cap;
+  fj.rule_ptr[m] = km->rule_ptr; fj.tile_ptr[m] = km->tile_ptr;
+  fj.desc[m] = km->tile_desc; fj.tile_cap[m] = km->tile_cap;
 }
 
 // D = 3 (rule-major maps of 3-D nets that do not run on neighbour tables; the stand-alone maps object): one map per call
@@ -620,8 +614,6 @@ static int build_kernel_maps6(DgrArena &arena, const Kmap6Job *jobs, int nj, int
   constexpr int K = 729, KW = (K + 31) / 32;
   DGR_REQUIRE(nj >= 1 && nj <= KM_MAXJOBS, "6-D kernel maps: %d jobs", nj);
   static const bool generic8 = getenv("DGR_KMAP_GENERIC8") != nullptr;   // A/B: the stride-8 map by 364 hash probes per row
-  static const int row_major = getenv("DGR_KMAP_ROWMAJOR") ? atoi(getenv("DGR_KMAP_ROWMAJOR")) : 0;    // EXPERIMENT
-  static const int region8 = getenv("DGR_KMAP_REGION8") ? atoi(getenv("DGR_KMAP_REGION8")) : 2 * KM_REGION;   // EXPERIMENT
   struct Tr {   // transients of one job
     int RB, symmetric;
     bool pruned;
@@ -676,7 +668,7 @@ static int build_kernel_maps6(DgrArena &arena, const Kmap6Job *jobs, int nj, int
     r.hit_waves = search_blocks * (KM_THREADS / 64);
     // (a wave = 64 rows under one first-half offset: a dozen records at the fine levels and in the strided maps, ~180 in
     // the stride-8 map with its 39 neighbours per row, several times that in its dense corners)
-    r.hl.region = r.pruned ? ((J.in->ts >= 8 && r.symmetric) ? region8 : KM_REGION / 2)
+    r.hl.region = r.pruned ? ((J.in->ts >= 8 && r.symmetric) ? 2 * KM_REGION : KM_REGION / 2)
                            : 64 * (KM_PROBES * (r.symmetric ? 2 : 1) + 1);
     DGR_REQUIRE(r.hit_waves < (1ll << 31), "6-D kernel map: too many search waves");
     DGR_ALLOC(r.hl.recs, arena, unsigned long long, r.hit_waves * r.hl.region);
@@ -690,7 +682,7 @@ static int build_kernel_maps6(DgrArena &arena, const Kmap6Job *jobs, int nj, int
     const Kmap6Job &J = jobs[m];
     Tr &r = t[m];
     if (r.pruned) {
-      const PrunedArgs pa{J.out->coords, J.out->n_dev, J.hb_out->second, r.n_cap, *J.hb, J.in->ts, r.symmetric, row_major};
+      const PrunedArgs pa{J.out->coords, J.out->n_dev, J.hb_out->second, r.n_cap, *J.hb, J.in->ts, r.symmetric};
       kmap_bits_pruned6<<<(int)(r.hit_waves / (KM_THREADS / 64)), KM_THREADS, 0, stream>>>(pa, KW, r.mask_out, r.mask_in, r.hl);
     } else {
       const int n_probe = r.symmetric ? K / 2 : K;
@@ -732,7 +724,7 @@ static int build_kernel_maps6(DgrArena &arena, const Kmap6Job *jobs, int nj, int
     DgrKernelMap *km = J.km;
     const PlaceArgs pl{K, KW, r.RB, r.mask_out, km->out_ptr, r.cell, r.base, km->pair_in, km->pair_out, km->pair_k, km->out_pos,
                        km->pair_cap, overflow, r.mask_in, km->in_ptr, km->in_pos, r.wpre_out, r.wpre_in};
-    PrunedArgs pa{J.out->coords, J.out->n_dev, nullptr, r.n_cap, DgrHalfBuckets(), J.in->ts, r.symmetric, row_major};
+    PrunedArgs pa{J.out->coords, J.out->n_dev, nullptr, r.n_cap, DgrHalfBuckets(), J.in->ts, r.symmetric};
     if (r.pruned) { pa.hb = *J.hb; pa.out_order = J.hb_out->second; }
     const int blocks = (int)std::min<int64_t>(dgr_ceil_div(r.hit_waves, KM_THREADS / 64), 16384);
     kmap_place_hits<<<blocks, KM_THREADS, 0, stream>>>(r.hl, (int)r.hit_waves, pl, pa);

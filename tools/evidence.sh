@@ -6,10 +6,15 @@
 R=$PWD; O=$R/gpurun_out/final; mkdir -p $O; rm -rf $O/*
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py"
-timeout 900 $B --steps 20 --warmup 3 > $O/bench_c1_default.json 2> $O/bench_c1_default.err
+# the driver's command: no flags (5 warm-up + 100 timed steps, two input sets taken in turn, parity + CPU baseline)
+timeout 900 $B > $O/bench_c1_default.json 2> $O/bench_c1_default.err
 timeout 300 $B --streams 1 --pairs-per-step 4 --no-parity > $O/bench_c1_s1_b4.json 2> $O/bench_c1_s1_b4.err
 timeout 300 $B --streams 1 --pairs-per-step 1 --no-parity > $O/bench_c1_s1_b1.json 2> $O/bench_c1_s1_b1.err
+# BASELINE configs[2] (KITTI-shaped, 13 k voxels per scan): batches of 4, 8 and 16 pairs per stream -- the small clouds
+# leave the persistent grids of the wide kernels under-filled at 4
 timeout 600 $B --kind outdoor --n-raw 120000 --voxel 0.3 --conv1-ks 5 > $O/bench_c3.json 2> $O/bench_c3.err
+timeout 600 $B --kind outdoor --n-raw 120000 --voxel 0.3 --conv1-ks 5 --pairs-per-step 8 --no-parity > $O/bench_c3_b8.json 2> $O/bench_c3_b8.err
+timeout 600 $B --kind outdoor --n-raw 120000 --voxel 0.3 --conv1-ks 5 --pairs-per-step 16 --no-parity > $O/bench_c3_b16.json 2> $O/bench_c3_b16.err
 timeout 600 $B --n-raw 200000 --voxel 0.025 --pairs-per-step 1 --no-parity > $O/bench_c5.json 2> $O/bench_c5.err
 timeout 600 $B --n-raw 200000 --voxel 0.025 --pairs-per-step 1 --no-parity --no-refine > $O/bench_c5_norefine.json 2> $O/bench_c5_norefine.err
 if [ "$1" != quick ]; then
@@ -43,6 +48,7 @@ python $R/tools/pmc_dominant.py "$K" "BASELINE configs[1]" $DBS > $O/dominant_pm
 python $R/tools/pmc_dominant.py "sparse_conv_os<64, 64" "BASELINE configs[1]" $DBS > $O/os_conv_pmc.json
 python $R/tools/pmc_dominant.py "sparse_conv_dense_f16x2<64, 64" "BASELINE configs[1]" $DBS > $O/dense_conv_pmc.json
 python $R/tools/pmc_dominant.py "reduce_rows_kernel<64" "BASELINE configs[1]" $DBS > $O/reduce_rows_pmc.json
-python $R/tools/pmc_dominant.py "sparse_conv_os<32, 32" "BASELINE configs[1]" $DBS > $O/os_conv32_pmc.json
+python $R/tools/pmc_dominant.py "sparse_conv_wide_f16x2<64, 1, 2>" "BASELINE configs[1]" $DBS > $O/wide64_pmc.json
+python $R/tools/pmc_dominant.py "conv1_grid_mfma" "BASELINE configs[1]" $DBS > $O/conv1_pmc.json
 rm -rf $O/kt1 $O/kt3 $O/pmc
 ls -la $O; tail -c 400 $O/bench_c1_default.json

@@ -1,7 +1,9 @@
 // Stand-alone harness around the wide-layer kernel (conv_wide.hip): (1) its product rows against an f64 host reference
 // on a small rule-major map with adversarial rows (magnitudes over 12 decades, one dominant channel, zero and denormal
 // rows, partial tiles, an empty rule), input split by dgr_split_rows; (2) timing on a synthetic map of the size of the
-// 6-D block4 layers of the benchmark (75 k rows, 729 offsets, 3.57 M pairs).
+// 6-D block4 layers of the benchmark (75 k rows, 729 offsets, 3.57 M pairs) -- twice: with the input rows of a tile in
+// ascending order inside a ~1000-row window (what a spatially sorted coordinate map would give) and with the row
+// numbering shuffled (what the first-occurrence order of the real maps gives).
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I../../include -DCHK_CIN=256 -DCHK_COUT=256 -o wide_check wide_check.hip
 //   ./wide_check [pairs_for_timing (0 = skip)] [reps]
 #include "../../deepglobalregistration_amd/csrc/conv_wide.hip"
@@ -121,7 +123,7 @@ int main(int argc, char **argv) {
   }
   if (timing_pairs <= 0) return 0;
   // ------------------------------------------------------------------ (2) timing
-  {
+  for (int shuffled = 0; shuffled < 2; ++shuffled) {
     const int K = 729, N = 75000;
     std::mt19937 rng(1);
     std::vector<std::vector<int32_t>> rules(K);
@@ -131,6 +133,12 @@ int main(int argc, char **argv) {
       const double keep = (double)per / N;
       std::uniform_real_distribution<double> U(0, 1);
       for (int i = 0; i < N; ++i) if (U(rng) < keep) r.push_back(i);
+    }
+    if (shuffled) {   // the same map under a random renumbering of the input rows
+      std::vector<int32_t> perm(N);
+      for (int i = 0; i < N; ++i) perm[i] = i;
+      std::shuffle(perm.begin(), perm.end(), rng);
+      for (auto &r : rules) for (auto &v : r) v = perm[v];
     }
     Map m = make_map(rules);
     const size_t P = m.pair_in.size();
@@ -167,8 +175,9 @@ int main(int argc, char **argv) {
       if (i > 0) { best = fminf(best, ms); sum += ms; }
     }
     const double flop = 2.0 * P * cin * cout;
-    printf("TIMING %s P=%zu tiles=%zu: mean %.3f ms, best %.3f ms = %.1f TFLOP/s algorithmic (x3 issued: %.3f of 2500)\n", name, P, m.desc.size(),
+    printf("TIMING (%s input rows) %s P=%zu tiles=%zu: mean %.3f ms, best %.3f ms = %.1f TFLOP/s algorithmic (x3 issued: %.3f of 2500)\n", shuffled ? "shuffled" : "window-sorted", name, P, m.desc.size(),
            sum / reps, best, flop / (sum / reps * 1e-3) / 1e12, 3 * flop / (sum / reps * 1e-3) / 1e12 / 2500.0);
+    hipFree(dy); hipFree(dys); hipFree(dwb); hipFree(dpi); hipFree(dtp); hipFree(dd); hipFree(drs); hipFree(dn); hipFree(dpl); hipFree(din);
   }
   return 0;
 }
