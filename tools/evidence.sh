@@ -28,7 +28,7 @@ timeout 600 $B --full-register --no-parity > $O/bench_c1_full_register.json 2> $
 timeout 600 $B --force-safeguard --no-parity --steps 3 --warmup 1 > $O/bench_c1_force_safeguard.json 2> $O/bench_c1_force_safeguard.err
 # the whole GPU suite with the parity tables (split operands vs f64; refinement vs the oracle, iteration-matched and free-running)
 if [ "$1" != quick ]; then   # PYTEST_ARGS: a subset (default: the whole suite)
-  (cd $R && DGR_PARITY_REPORT=$O/parity timeout 1200 python -m pytest ${PYTEST_ARGS:-tests} -m gpu -q 2>&1 | tail -15 > $O/pytest_gpu.log)
+  (cd $R && DGR_PARITY_REPORT=$O/parity timeout 1800 python -m pytest ${PYTEST_ARGS:-tests} -m gpu -q 2>&1 | tail -15 > $O/pytest_gpu.log)
 fi
 # kernel stats: the single-stream command gives durations free of time-slicing (comparable with roofline.avg_launch_us)
 timeout 300 rocprofv3 --kernel-trace -d $O/kt1 -o kt -- $B --streams 1 --pairs-per-step 4 --no-parity --steps 5 > $O/kt1.log 2>&1
