@@ -144,7 +144,7 @@ def oracle_parity_and_baseline(ck, args, pair0, do_baseline):
     p0, c0, p1, c1 = pair0['xyz0'], pair0['coords0'], pair0['xyz1'], pair0['coords1']
     n0, n1 = len(p0), len(p1)
     t = {}
-    runs = {'fcgf': [], 'inlier_net': []}
+    net_runs = {'fcgf': [], 'inlier_net': []}
     n_runs = 3 if do_baseline else 1
     c6 = f6 = None
     if do_baseline:
@@ -157,13 +157,13 @@ def oracle_parity_and_baseline(ck, args, pair0, do_baseline):
         t0 = time.time()
         oF0 = oresunet.resunet_forward(ck['state_dict'], c0, np.ones((n0, 1), np.float32), 3, ks, True)
         oF1 = oresunet.resunet_forward(ck['state_dict'], c1, np.ones((n1, 1), np.float32), 3, ks, True)
-        runs['fcgf'].append(time.time() - t0)
+        net_runs['fcgf'].append(time.time() - t0)
         t0 = time.time()
         c6, f6 = opipe.inlier_inputs(p0, p1, c0, c1, np.arange(n0), pair0['idx1'])
         ologit = oresunet.resunet_forward(ck['state_dict_inlier'], c6, f6, 6, 3, False).reshape(-1)
-        runs['inlier_net'].append(time.time() - t0)
-    t['fcgf'] = float(np.median(runs['fcgf']))
-    t['inlier_net'] = float(np.median(runs['inlier_net']))
+        net_runs['inlier_net'].append(time.time() - t0)
+    t['fcgf'] = float(np.median(net_runs['fcgf']))
+    t['inlier_net'] = float(np.median(net_runs['inlier_net']))
     parity = {'pair': 0, 'voxels': [n0, n1],
               'dF': float(max(np.abs(pair0['F0'] - oF0).max(), np.abs(pair0['F1'] - oF1).max())),
               'dlogit_rel': float(np.abs(pair0['logit'] - ologit).max() / max(1e-12, np.abs(ologit).max())),
@@ -228,7 +228,8 @@ def oracle_parity_and_baseline(ck, args, pair0, do_baseline):
                       f'on a host that reports {found} cores (the oracle is thousands of small gather / mm / index_add '
                       'calls per forward: beyond ~16 threads their fork/join overhead outweighs the parallel work)',
             'stage_s': {k: round(v, 3) for k, v in t.items()},
-            'stage_runs_s': {k: [round(x, 3) for x in v] for k, v in runs.items()},
+            'stage_runs_s': dict({k: [round(x, 3) for x in v] for k, v in net_runs.items()},
+                                 registration=[round(x, 3) for x in runs]),
             'reference_modules_in_container': {
                 'note': 'the reference\'s own core/knn.py / core/registration.py timed on CPU tensors in the build '
                         'container (8 cores, torch 2.10; BASELINE.md section 2) -- /root/reference is absent on the GPU box',

@@ -103,7 +103,7 @@ __device__ __forceinline__ int mask_rank_pre(const uint32_t *__restrict__ m, con
 // =========================== D = 6: bit-matrix pipeline =====================================
 // A 6-D map has 729 offsets but only 2..45 neighbours per row (0.3..6 % density), so nothing of
 // size [K, N] is ever materialised except ONE BIT per (row, offset):
-//   bits     search (pruned or generic) sets mask_out[o][k] (and mask_in[i][k] for maps that are
+//   bits     the search (pruned_search6) sets mask_out[o][k] (and mask_in[i][k] for maps that are
 //            also used swapped).  Same-stride maps are symmetric -- (o, k) -> i  <=>  (i, K-1-k) -> o
 //            -- so only offsets below the centre are searched and every hit sets both bits.
 //            Every hit is also APPENDED as a record (offset, row, input row) to a hit list -- in no particular
@@ -162,66 +162,6 @@ __device__ __forceinline__ int64_t hit_slots(int n, const HitList &h, volatile i
 }
 __device__ __forceinline__ void hit_end(const HitList &h, volatile int *cur, int wave_id) {
   if ((threadIdx.x & 63) == 0) h.wave_count[wave_id] = cur[threadIdx.x >> 6];
-}
-
-// generic search, bits only: grid = (row blocks, ceil(offsets to probe / 4)); a thread probes four consecutive
-// offsets of its row with the batched look-up (two memory latencies for the four probes).  Its regions hold the most
-// a wave can produce (64 x (4 probes x 2 + the centre record)): no overflow, no replay.  Since round 4 the 6-D maps of
-// the network all take the pruned search below; this one stays for DGR_KMAP_GENERIC8=1 (A/B of the stride-8 map).
-constexpr int KM_PROBES = 4;
-template <int D>
-__global__ void __launch_bounds__(KM_THREADS)
-    kmap_bits(const int32_t *__restrict__ out_coords, const int32_t *n_out_dev,
-              const int32_t *__restrict__ in_coords, const int32_t *__restrict__ in_table, uint32_t in_mask,
-              int ks, int ts_in, int K, int KW, int n_probe, int symmetric, uint32_t *mask_out, uint32_t *mask_in,
-              HitList hl) {
-  constexpr int NC = D + 1;
-  __shared__ int hit_cur[KM_THREADS / 64];
-  hit_begin(hit_cur);
-  const int wid = (int)((blockIdx.y * gridDim.x + blockIdx.x) * (KM_THREADS / 64) + (threadIdx.x >> 6));
-  const int k0 = blockIdx.y * KM_PROBES;
-  const int64_t o = (int64_t)blockIdx.x * KM_THREADS + threadIdx.x;
-  if (o < *n_out_dev) {
-  if (symmetric && k0 == 0) {  // the centre offset always maps a row onto itself
-    const int c = K >> 1;
-    atomicOr(&mask_out[o * KW + (c >> 5)], 1u << (c & 31));
-    const int64_t s = hit_slots(1, hl, hit_cur, wid);
-    if (s >= 0) hl.recs[s] = hit_pack(c, o, o);
-  }
-  int32_t base[NC];
-#pragma unroll
-  for (int d = 0; d < NC; ++d) base[d] = out_coords[o * NC + d];
-  int32_t q[KM_PROBES][NC];
-#pragma unroll
-  for (int u = 0; u < KM_PROBES; ++u) {
-    int32_t delta[D];
-    offset_of<D>(min(k0 + u, n_probe - 1), ks, ts_in, delta);
-    q[u][0] = base[0];
-#pragma unroll
-    for (int d = 0; d < D; ++d) q[u][1 + d] = base[1 + d] + delta[d];
-  }
-  int hit[KM_PROBES];
-  dgr_lookup_many<NC, KM_PROBES>(in_table, in_mask, in_coords, q, hit);
-#pragma unroll
-  for (int u = 0; u < KM_PROBES; ++u) {
-    const int k = k0 + u;
-    if (k >= n_probe || hit[u] < 0) continue;
-    atomicOr(&mask_out[o * KW + (k >> 5)], 1u << (k & 31));
-    const int km = K - 1 - k;
-    if (symmetric) {
-      atomicOr(&mask_out[(int64_t)hit[u] * KW + (km >> 5)], 1u << (km & 31));
-    } else if (mask_in) {
-      atomicOr(&mask_in[(int64_t)hit[u] * KW + (k >> 5)], 1u << (k & 31));
-    }
-    const int n = symmetric ? 2 : 1;   // (k < K / 2 here: the mirror is another pair)
-    const int64_t s = hit_slots(n, hl, hit_cur, wid);
-    if (s >= 0) {
-      hl.recs[s] = hit_pack(k, o, hit[u]);
-      if (n == 2) hl.recs[s + 1] = hit_pack(km, hit[u], o);
-    }
-  }
-  }
-  hit_end(hl, hit_cur, wid);
 }
 
 // pruned search: one thread per (output row, first-half offset).  A 6-D neighbour (ca + da, cb + db) can only exist
@@ -384,15 +324,13 @@ __device__ __forceinline__ void place_pair(const PlaceArgs &p, int k, int64_t o,
 }
 
 // one wave per region of the hit list: one lane per record places the pair; a wave whose region overflowed during the
-// search (count -1) repeats that wave's search and places what it finds (`replay.hb.table` NULL: the generic search,
-// whose regions cannot overflow)
+// search (count -1) repeats that wave's search and places what it finds
 __global__ void __launch_bounds__(KM_THREADS)
     kmap_place_hits(HitList h, int n_waves, PlaceArgs p, PrunedArgs replay) {
   const int lane = threadIdx.x & 63;
   for (int r = blockIdx.x * (KM_THREADS / 64) + (threadIdx.x >> 6); r < n_waves; r += gridDim.x * (KM_THREADS / 64)) {
     const int n = h.wave_count[r];
     if (n < 0) {
-      if (!replay.hb.table) { *p.overflow = 2; continue; }
       pruned_search6(replay, (int64_t)r * 64 + lane, [&](int k, int64_t o, int in) {
         place_pair(p, k, o, in);
         if (replay.symmetric && 728 - k != k) place_pair(p, 728 - k, in, o);
@@ -613,10 +551,8 @@ static int build_kernel_maps6(DgrArena &arena, const Kmap6Job *jobs, int nj, int
                               hipStream_t stream) {
   constexpr int K = 729, KW = (K + 31) / 32;
   DGR_REQUIRE(nj >= 1 && nj <= KM_MAXJOBS, "6-D kernel maps: %d jobs", nj);
-  static const bool generic8 = getenv("DGR_KMAP_GENERIC8") != nullptr;   // A/B: the stride-8 map by 364 hash probes per row
   struct Tr {   // transients of one job
     int RB, symmetric;
-    bool pruned;
     int64_t n_cap, n_in_cap, hit_waves;
     int32_t *counts, *base, *total, *cnt_out, *cnt_in;
     uint32_t *mask_out, *mask_in;
@@ -653,23 +589,20 @@ static int build_kernel_maps6(DgrArena &arena, const Kmap6Job *jobs, int nj, int
     r.RB = (int)dgr_ceil_div(r.n_cap, KM_THREADS);
     // same-stride maps (in and out are the SAME coordinate set) are symmetric: search half the offsets
     r.symmetric = (J.in->coords == J.out->coords && !J.need_in_csr) ? 1 : 0;
-    r.pruned = J.hb && J.hb->built && J.hb_out && J.hb_out->built && !(generic8 && J.in->ts == 8 && r.symmetric);
+    DGR_REQUIRE(J.hb && J.hb->built && J.hb_out && J.hb_out->built, "6-D kernel map: first-half buckets missing");
     DGR_ALLOC(r.counts, arena, int32_t, (int64_t)K * r.RB);
     DGR_ALLOC(r.base, arena, int32_t, (int64_t)K * r.RB);
     DGR_ALLOC(r.total, arena, int32_t, 1);
     r.cnt_in = nullptr;
     if (J.need_in_csr) DGR_ALLOC(r.cnt_in, arena, int32_t, r.n_in_cap + 1);
     DGR_ALLOC(r.cell, arena, int4, (int64_t)r.RB * (KM_THREADS / 64) * K);
-    // hit list: one region per wave of the search (pruned: KM_REGION records, overflow -> replay; generic: the most 64
-    // of its threads can produce)
-    // (pruned: thread = (first-half offset, row): whole row blocks per offset, so that a wave never mixes offsets)
-    const int64_t search_blocks = r.pruned ? dgr_ceil_div(r.n_cap * (r.symmetric ? 14 : 27), KM_THREADS)
-                                           : (int64_t)r.RB * dgr_ceil_div(r.symmetric ? K / 2 : K, KM_PROBES);
+    // hit list: one region per wave of the search (thread = (first-half offset, row in bucket order)); a wave whose
+    // region overflows is replayed by the placing kernel
+    const int64_t search_blocks = dgr_ceil_div(r.n_cap * (r.symmetric ? 14 : 27), KM_THREADS);
     r.hit_waves = search_blocks * (KM_THREADS / 64);
     // (a wave = 64 rows under one first-half offset: a dozen records at the fine levels and in the strided maps, ~180 in
     // the stride-8 map with its 39 neighbours per row, several times that in its dense corners)
-    r.hl.region = r.pruned ? ((J.in->ts >= 8 && r.symmetric) ? 2 * KM_REGION : KM_REGION / 2)
-                           : 64 * (KM_PROBES * (r.symmetric ? 2 : 1) + 1);
+    r.hl.region = (J.in->ts >= 8 && r.symmetric) ? 2 * KM_REGION : KM_REGION / 2;
     DGR_REQUIRE(r.hit_waves < (1ll << 31), "6-D kernel map: too many search waves");
     DGR_ALLOC(r.hl.recs, arena, unsigned long long, r.hit_waves * r.hl.region);
     DGR_ALLOC(r.hl.wave_count, arena, int32_t, r.hit_waves);
@@ -681,14 +614,9 @@ static int build_kernel_maps6(DgrArena &arena, const Kmap6Job *jobs, int nj, int
   for (int m = 0; m < nj; ++m) {
     const Kmap6Job &J = jobs[m];
     Tr &r = t[m];
-    if (r.pruned) {
+    {
       const PrunedArgs pa{J.out->coords, J.out->n_dev, J.hb_out->second, r.n_cap, *J.hb, J.in->ts, r.symmetric};
       kmap_bits_pruned6<<<(int)(r.hit_waves / (KM_THREADS / 64)), KM_THREADS, 0, stream>>>(pa, KW, r.mask_out, r.mask_in, r.hl);
-    } else {
-      const int n_probe = r.symmetric ? K / 2 : K;
-      kmap_bits<6><<<dim3(r.RB, (n_probe + KM_PROBES - 1) / KM_PROBES), KM_THREADS, 0, stream>>>(
-          J.out->coords, J.out->n_dev, J.in->coords, J.in->table, J.in->table_mask, 3, J.in->ts, K, KW, n_probe, r.symmetric,
-          r.mask_out, r.mask_in, r.hl);
     }
     kmap_colmask<<<r.RB, KM_THREADS, 0, stream>>>(r.mask_out, J.out->n_dev, K, KW, r.RB, r.cell, r.counts, r.cnt_out, r.wpre_out);
     if (J.need_in_csr)
@@ -724,8 +652,7 @@ static int build_kernel_maps6(DgrArena &arena, const Kmap6Job *jobs, int nj, int
     DgrKernelMap *km = J.km;
     const PlaceArgs pl{K, KW, r.RB, r.mask_out, km->out_ptr, r.cell, r.base, km->pair_in, km->pair_out, km->pair_k, km->out_pos,
                        km->pair_cap, overflow, r.mask_in, km->in_ptr, km->in_pos, r.wpre_out, r.wpre_in};
-    PrunedArgs pa{J.out->coords, J.out->n_dev, nullptr, r.n_cap, DgrHalfBuckets(), J.in->ts, r.symmetric};
-    if (r.pruned) { pa.hb = *J.hb; pa.out_order = J.hb_out->second; }
+    const PrunedArgs pa{J.out->coords, J.out->n_dev, J.hb_out->second, r.n_cap, *J.hb, J.in->ts, r.symmetric};
     const int blocks = (int)std::min<int64_t>(dgr_ceil_div(r.hit_waves, KM_THREADS / 64), 16384);
     kmap_place_hits<<<blocks, KM_THREADS, 0, stream>>>(r.hl, (int)r.hit_waves, pl, pa);
     km->built = true;
