@@ -371,31 +371,76 @@ __global__ void bucket_fill_kernel(const int32_t *__restrict__ row_bucket, const
   second[start[b] + atomicAdd(&cursor[b], 1)] = make_int4(c[4], c[5], c[6], (int32_t)r);   // order inside a bucket is irrelevant
 }
 
-int dgr_build_half_buckets(DgrArena &arena, const DgrCoordMap &cm, DgrHalfBuckets *hb, hipStream_t stream) {
-  const int64_t n = cm.n_cap;
-  int32_t *keys, *flag, *rank, *nb_dev, *row_bucket, *counts, *cursor;
-  DGR_ALLOC(keys, arena, int32_t, n * 4);
-  DGR_ALLOC(flag, arena, int32_t, n);
-  DGR_ALLOC(rank, arena, int32_t, n);
-  DGR_ALLOC(nb_dev, arena, int32_t, 1);
-  DGR_ALLOC(row_bucket, arena, int32_t, n);
-  DGR_ALLOC(counts, arena, int32_t, 2 * (n + 1));   // counts | cursor: one clear
-  cursor = counts + (n + 1);
-  DGR_ALLOC(hb->bkeys, arena, int32_t, n * 4);
-  DGR_ALLOC(hb->start, arena, int32_t, n + 1);
-  DGR_ALLOC(hb->second, arena, int4, n);
-  half_keys_kernel<<<grid_for(n), 256, 0, stream>>>(cm.coords, cm.n_dev, keys);
-  DGR_CHECK(unique_rows_t<4>(arena, keys, cm.n_dev, n, flag, rank, nb_dev, &hb->table, &hb->mask, stream));
-  unique_compact<4><<<grid_for(n), 256, 0, stream>>>(keys, cm.n_dev, n, flag, rank, hb->bkeys, nullptr);
-  table_relabel<<<grid_for((int64_t)hb->mask + 1), 256, 0, stream>>>(hb->table, hb->mask + 1, rank);
-  DGR_HIP_CHECK(hipMemsetAsync(counts, 0, (size_t)2 * (n + 1) * sizeof(int32_t), stream));
-  bucket_count_kernel<<<grid_for(n), 256, 0, stream>>>(keys, cm.n_dev, hb->table, hb->mask, hb->bkeys, row_bucket,
-                                                       counts);
+// The first-half buckets of ALL levels of a 6-D sparse tensor, step by step together: the levels are independent once
+// their coordinate maps exist, so the hash tables are cleared by one memset, the bucket counters by another, and the
+// two scans per level (bucket ranks, bucket starts) run as two multi-array scans -- round 3 built level after level:
+// 8 clears and 24 scan launches per forward.
+int dgr_build_half_buckets(DgrArena &arena, const DgrCoordMap *cm, DgrHalfBuckets *hb, int levels, hipStream_t stream) {
+  DGR_REQUIRE(levels >= 1 && levels <= 4, "half buckets: %d levels", levels);
+  int32_t *keys[4], *flag[4], *rank[4], *nb_dev[4], *row_bucket[4], *counts[4], *cursor[4];
+  uint32_t cap[4];
+  size_t table_words = 0, count_words = 0;
+  for (int l = 0; l < levels; ++l) {
+    const int64_t n = cm[l].n_cap;
+    cap[l] = dgr_next_pow2((uint64_t)(2 * n > 64 ? 2 * n : 64));
+    table_words += cap[l];
+    count_words += 2 * (size_t)(n + 1);
+  }
+  int32_t *tables, *cnts;
+  DGR_ALLOC(tables, arena, int32_t, table_words);
+  DGR_ALLOC(cnts, arena, int32_t, count_words);
+  DGR_HIP_CHECK(hipMemsetAsync(tables, 0xff, table_words * sizeof(int32_t), stream));
+  DGR_HIP_CHECK(hipMemsetAsync(cnts, 0, count_words * sizeof(int32_t), stream));
+  for (int l = 0; l < levels; ++l) {
+    const int64_t n = cm[l].n_cap;
+    hb[l].table = tables; tables += cap[l];
+    hb[l].mask = cap[l] - 1;
+    counts[l] = cnts; cursor[l] = cnts + (n + 1); cnts += 2 * (n + 1);
+    DGR_ALLOC(keys[l], arena, int32_t, n * 4);
+    DGR_ALLOC(flag[l], arena, int32_t, n);
+    DGR_ALLOC(rank[l], arena, int32_t, n);
+    DGR_ALLOC(nb_dev[l], arena, int32_t, 1);
+    DGR_ALLOC(row_bucket[l], arena, int32_t, n);
+    DGR_ALLOC(hb[l].bkeys, arena, int32_t, n * 4);
+    DGR_ALLOC(hb[l].start, arena, int32_t, n + 1);
+    DGR_ALLOC(hb[l].second, arena, int4, n);
+  }
+  // distinct first halves, first-occurrence order (unique_rows_t, all levels at once)
+  for (int l = 0; l < levels; ++l) {
+    const int64_t n = cm[l].n_cap;
+    half_keys_kernel<<<grid_for(n), 256, 0, stream>>>(cm[l].coords, cm[l].n_dev, keys[l]);
+    unique_insert<4><<<grid_for(n), 256, 0, stream>>>(keys[l], cm[l].n_dev, n, hb[l].table, hb[l].mask);
+    unique_flag<4><<<grid_for(n), 256, 0, stream>>>(keys[l], cm[l].n_dev, n, hb[l].table, hb[l].mask, flag[l], nullptr);
+  }
   DGR_LAUNCH_CHECK();
-  DGR_CHECK(dgr_exclusive_scan_i32(arena, counts, hb->start, n + 1, nullptr, stream));
-  bucket_fill_kernel<<<grid_for(n), 256, 0, stream>>>(row_bucket, cm.n_dev, hb->start, cursor, cm.coords, hb->second);
+  {
+    const int32_t *ins[4];
+    int32_t *outs[4], *tots[4];
+    int64_t ns[4];
+    for (int l = 0; l < levels; ++l) { ins[l] = flag[l]; outs[l] = rank[l]; tots[l] = nb_dev[l]; ns[l] = cm[l].n_cap; }
+    DGR_CHECK(dgr_exclusive_scan_multi(arena, levels, ins, outs, ns, tots, stream));
+  }
+  for (int l = 0; l < levels; ++l) {
+    const int64_t n = cm[l].n_cap;
+    unique_compact<4><<<grid_for(n), 256, 0, stream>>>(keys[l], cm[l].n_dev, n, flag[l], rank[l], hb[l].bkeys, nullptr);
+    table_relabel<<<grid_for((int64_t)hb[l].mask + 1), 256, 0, stream>>>(hb[l].table, hb[l].mask + 1, rank[l]);
+    bucket_count_kernel<<<grid_for(n), 256, 0, stream>>>(keys[l], cm[l].n_dev, hb[l].table, hb[l].mask, hb[l].bkeys, row_bucket[l],
+                                                         counts[l]);
+  }
   DGR_LAUNCH_CHECK();
-  hb->built = true;
+  {
+    const int32_t *ins[4];
+    int32_t *outs[4], *tots[4];
+    int64_t ns[4];
+    for (int l = 0; l < levels; ++l) { ins[l] = counts[l]; outs[l] = hb[l].start; tots[l] = nullptr; ns[l] = cm[l].n_cap + 1; }
+    DGR_CHECK(dgr_exclusive_scan_multi(arena, levels, ins, outs, ns, tots, stream));
+  }
+  for (int l = 0; l < levels; ++l) {
+    bucket_fill_kernel<<<grid_for(cm[l].n_cap), 256, 0, stream>>>(row_bucket[l], cm[l].n_dev, hb[l].start, cursor[l], cm[l].coords,
+                                                                  hb[l].second);
+    hb[l].built = true;
+  }
+  DGR_LAUNCH_CHECK();
   return DGR_OK;
 }
 

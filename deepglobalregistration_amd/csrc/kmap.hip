@@ -736,7 +736,7 @@ int dgr_nbr_counts(const DgrNbrTable &t, const int32_t *n_out_dev, int64_t count
 
 int dgr_build_coord_maps(DgrArena &arena, const int32_t *coords, int64_t N, DgrMapSet *ms,
                          hipStream_t stream);
-int dgr_build_half_buckets(DgrArena &arena, const DgrCoordMap &cm, DgrHalfBuckets *hb, hipStream_t stream);
+int dgr_build_half_buckets(DgrArena &arena, const DgrCoordMap *cm, DgrHalfBuckets *hb, int levels, hipStream_t stream);
 
 int dgr_build_maps(DgrArena &arena, const int32_t *coords, int64_t N, int D, int conv1_ks,
                    DgrMapSet *ms, hipStream_t stream, bool skip_conv1_map, bool lean, bool nbr_tables) {
@@ -775,7 +775,7 @@ int dgr_build_maps(DgrArena &arena, const int32_t *coords, int64_t N, int D, int
   if (D == 6) {
     DGR_REQUIRE(conv1_ks == 3, "6-D kernel maps support kernel size 3 only (got %d)", conv1_ks);
     // first-half buckets of every level: the pruned search of all seven maps (since round 4 also at tensor stride 8)
-    for (int l = 0; l < 4; ++l) DGR_CHECK(dgr_build_half_buckets(arena, ms->cm[l], &ms->hb[l], stream));
+    DGR_CHECK(dgr_build_half_buckets(arena, ms->cm, ms->hb, 4, stream));
     Kmap6Job jobs[7];
     for (int l = 0; l < 4; ++l) jobs[l] = {&ms->cm[l], &ms->cm[l], &ms->hb[l], &ms->hb[l], false, !lean, !lean || l == 0, &ms->same[l]};
     // strided maps are also used swapped by the transposed convs: the in-major CSR too
