@@ -88,6 +88,10 @@ struct DgrCoordMap {
   int ts = 1;                 // tensor stride
   int32_t *table = nullptr;   // open addressing: row index or -1
   uint32_t table_mask = 0;    // capacity - 1
+  // 6-D maps at tensor strides > 1 are numbered in the order of their first-half buckets (dgr_build_half_buckets): the
+  // row order of a coarse map is internal.  canon[row] = the row's index in first-occurrence order (what
+  // ME / the oracle would call it); the inspection entry points translate through it.  NULL: rows are in that order.
+  int32_t *canon = nullptr;
 };
 
 // D = 6 only: rows grouped by their first-half key (batch, x0, y0, z0); lets the kernel-map search

@@ -8,6 +8,10 @@
 // Offset enumeration: first spatial dimension fastest -- kept in ONE place:
 // `offset_of`.  Deterministic: two passes (count, fill) with block-level ranks, no atomics on
 // the pair positions.
+#include <string.h>
+
+#include <algorithm>
+
 #include "dgr_internal.h"
 #include "hash.h"
 
@@ -736,7 +740,7 @@ int dgr_nbr_counts(const DgrNbrTable &t, const int32_t *n_out_dev, int64_t count
 
 int dgr_build_coord_maps(DgrArena &arena, const int32_t *coords, int64_t N, DgrMapSet *ms,
                          hipStream_t stream);
-int dgr_build_half_buckets(DgrArena &arena, const DgrCoordMap *cm, DgrHalfBuckets *hb, int levels, hipStream_t stream);
+int dgr_build_half_buckets(DgrArena &arena, DgrCoordMap *cm, DgrHalfBuckets *hb, int levels, int renumber_from, hipStream_t stream);
 
 int dgr_build_maps(DgrArena &arena, const int32_t *coords, int64_t N, int D, int conv1_ks,
                    DgrMapSet *ms, hipStream_t stream, bool skip_conv1_map, bool lean, bool nbr_tables) {
@@ -775,7 +779,8 @@ int dgr_build_maps(DgrArena &arena, const int32_t *coords, int64_t N, int D, int
   if (D == 6) {
     DGR_REQUIRE(conv1_ks == 3, "6-D kernel maps support kernel size 3 only (got %d)", conv1_ks);
     // first-half buckets of every level: the pruned search of all seven maps (since round 4 also at tensor stride 8)
-    DGR_CHECK(dgr_build_half_buckets(arena, ms->cm, ms->hb, 4, stream));
+    // (the coarse maps are numbered in bucket order on the way; level 0 keeps the caller's row order)
+    DGR_CHECK(dgr_build_half_buckets(arena, ms->cm, ms->hb, 4, 1, stream));
     Kmap6Job jobs[7];
     for (int l = 0; l < 4; ++l) jobs[l] = {&ms->cm[l], &ms->cm[l], &ms->hb[l], &ms->hb[l], false, !lean, !lean || l == 0, &ms->same[l]};
     // strided maps are also used swapped by the transposed convs: the in-major CSR too
@@ -859,8 +864,15 @@ extern "C" int dgr_maps_get_coords(dgr_maps *m, int ts, int32_t *host_out, int64
   *n = n32;
   if (host_out) {
     DGR_REQUIRE(capacity >= (int64_t)n32 * m->ms.nc, "host buffer too small");
-    DGR_HIP_CHECK(hipMemcpy(host_out, m->ms.cm[l].coords, (size_t)n32 * m->ms.nc * sizeof(int32_t),
-                            hipMemcpyDeviceToHost));
+    const int nc = m->ms.nc;
+    if (!m->ms.cm[l].canon) {
+      DGR_HIP_CHECK(hipMemcpy(host_out, m->ms.cm[l].coords, (size_t)n32 * nc * sizeof(int32_t), hipMemcpyDeviceToHost));
+    } else {   // rows back in first-occurrence order
+      std::vector<int32_t> tmp((size_t)n32 * nc), canon(n32);
+      DGR_HIP_CHECK(hipMemcpy(tmp.data(), m->ms.cm[l].coords, tmp.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+      DGR_HIP_CHECK(hipMemcpy(canon.data(), m->ms.cm[l].canon, canon.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+      for (int32_t p = 0; p < n32; ++p) memcpy(host_out + (size_t)canon[p] * nc, tmp.data() + (size_t)p * nc, nc * sizeof(int32_t));
+    }
   }
   return DGR_OK;
 }
@@ -923,6 +935,31 @@ extern "C" int dgr_maps_get_kernel_map(dgr_maps *m, int kind, int ts, int32_t *r
     DGR_REQUIRE(pair_cap >= total, "pair buffers too small");
     DGR_HIP_CHECK(hipMemcpy(pair_in, km->pair_in, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost));
     DGR_HIP_CHECK(hipMemcpy(pair_out, km->pair_out, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToHost));
+    // rows in first-occurrence numbering (coarse 6-D maps are numbered by bucket inside the library), pairs of a rule
+    // sorted by output row in THAT numbering: the layout the getter documents
+    const DgrCoordMap &cin = m->ms.cm[l], &cout = m->ms.cm[kind == 2 ? l + 1 : l];
+    if (cin.canon || cout.canon) {
+      auto fetch = [&](const DgrCoordMap &c, std::vector<int32_t> &v) -> int {
+        if (!c.canon) return DGR_OK;
+        int32_t n = 0;
+        DGR_HIP_CHECK(hipMemcpy(&n, c.n_dev, sizeof(int32_t), hipMemcpyDeviceToHost));
+        v.resize(n);
+        DGR_HIP_CHECK(hipMemcpy(v.data(), c.canon, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+        return DGR_OK;
+      };
+      std::vector<int32_t> ci, co, rp(km->K + 1);
+      DGR_CHECK(fetch(cin, ci));
+      DGR_CHECK(fetch(cout, co));
+      DGR_HIP_CHECK(hipMemcpy(rp.data(), km->rule_ptr, rp.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+      std::vector<std::pair<int32_t, int32_t>> tmp;
+      for (int k = 0; k < km->K; ++k) {
+        tmp.clear();
+        for (int32_t q = rp[k]; q < rp[k + 1]; ++q)
+          tmp.push_back({cout.canon ? co[pair_out[q]] : pair_out[q], cin.canon ? ci[pair_in[q]] : pair_in[q]});
+        std::sort(tmp.begin(), tmp.end());
+        for (size_t u = 0; u < tmp.size(); ++u) { pair_out[rp[k] + u] = tmp[u].first; pair_in[rp[k] + u] = tmp[u].second; }
+      }
+    }
   }
   return DGR_OK;
 }

@@ -64,6 +64,7 @@ struct DgrTensorRef {
   const float *ptr = nullptr;
   int ld = 0, cols = 0;
   const int32_t *n_dev = nullptr;
+  const int32_t *canon = nullptr;   // rows of a coarse 6-D map: library numbering -> first-occurrence numbering
 };
 
 struct dgr_net {
@@ -637,11 +638,11 @@ int dgr_resunet_forward_impl(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, 
   net->run_generation = ctx->arena.generation;
   I.clear();
   I["s1"] = {S1.ptr, 96, 32, ms.cm[0].n_dev};
-  I["s2"] = {S2.ptr, 128, 64, ms.cm[1].n_dev};
-  I["s4"] = {S4.ptr, 256, 128, ms.cm[2].n_dev};
-  I["s8"] = {S8.ptr, 256, 256, ms.cm[3].n_dev};
-  I["s4_tr"] = {cat4, 256, 128, ms.cm[2].n_dev};
-  I["s2_tr"] = {cat2, 128, 64, ms.cm[1].n_dev};
+  I["s2"] = {S2.ptr, 128, 64, ms.cm[1].n_dev, ms.cm[1].canon};
+  I["s4"] = {S4.ptr, 256, 128, ms.cm[2].n_dev, ms.cm[2].canon};
+  I["s8"] = {S8.ptr, 256, 256, ms.cm[3].n_dev, ms.cm[3].canon};
+  I["s4_tr"] = {cat4, 256, 128, ms.cm[2].n_dev, ms.cm[2].canon};
+  I["s2_tr"] = {cat2, 128, 64, ms.cm[1].n_dev, ms.cm[1].canon};
   I["s1_tr"] = {cat1, 96, 64, ms.cm[0].n_dev};
 
   return DGR_OK;
@@ -788,8 +789,18 @@ extern "C" int dgr_net_get_intermediate(dgr_ctx *ctx, dgr_net *net, const char *
   *cols = t.cols;
   if (host_out) {
     DGR_REQUIRE(capacity >= (int64_t)n * t.cols, "host buffer too small");
-    DGR_HIP_CHECK(hipMemcpy2D(host_out, (size_t)t.cols * sizeof(float), t.ptr, (size_t)t.ld * sizeof(float),
-                              (size_t)t.cols * sizeof(float), (size_t)n, hipMemcpyDeviceToHost));
+    if (!t.canon) {
+      DGR_HIP_CHECK(hipMemcpy2D(host_out, (size_t)t.cols * sizeof(float), t.ptr, (size_t)t.ld * sizeof(float),
+                                (size_t)t.cols * sizeof(float), (size_t)n, hipMemcpyDeviceToHost));
+    } else {   // rows back in first-occurrence order (coarse 6-D maps are numbered in bucket order)
+      std::vector<float> tmp((size_t)n * t.cols);
+      std::vector<int32_t> canon(n);
+      DGR_HIP_CHECK(hipMemcpy2D(tmp.data(), (size_t)t.cols * sizeof(float), t.ptr, (size_t)t.ld * sizeof(float),
+                                (size_t)t.cols * sizeof(float), (size_t)n, hipMemcpyDeviceToHost));
+      DGR_HIP_CHECK(hipMemcpy(canon.data(), t.canon, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+      for (int32_t p = 0; p < n; ++p)
+        memcpy(host_out + (size_t)canon[p] * t.cols, tmp.data() + (size_t)p * t.cols, (size_t)t.cols * sizeof(float));
+    }
     for (int64_t i = 0; i < (int64_t)n * t.cols; ++i) host_out[i] = host_out[i] > 0.f ? host_out[i] : 0.f;
   }
   return DGR_OK;

@@ -1,0 +1,10 @@
+set -x
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r11; mkdir -p $O
+export TMPDIR=/tmp
+(timeout 1200 python -m pytest tests/test_gpu_maps.py tests/test_gpu_resunet.py tests/test_gpu_pipeline.py -m gpu -x -q 2>&1 | tail -8) > $O/pytest.log 2>&1
+for rep in 1 2; do
+DGR_HIP_LIB=$PWD/deepglobalregistration_amd/lib_prev/libdgr_hip.so timeout 300 python bench.py --streams 1 --pairs-per-step 4 --no-parity --steps 30 > $O/bench_prev_$rep.json 2> $O/bench_prev_$rep.err
+timeout 300 python bench.py --streams 1 --pairs-per-step 4 --no-parity --steps 30 > $O/bench_new_$rep.json 2> $O/bench_new_$rep.err
+done
+tail -4 $O/pytest.log
