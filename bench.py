@@ -666,8 +666,9 @@ def main():
                          'frac': products * alg / peak,
                          'pipe': 'dense f16 MFMA (v_mfma_f32_32x32x16_f16)' if split else 'f32 MFMA (v_mfma_f32_32x32x2_f32)',
                          'products_per_mac': products, 'algorithmic_tflops': alg,
-                         'limited_by': 'not the matrix pipe: per-CU vector-memory throughput (4 bytes of weights per MAC-column '
-                                       'at 64 pairs per tile) and the HBM write stream of the product rows (DESIGN.md 4.2)'
+                         'limited_by': 'not the matrix pipe: the memory system -- one gathered and one product KB per pair (rule-major '
+                                       'tiles of 64 pairs) are ~7.7 GB per launch through HBM / MALL at ~4.3 TB/s, against a measured '
+                                       '3.6-5.2 TB/s for random 256-byte rows; row order irrelevant (DESIGN.md 4.2)'
                                        if split else None,
                          'traffic': pmc.get('hbm_bytes_per_launch') if pmc else None,
                          'traffic_source': (f'profiles/{pmc_file}: separate rocprofv3 --pmc passes of the one-stream command, '
