@@ -436,7 +436,8 @@ struct Fwd {
       return DGR_OK;
     }
     const bool small_cin = km && !swapped && !res && L.cin <= 8 && L.cout == 32 && L.cin_pad == 8;
-    const char *kname = "conv_small_cin_kernel";
+    // (Cin = 6 / 1 -- the inlier net's two input widths -- run the thread-per-voxel variant, conv.hip)
+    const char *kname = (L.cin == 6 || L.cin == 1) ? "conv_small_cin_row_kernel" : "conv_small_cin_kernel";
     const bool wide = L.wb && km;
     if (small_cin)
       DGR_CHECK(dgr_conv_small_cin(in.ptr, in.ld, in.relu, L.cin, L.w, L.shift, *km, cout_map.n_dev, cout_map.n_cap,

@@ -47,7 +47,7 @@ def test_a_reordered_implementation_stays_inside_the_reported_band():
 def test_bench_checker_legs_run_on_cpu(monkeypatch):
     """`bench.py`'s parity + CPU-baseline leg (the part of the driver's no-flag command that runs AFTER the timed
     region) end to end on a tiny pair, with the oracle itself standing in for the HIP outputs and the HIP refinement:
-    every key the bench line promises is there, the deviations are zero, the flags say so.  (Round 4 shipped a name
+    every key the bench line promises is there, the deviations are rounding noise, the flags say so.  (Round 4 shipped a name
     collision in this function to the GPU box once: nothing on the CPU side executed it.)"""
     import argparse
     import bench   # (repo root is on sys.path: tests/conftest.py)
@@ -75,9 +75,10 @@ def test_bench_checker_legs_run_on_cpu(monkeypatch):
     pair0 = {'xyz0': p0, 'coords0': c0, 'xyz1': p1, 'coords1': c1, 'idx1': idx1, 'F0': F0, 'F1': F1, 'logit': logit,
              'forced': forced, 'device': 'cpu'}
     parity, base = bench.oracle_parity_and_baseline(ck, args, pair0, True)
-    assert parity['dF'] == 0 and parity['dlogit_rel'] == 0 and parity['features_logits_within_1e-4']
+    # (two runs of the oracle agree to rounding only: its BLAS sums depend on the thread count the process is at)
+    assert parity['dF'] < 1e-6 and parity['dlogit_rel'] < 1e-6 and parity['features_logits_within_1e-4']
     if 'dR' in parity:                        # the tiny pair passes the gate with all-ground-truth matches
-        assert parity['dR'] == 0 and parity['dt'] == 0 and parity['rt_within_1e-4'] and parity['within_1e-4'] and parity['ok']
+        assert parity['dR'] < 1e-6 and parity['dt'] < 1e-6 and parity['rt_within_1e-4'] and parity['within_1e-4'] and parity['ok']
     assert base['kind'] == 'port' and base['value'] > 0 and base['cores'] >= 1
     assert set(base['stage_s']) == {'fcgf', 'inlier_net', 'knn', 'registration'}
     assert len(base['stage_runs_s']['fcgf']) == 3 and len(base['stage_runs_s']['inlier_net']) == 3
