@@ -21,6 +21,11 @@ Parity status (see DESIGN.md "Oracle"):
   `model/common.py:11-21`); the conventions that cannot be verified here
   (kernel-offset enumeration order, transposed-map convention, quantize
   ordering) live in exactly one function each in `me_semantics.py`.
+  The NETWORK on top of those conventions (topology, op order, state-dict
+  layout) is pinned: `tests/golden/make_golden_model.py` runs the reference's
+  own `ResUNetBN2C` classes over a stand-in for the ME import
+  (`tests/golden/me_stub`) and `tests/test_oracle_model_golden.py` holds
+  `oracle.resunet` to the committed outputs.
 * `oracle.open3d_reg`: **parity unpinned** -- Open3D==0.17.0 is not installed
   and not vendored; restates `RegistrationICP` and
   `RegistrationRANSACBasedOnCorrespondence` as the reference calls them

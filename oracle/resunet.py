@@ -2,7 +2,9 @@
 
 TEST INFRASTRUCTURE (see oracle/__init__.py).  **Parity unpinned** for the
 MinkowskiEngine part (see me_semantics.py); topology, channel tables and op
-order follow the reference exactly:
+order follow the reference exactly -- pinned by outputs of the reference's own
+model classes (tests/golden/make_golden_model.py -> resunet_model.npz,
+tests/test_oracle_model_golden.py):
 
 * topology / forward order      `model/resunet.py:419-649`
 * channel tables (ResUNetBN2C)  `model/resunet.py:662-665`

@@ -9,9 +9,10 @@ Imports `core/knn.py`, `core/metrics.py`, `core/loss.py`, `core/registration.py`
 from /root/reference unchanged (they run on CPU torch) and stores seeded
 input/output vectors as small .npz files next to this script.  The reference
 has no tests or golden vectors of its own, so these are
-the pins for the kNN / Procrustes / refinement stages.  The sparse-conv stack
-cannot be pinned this way (MinkowskiEngine is not importable) -- see
-oracle/__init__.py.
+the pins for the kNN / Procrustes / refinement stages.  MinkowskiEngine is not
+importable, so the sparse-conv arithmetic cannot be pinned this way (see
+oracle/__init__.py); the model classes built on it are, by
+make_golden_model.py next to this script.
 """
 import os
 import sys
