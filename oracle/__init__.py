@@ -26,6 +26,11 @@ Parity status (see DESIGN.md "Oracle"):
   own `ResUNetBN2C` classes over a stand-in for the ME import
   (`tests/golden/me_stub`) and `tests/test_oracle_model_golden.py` holds
   `oracle.resunet` to the committed outputs.
+* `oracle.pipeline`: the learned branch of `register()` is **pinned** by a
+  run of the reference's own `DeepGlobalRegistration.register()` over the same
+  stand-in (`tests/golden/make_golden_register.py`,
+  `tests/test_oracle_register_golden.py`); the safeguard / ICP tail goes
+  through `oracle.open3d_reg` (unpinned, below).
 * `oracle.open3d_reg`: **parity unpinned** -- Open3D==0.17.0 is not installed
   and not vendored; restates `RegistrationICP` and
   `RegistrationRANSACBasedOnCorrespondence` as the reference calls them

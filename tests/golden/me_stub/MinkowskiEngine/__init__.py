@@ -1,7 +1,8 @@
-"""A stand-in for the few MinkowskiEngine 0.5.4 names `model/resunet.py`, `model/residual_block.py` and
-`model/common.py` of the reference touch -- so that the reference's OWN model classes execute in this container
-(tests/golden/make_golden_model.py) and pin `oracle/resunet.py`'s restatement of their topology, op order and
-state-dict layout.  TEST INFRASTRUCTURE, imported by that generator only (never by the package, the oracle or a test).
+"""A stand-in for the few MinkowskiEngine 0.5.4 names `model/*.py` and `core/deep_global_registration.py` of the
+reference touch -- so that the reference's OWN model classes and its `register()` execute in this container
+(tests/golden/make_golden_model.py, make_golden_register.py) and pin the oracle's restatement of their topology, op
+order, state-dict layout and glue.  TEST INFRASTRUCTURE, imported by those generators only (never by the package, the
+oracle or a test).
 
 What it is NOT: MinkowskiEngine.  The arithmetic below restates ME's published semantics of a generalized sparse
 convolution in the plainest form available -- Python dictionaries from coordinate tuples to rows, one matrix product
@@ -14,6 +15,7 @@ two are independent implementations of one reading of ME; whether that reading i
   output coordinate, kernel index with the first spatial axis fastest;
 * a transposed convolution writes onto the existing coordinate set of the finer stride through the forward map
   swapped (in = coarse row, out = fine row, same kernel index);
+* `utils.sparse_quantize` keeps the FIRST point of every voxel, voxels in the order of their first points;
 * parameters: `kernel` [K, Cin, Cout] ([Cin, Cout] when K = 1), `bias` [1, Cout]; `MinkowskiBatchNorm.bn` is a
   `torch.nn.BatchNorm1d` on the feature matrix.
 """
@@ -213,4 +215,4 @@ class MinkowskiELU(nn.Module):
         return x._like(torch.nn.functional.elu(x.F))
 
 
-from . import MinkowskiFunctional  # noqa: E402,F401
+from . import MinkowskiFunctional, utils  # noqa: E402,F401

@@ -140,3 +140,29 @@ def test_register_learned_branch_matches_oracle(ck):
           f'{np.abs(T_reg - o["T_before_icp"]).max():.1e}, after ICP {dT:.1e} (ICP iterations {dgr.last_icp["iterations"]} / {o["icp"]["iterations"]})')
     assert dT <= 1e-4, dT
     assert rot_angle_deg(T[:3, :3], T_gt[:3, :3]) < 2.0 and np.linalg.norm(T[:3, 3] - T_gt[:3, 3]) < 0.1
+
+
+def test_register_equals_the_reference_run():
+    """No oracle and no harness here: `register()` of the HIP path against the committed run of the REFERENCE's own
+    `register()` (tests/golden/make_golden_register.py: core/deep_global_registration.py imported from /root/reference
+    over stand-ins for its MinkowskiEngine / Open3D imports; learned branch, `use_icp = False`) on the same raw points
+    and the same seeded checkpoint -- matches exact, logits 1e-4, T 1e-4 (or, should the free-running refinement stop
+    elsewhere, the band of tests/helpers.assert_refine_parity)."""
+    from test_oracle_register_golden import golden_case
+    g, ck = golden_case()
+    dgr = _dgr(ck, clip_weight_thresh=float(g['clip_weight_thresh']))
+    dgr.use_icp = False
+    T = dgr.register(g['xyz0'], g['xyz1'])
+    assert dgr.last_status == 'ok' and T.dtype == np.float64
+    idx1 = dgr.last_corres_idx1.cpu().numpy().reshape(-1)
+    assert np.array_equal(idx1, g['idx1'].reshape(-1)), int((idx1 != g['idx1'].reshape(-1)).sum())
+    dl = np.abs(dgr.last_logit.cpu().numpy().reshape(-1) - g['logit'].reshape(-1)).max() / np.abs(g['logit']).max()
+    dT = float(np.abs(T - g['T']).max())
+    print(f'HIP register() vs the reference run: N0={len(idx1)}, matches equal, dlogit {dl:.1e}, max|T - T_reference| {dT:.1e}, '
+          f'refinement iterations {dgr.last_stats["iterations"]}')
+    assert dl < 1e-4, dl
+    if dT > 1e-4:
+        w = 1 / (1 + np.exp(-g['logit'].reshape(-1).astype(np.float64)))
+        w[w < float(g['clip_weight_thresh'])] = 0
+        assert_refine_parity(g['p0'], g['p1'][idx1], w.astype(np.float32), T[:3, :3], T[:3, 3], dict(dgr.last_stats),
+                             break_threshold_ratio=1e-4, quantization_size=2 * float(g['voxel']))
