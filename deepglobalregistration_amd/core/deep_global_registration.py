@@ -52,6 +52,7 @@ class DeepGlobalRegistration:
         self.harness_logits = None
         self.last_corres_idx1 = None
         self.last_logit = None
+        self.last_wsum = None
         self.feat_timer = Timer()
         self.reg_timer = Timer()
         self.last_status = None
@@ -84,6 +85,10 @@ class DeepGlobalRegistration:
         self.fcgf_model = FCGFModel(1, n_out, bn_momentum=_cfg_get(network_config, 'bn_momentum', 0.05),
                                     conv1_kernel_size=ks,
                                     normalize_feature=_cfg_get(network_config, 'normalize_feature'))
+        # optional runtime keys: the MinkowskiEngine conventions the checkpoint was written under (model/me_conventions.py)
+        me_conv = {'kernel_order': _cfg_get(config, 'me_kernel_order', 'first_axis_fastest'),
+                   'transposed_mirrored': bool(_cfg_get(config, 'me_transposed_mirrored', False))}
+        self.fcgf_model.me_conventions = dict(me_conv)
         self.fcgf_model.load_state_dict(state['state_dict'])
         self.fcgf_model = self.fcgf_model.to(self.device).eval()
 
@@ -95,6 +100,7 @@ class DeepGlobalRegistration:
         self.inlier_model = InlierModel(num_feats, 1, bn_momentum=_cfg_get(network_config, 'bn_momentum', 0.05),
                                         conv1_kernel_size=_cfg_get(network_config, 'inlier_conv1_kernel_size'),
                                         normalize_feature=False, D=6)
+        self.inlier_model.me_conventions = dict(me_conv)
         self.inlier_model.load_state_dict(state['state_dict_inlier'])
         self.inlier_model = self.inlier_model.to(self.device).eval()
         self.nn_max_n = _cfg_get(network_config, 'nn_max_n', 250)
@@ -190,6 +196,7 @@ class DeepGlobalRegistration:
         weights, wsum = ops.sigmoid_clip_sum(logit, self.clip_weight_thresh)
 
         wsum_threshold = max(200, len(weights) * 0.05)
+        self.last_wsum = (float(wsum), float(wsum_threshold))     # the reference prints these (:279-281)
         T = np.identity(4)
         safeguard = wsum < wsum_threshold
         if not safeguard:

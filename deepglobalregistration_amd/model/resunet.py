@@ -6,6 +6,7 @@ import torch
 
 from .. import ops
 from ..sparse import SparseTensor
+from . import me_conventions
 
 
 class ResUNet2:
@@ -28,11 +29,16 @@ class ResUNet2:
         self._state = None
         self._net = None
         self.training = True
+        # how the CHECKPOINT enumerates kernel offsets / pairs them in transposed convs (me_conventions.py; the default
+        # is the library's own reading of MinkowskiEngine 0.5.4); set before load_state_dict
+        self.me_conventions = dict(me_conventions.DEFAULT)
 
     # --- torch.nn.Module-like surface used by core/deep_global_registration.py:114-131 -------
     def load_state_dict(self, state_dict, strict=True):
         self._state = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v))
                        for k, v in state_dict.items()}
+        self._state = me_conventions.convert_state_dict(self._state, self.D, self.me_conventions['kernel_order'],
+                                                        self.me_conventions['transposed_mirrored'])
         self._net = None
         return self
 

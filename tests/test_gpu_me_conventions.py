@@ -1,0 +1,30 @@
+"""Runtime keys `me_kernel_order` / `me_transposed_mirrored` (model/me_conventions.py) through the product class: a
+checkpoint stated to be in another MinkowskiEngine convention registers exactly like its host-converted copy under
+the default reading, and not like the unconverted one."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_stated_convention_equals_converted_checkpoint():
+    from deepglobalregistration_amd import synth
+    from deepglobalregistration_amd.core.deep_global_registration import DeepGlobalRegistration
+    from deepglobalregistration_amd.model import me_conventions as mc
+    ck = synth.synth_checkpoint(seed=5, voxel_size=0.05, feat_conv1_kernel_size=5)
+    x0, x1, _ = synth.synth_pair(9, n_raw=4000)
+
+    def run(ckpt, **keys):
+        dgr = DeepGlobalRegistration(dict({'weights': ckpt, 'use_icp': False, 'clip_weight_thresh': 0.0}, **keys), torch.device('cuda'))
+        T = dgr.register(x0, x1)
+        return T, dgr.last_logit.cpu().numpy().copy(), dgr.last_corres_idx1.cpu().numpy().copy(), dgr.last_wsum
+
+    T_a, logit_a, idx_a, wsum_a = run(ck, me_kernel_order='last_axis_fastest', me_transposed_mirrored=True)
+    conv = dict(ck, state_dict=mc.convert_state_dict(ck['state_dict'], 3, 'last_axis_fastest', True),
+                state_dict_inlier=mc.convert_state_dict(ck['state_dict_inlier'], 6, 'last_axis_fastest', True))
+    T_b, logit_b, idx_b, wsum_b = run(conv)
+    assert np.array_equal(idx_a, idx_b) and np.array_equal(logit_a, logit_b) and np.array_equal(T_a, T_b) and wsum_a == wsum_b
+    T_c, logit_c, idx_c, _ = run(ck)                       # the default reading of the same file: another network
+    assert (idx_a != idx_c).mean() > 0.5
+    assert wsum_a[1] == max(200, 0.05 * len(idx_a))
