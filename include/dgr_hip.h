@@ -76,7 +76,12 @@ int dgr_voxelize(dgr_ctx *ctx, const void *xyz, int is_f64, int64_t M, double vo
  * class at model/resunet.py:419-665).  Tensors are HOST float32 arrays in MinkowskiEngine
  * state_dict layout ("conv1.kernel" [K,Cin,Cout], "norm1.bn.weight", ..., "final.bias");
  * the library folds eval-mode batch norm into the kernels, re-tiles them for the MFMA
- * B-operand and copies them to HBM; the caller may free its arrays afterwards. */
+ * B-operand and copies them to HBM; the caller may free its arrays afterwards.
+ * Offset axis of a kernel: index j = sum_d (delta_d + ks/2) ks^d, FIRST spatial axis fastest; a transposed
+ * convolution (conv4_tr / conv3_tr / conv2_tr) pairs index and offset like the forward strided map it swaps -- the
+ * library's reading of MinkowskiEngine 0.5.4 (unverifiable offline).  A checkpoint in another convention is
+ * re-indexed by the caller before this call: deepglobalregistration_amd/model/me_conventions.py does it for the
+ * Python host, tools/check_me_conventions.py tells the readings apart on a real pair. */
 typedef struct {
   const char *name;
   const float *data; /* host */
