@@ -45,7 +45,10 @@ def main():
     print('rows', len(coords), [len(p) for p in parts], flush=True)
     net = ops.NetHandle(synth.synth_state_dict(3, 1, 32, 7, 0), 3, 1, 32, 7, True)
     res, base = {}, None
+    only = sys.argv[2].split(',') if len(sys.argv) > 2 else None     # (optional: a subset of the orders, for A/B runs of library builds)
     for name, perm in orders(coords, rng).items():
+        if only and name not in only:
+            continue
         c = torch.from_numpy(np.ascontiguousarray(coords[perm])).cuda()
         f = torch.ones(len(c), 1, device='cuda')
         for _ in range(3):
