@@ -28,9 +28,9 @@
 //   * input rows carry their largest |x| (bits, written by their producer's epilogue: out_amax below and in
 //     conv_os.hip / conv.hip) -- the row's power-of-two scale is dgr_row_scale_of of it; no separate scale pass.
 //
-// What bounds it (tools/ab_fcgf.py ablations on the 195 k-row 64 -> 64 layers, 203 us; round 3): no gather 113, no
-// MFMA 215, no split 183, no weight staging 166, gather only 152 -- gathering 2.4 M random 256-byte rows out of a 50-MB
-// tensor, at the rate of the memory system for random rows beyond the 4-MB L2 of an XCD (3.6 - 5.2 TB/s, vmem_bw).
+// What bounds it (the round-3 reading "the gather rate of random rows" was wrong): row order
+// and occupancy change nothing; the loop runs at the pace of its LDS traffic -- every wave re-reads the offset's 16 KB of
+// staged weights, plus the ds_bpermutes -- and of the barrier per offset (branch dense-ring: weights from L2, +10 %).
 //
 // Weight layout: the split pieces of conv_os.hip, WB[piece][k][s][jb][lane] = 8 halves =
 // W_folded[k][32 s + 8 (lane >> 4) + e][16 jb + (lane & 15)] (net.hip).
