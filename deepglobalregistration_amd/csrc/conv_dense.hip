@@ -17,8 +17,8 @@
 //     list-based kernel keeps 8 - 16 % busy, in exchange for its three dependent LDS look-ups per slot, its LDS
 //     read-modify-write accumulation and its per-group weight re-loads (32 KB of weight fragments per 8 KB of
 //     gathered rows through the CU's vector-memory path);
-//   * the offset's weights (both pieces, <= 16 KB) are staged ONCE per workgroup and offset in LDS (double-buffered,
-//     one barrier per offset) and read by every wave as MFMA A operands: each 16-byte fragment serves RG row groups;
+//   * the offset's weights (both pieces, <= 16 KB) stream from L2 through a register ring per wave, in this kernel's
+//     operand order (pre-permuted at load time, net.hip): no LDS stage, no barrier in the offset loop;
 //   * accumulators stay in registers for the whole layer: per offset a zero-initialised tile `tmp`, folded as
 //     total += tmp * 2^-e(row, k) / weight scale -- the same two roundings per (row, offset) as conv_os.hip, in the
 //     same ascending-k order on top of shift + residual.  Results do not depend on scheduling; they agree with the
@@ -28,12 +28,13 @@
 //   * input rows carry their largest |x| (bits, written by their producer's epilogue: out_amax below and in
 //     conv_os.hip / conv.hip) -- the row's power-of-two scale is dgr_row_scale_of of it; no separate scale pass.
 //
-// What bounds it (the round-3 reading "the gather rate of random rows" was wrong): row order
-// and occupancy change nothing; the loop runs at the pace of its LDS traffic -- every wave re-reads the offset's 16 KB of
-// staged weights, plus the ds_bpermutes -- and of the barrier per offset (branch dense-ring: weights from L2, +10 %).
+// What bounded it until round 4 (the round-3 reading "the gather rate of random rows" was
+// wrong: row order and occupancy change nothing): the LDS traffic of the loop -- every wave re-read the offset's 16 KB of
+// staged weights -- and the barrier per offset.  Now the weights stream from L2 per wave (below): +10 %, the same bits.
 //
 // Weight layout: the split pieces of conv_os.hip, WB[piece][k][s][jb][lane] = 8 halves =
-// W_folded[k][32 s + 8 (lane >> 4) + e][16 jb + (lane & 15)] (net.hip).
+// W_folded[k][32 s + 8 (lane >> 4) + e][16 jb + (lane & 15)], re-ordered per fragment group for the gather's channel
+// order: lane (col, lq) holds half (lq & 1) of the natural fragments of lanes (col, lq >> 1) and (col, (lq >> 1) + 2) (net.hip).
 #include "dgr_internal.h"
 #include "split.h"
 
