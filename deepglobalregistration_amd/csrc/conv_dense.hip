@@ -17,8 +17,8 @@
 //     list-based kernel keeps 8 - 16 % busy, in exchange for its three dependent LDS look-ups per slot, its LDS
 //     read-modify-write accumulation and its per-group weight re-loads (32 KB of weight fragments per 8 KB of
 //     gathered rows through the CU's vector-memory path);
-//   * the offset's weights (both pieces, <= 16 KB) are staged ONCE per workgroup and offset in LDS (double-buffered,
-//     one barrier per offset) and read by every wave as MFMA A operands: each 16-byte fragment serves RG row groups;
+//   * the offset's weights (both pieces, <= 16 KB) stream from L2 through a register ring per wave, in this kernel's
+//     operand order (pre-permuted at load time, net.hip): no LDS stage, no barrier in the offset loop;
 //   * accumulators stay in registers for the whole layer: per offset a zero-initialised tile `tmp`, folded as
 //     total += tmp * 2^-e(row, k) / weight scale -- the same two roundings per (row, offset) as conv_os.hip, in the
 //     same ascending-k order on top of shift + residual.  Results do not depend on scheduling; they agree with the
@@ -28,12 +28,13 @@
 //   * input rows carry their largest |x| (bits, written by their producer's epilogue: out_amax below and in
 //     conv_os.hip / conv.hip) -- the row's power-of-two scale is dgr_row_scale_of of it; no separate scale pass.
 //
-// What bounds it (the round-3 reading "the gather rate of random rows" was wrong): row order
-// and occupancy change nothing; the loop runs at the pace of its LDS traffic -- every wave re-reads the offset's 16 KB of
-// staged weights, plus the ds_bpermutes -- and of the barrier per offset (branch dense-ring: weights from L2, +10 %).
+// What bounded it until round 4 (the round-3 reading "the gather rate of random rows" was
+// wrong: row order and occupancy change nothing): the LDS traffic of the loop -- every wave re-read the offset's 16 KB of
+// staged weights -- and the barrier per offset.  Now the weights stream from L2 per wave (below): +10 %, the same bits.
 //
 // Weight layout: the split pieces of conv_os.hip, WB[piece][k][s][jb][lane] = 8 halves =
-// W_folded[k][32 s + 8 (lane >> 4) + e][16 jb + (lane & 15)] (net.hip).
+// W_folded[k][32 s + 8 (lane >> 4) + e][16 jb + (lane & 15)], re-ordered per fragment group for the gather's channel
+// order: lane (col, lq) holds half (lq & 1) of the natural fragments of lanes (col, lq >> 1) and (col, (lq >> 1) + 2) (net.hip).
 #include "dgr_internal.h"
 #include "split.h"
 
@@ -67,11 +68,9 @@ __global__ void __launch_bounds__(64 * WAVES, 2) sparse_conv_dense_f16x2(ConvDen
   constexpr int S = CIN / 32, NCB = COUT / 16;
   constexpr int THREADS = 64 * WAVES;
   constexpr int MB = WAVES * RG * 16;            // output rows per workgroup
-  constexpr int WP = S * NCB * 64;               // 16-byte units per piece and offset
-  constexpr int WU = 2 * WP;                     // ... per offset
-  constexpr int WPT = (WU + THREADS - 1) / THREADS;
-  static_assert(WU % THREADS == 0 || WU < THREADS, "weight staging shape");
-  __shared__ u32x4 wlds[2][WU];
+  constexpr int NST = S * NCB;                   // (32-channel step, 16-column block) steps per offset
+  constexpr int WD = NST >= 8 ? 8 : NST >= 4 ? 4 : 2;   // weight ring: the fragments of WD steps in flight per wave
+  static_assert(NST % WD == 0, "the weight ring turns a whole number of times per offset (static register indexing)");
   __shared__ int nbr_s[KV][MB];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -85,33 +84,18 @@ __global__ void __launch_bounds__(64 * WAVES, 2) sparse_conv_dense_f16x2(ConvDen
   if (j >= per || blk >= nblocks) return;
   const int64_t row0 = (int64_t)blk * MB;
 
-  // the offset's weights: global -> registers (one offset ahead) -> LDS buffer (k & 1)
-  struct WRegs { u32x4 v[WPT]; };
-  auto wload = [&](int k, WRegs &w) {
-#pragma unroll
-    for (int u = 0; u < WPT; ++u) {
-      const int c = min(tid + u * THREADS, WU - 1);
-      const int p = c / WP, i = c - p * WP;
-      w.v[u] = a.wb[(int64_t)p * a.piece_stride + (int64_t)k * WP + i];
-    }
+  // the offset's weights never touch LDS: every wave streams the fragments of its (offset, 32-channel step, 16-column
+  // block) sequence -- contiguous in memory, pre-permuted at load time into this kernel's operand order (net.hip) --
+  // through a register ring WD steps deep.  (Staged per workgroup and offset in LDS, as until round 4, they cost a
+  // barrier per offset and two thirds of the kernel's LDS reads, and those reads, not the MFMAs, bounded it:
+  // DESIGN.md section 8.)
+  u32x4 rh[WD], rm[WD];
+  const u32x4 *wph = a.wb + lane, *wpm = a.wb + a.piece_stride + lane;
+  auto wreq = [&](int g, int i) {
+    const int gg = min(g, KV * NST - 1);
+    rh[i] = wph[(int64_t)gg * 64];
+    rm[i] = wpm[(int64_t)gg * 64];
   };
-  auto wstore = [&](int buf, const WRegs &w) {
-#pragma unroll
-    for (int u = 0; u < WPT; ++u) {
-      const int c = tid + u * THREADS;
-      if (WU % THREADS == 0 || c < WU) {
-        // fragment c = (piece, s, cb, lane' = (col, lq')) holds channels 8 lq' + (0..7) of its 32-channel step; the
-        // gather below hands lane (col, lq) the channels 4 lq + (0..3) and 16 + 4 lq + (0..3): each 8-byte half u goes
-        // to lane (col, 2 (lq' & 1) + u), first or second half by lq' >> 1
-        const int ln = c & 63, col = ln & 15, lqs = ln >> 4;
-        u32x2 *dst = reinterpret_cast<u32x2 *>(&wlds[buf][(c & ~63) + col]);
-        dst[(16 * (2 * (lqs & 1) + 0)) * 2 + (lqs >> 1)] = u32x2{w.v[u].x, w.v[u].y};
-        dst[(16 * (2 * (lqs & 1) + 1)) * 2 + (lqs >> 1)] = u32x2{w.v[u].z, w.v[u].w};
-      }
-    }
-  };
-  WRegs wr;
-  wload(0, wr);
   for (int e = tid; e < KV * MB; e += THREADS) {
     const int k = e / MB, r = e - k * MB;
     nbr_s[k][r] = (row0 + r < n_out) ? a.nbr[(int64_t)k * a.n_pad + row0 + r] : -1;
@@ -136,8 +120,6 @@ __global__ void __launch_bounds__(64 * WAVES, 2) sparse_conv_dense_f16x2(ConvDen
     }
   }
   __syncthreads();
-  wstore(0, wr);
-  wload(1, wr);
 
   // gathered rows of the NEXT offset: requested here, consumed (split into pieces) at the top of the next iteration
   const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in), 0, a.in_bytes, 0x00020000);
@@ -176,8 +158,9 @@ __global__ void __launch_bounds__(64 * WAVES, 2) sparse_conv_dense_f16x2(ConvDen
   RowSet gA, gB;
   gather(0, gA);
   if (DEPTH == 2) gather(1, gB);
+#pragma unroll
+  for (int i = 0; i < WD; ++i) wreq(i, i);
   const int relu_lo = a.in_relu ? 0 : (int)0x80000000;   // pending ReLU of the producer as one integer max per value
-  __syncthreads();
 
   auto body = [&](int k, RowSet &g) {
     // ---- operands of this offset: s x = h + m, two f16 pieces (dgr_split2), in MFMA B layout
@@ -217,12 +200,8 @@ __global__ void __launch_bounds__(64 * WAVES, 2) sparse_conv_dense_f16x2(ConvDen
     __builtin_amdgcn_sched_barrier(0);   // operands complete before the raw registers are re-requested (else the scheduler
                                          // keeps both generations alive and a register-pair false dependency makes the
                                          // conversions wait for the NEW requests)
-    // ---- next offset: weights into the other LDS buffer (its readers finished before the last barrier), rows and
-    //      the offset after next's weights requested; everything arrives during this offset's MFMAs
-    // (the weights are requested BEFORE the rows: the memory counter is in order, and the next wstore must not have to
-    // wait for row requests that are younger than its weights)
-    wstore((k + 1) & 1, wr);   // (after the last offset: into the buffer nobody reads any more)
-    wload(min(k + 2, KV - 1), wr);
+    // ---- next offset's rows requested; they arrive during this offset's MFMAs (the weight ring is refilled step by
+    //      step below: in the in-order memory counter every ring slot is older than the rows requested after it)
     gather(min(k + DEPTH, KV - 1), g);   // refills the set just consumed
     __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks these requests below the MFMAs: no time in flight)
     // ---- this offset's tile: tmp = W[k]^T x (zero for missing neighbours)
@@ -231,26 +210,23 @@ __global__ void __launch_bounds__(64 * WAVES, 2) sparse_conv_dense_f16x2(ConvDen
     for (int rg = 0; rg < RG; ++rg)
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) tmp[rg][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const u32x4 *wl = wlds[k & 1];
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
+    for (int j = 0; j < NST; ++j) {
+      const int s = j / NCB, cb = j % NCB;
+      const f16x8 wh = __builtin_bit_cast(f16x8, rh[j % WD]);
+      const f16x8 wm = __builtin_bit_cast(f16x8, rm[j % WD]);
 #pragma unroll
-      for (int cb = 0; cb < NCB; ++cb) {
-        const f16x8 wh = __builtin_bit_cast(f16x8, wl[(s * NCB + cb) * 64 + lane]);
-        const f16x8 wm = __builtin_bit_cast(f16x8, wl[WP + (s * NCB + cb) * 64 + lane]);
-#pragma unroll
-        for (int rg = 0; rg < RG; ++rg) {
-          tmp[rg][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm, bh[rg][s], tmp[rg][cb], 0, 0, 0);
-          tmp[rg][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bm[rg][s], tmp[rg][cb], 0, 0, 0);
-          tmp[rg][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bh[rg][s], tmp[rg][cb], 0, 0, 0);
-        }
+      for (int rg = 0; rg < RG; ++rg) {
+        tmp[rg][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm, bh[rg][s], tmp[rg][cb], 0, 0, 0);
+        tmp[rg][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bm[rg][s], tmp[rg][cb], 0, 0, 0);
+        tmp[rg][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bh[rg][s], tmp[rg][cb], 0, 0, 0);
       }
+      wreq(k * NST + j + WD, j % WD);   // the ring slot just consumed
     }
 #pragma unroll
     for (int rg = 0; rg < RG; ++rg)
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) total[rg][cb] += tmp[rg][cb] * fold[rg];
-    __syncthreads();   // buffer k & 1 is free again; buffer (k + 1) & 1 is complete
   };
   if (DEPTH == 1) {
 #pragma unroll 1
@@ -311,12 +287,12 @@ static int launch_dense(const ConvDenseArgs &ka, int64_t n_out_cap, hipStream_t 
 int dgr_conv_dense_launch(const DgrConvOsLaunch &a, hipStream_t stream, const char **kernel_name) {
   DGR_REQUIRE(a.nbr && a.nbr->built && a.nbr->K == 27, "dense-tile conv: no neighbour table");
   DGR_REQUIRE(dgr_conv_dense_supported(a.cin, a.cin_pad, a.cout), "dense-tile conv: Cin = %d, Cout = %d not built", a.cin, a.cout);
-  DGR_REQUIRE(a.wb3 && a.row_amax, "dense-tile conv: needs the split weights and the input rows' maxima");
+  DGR_REQUIRE(a.wbd && a.row_amax, "dense-tile conv: needs the split weights in its operand order and the input rows' maxima");
   DGR_REQUIRE((a.in_ld & 3) == 0 && (a.out_ld & 3) == 0 && (a.res == nullptr || (a.res_ld & 3) == 0),
               "dense-tile conv: row strides must be multiples of 4");
   ConvDenseArgs ka;
   ka.in = a.in; ka.out = a.out; ka.shift = a.shift; ka.res = a.res;
-  ka.wb = static_cast<const u32x4 *>(a.wb3); ka.piece_stride = a.piece_stride;
+  ka.wb = static_cast<const u32x4 *>(a.wbd); ka.piece_stride = a.piece_stride;
   ka.nbr = a.nbr->nbr; ka.n_out_dev = a.n_out_dev; ka.n_pad = a.nbr->n_pad;
   ka.in_ld = a.in_ld; ka.in_relu = a.in_relu; ka.out_ld = a.out_ld; ka.out_relu = a.out_relu;
   ka.res_ld = a.res_ld; ka.res_relu = a.res_relu;

@@ -227,6 +227,7 @@ struct DgrConvOsLaunch {
   float *out; int out_ld, out_relu;
   const float *w16, *shift;
   const void *wb3; int64_t piece_stride;   // split weights: two f16 pieces (16-byte units per piece), or null
+  const void *wbd = nullptr;               // ... and in the dense-tile kernel's operand order (same piece stride), or null
   // ... with, per input row, the bits of its largest |x| after the pending ReLU (the row's power-of-two scale is
   // dgr_row_scale_of of it; written by the row's PRODUCER, see out_amax) and the layer's inverse weight scale
   const uint32_t *row_amax = nullptr; float w_unscale = 1.f;

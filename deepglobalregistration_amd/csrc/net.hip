@@ -30,6 +30,7 @@ struct DgrLayer {
   float *w = nullptr;      // device, tiled
   float *w16 = nullptr;    // device, 16x16x4 fragment order (3-D K = 27 layers: output-stationary conv, conv_os.hip)
   void *w16b = nullptr;    // device, the same as two f16 pieces in 16x16x32 fragment order (conv_os.hip)
+  void *w16d = nullptr;    // device, the pieces once more in the channel order of the dense-tile kernel's gather (conv_dense.hip)
   int64_t w16b_piece = 0;
   float *wc = nullptr;     // device, conv1 weights in the operand order of conv1_grid_mfma (3-D conv1 with one input channel)
   void *wb = nullptr;      // device, two f16 pieces in 32x32x16 fragment order (wide layers, conv_wide.hip)
@@ -232,6 +233,23 @@ static int make_layer(dgr_net *net, const dgr_weight_desc *descs, int nd, const 
       DGR_HIP_CHECK(hipMalloc(&L.w16b, pcs.size() * sizeof(uint16_t)));
       DGR_HIP_CHECK(hipMemcpy(L.w16b, pcs.data(), pcs.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
       net->param_bytes += pcs.size() * sizeof(uint16_t);
+      if (net->D == 3 && K == 27 && dgr_conv_dense_supported(cin, L.cin_pad, cout)) {
+        // conv_dense.hip reads its weight operands straight from memory: the quad-coalesced gather hands lane (col, lq)
+        // the channels 4 lq .. + 3 and 16 + 4 lq .. + 3 of a 32-channel step, so its 16-byte operand is half (lq & 1) of the
+        // natural fragments of lanes (col, lq >> 1) and (col, (lq >> 1) + 2)
+        std::vector<uint16_t> pd(pcs.size());
+        for (size_t f = 0; f < pcs.size() / 8; ++f) {
+          const size_t base = f & ~(size_t)63;
+          const int lane = (int)(f & 63), col = lane & 15, lq = lane >> 4;
+          for (int h = 0; h < 2; ++h) {
+            const size_t srcf = base + col + 16 * ((lq >> 1) + 2 * h);
+            for (int e = 0; e < 4; ++e) pd[f * 8 + 4 * h + e] = pcs[srcf * 8 + 4 * (lq & 1) + e];
+          }
+        }
+        DGR_HIP_CHECK(hipMalloc(&L.w16d, pd.size() * sizeof(uint16_t)));
+        DGR_HIP_CHECK(hipMemcpy(L.w16d, pd.data(), pd.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        net->param_bytes += pd.size() * sizeof(uint16_t);
+      }
     }
   }
   if (net->D == 3 && name == "conv1" && cin == 1 && cout == 32 && K <= 343) {
@@ -311,6 +329,7 @@ extern "C" void dgr_net_destroy(dgr_net *net) {
     if (l.wb) (void)hipFree(l.wb);
     if (l.wc) (void)hipFree(l.wc);
     if (l.w16b) (void)hipFree(l.w16b);
+    if (l.w16d) (void)hipFree(l.w16d);
     if (l.shift) (void)hipFree(l.shift);
   }
   delete net;
@@ -395,6 +414,7 @@ struct Fwd {
       o.rows_per_block = lvl_out <= 1 ? 64 : lvl_out == 2 ? 32 : 16;
       o.w16 = L.w16; o.shift = L.shift;
       o.wb3 = L.w16b; o.piece_stride = L.w16b_piece;
+      o.wbd = L.w16d;
       o.w_unscale = L.w_unscale; o.n_in_cap = cin_map.n_cap;
       static const bool os_f32 = getenv("DGR_EXACT_F32") != nullptr;   // (conv_os.hip reads the same switch)
       if (L.w16b && !os_f32) {
@@ -415,7 +435,7 @@ struct Fwd {
       bool same_stride = false;
       for (int l = 0; l < 4; ++l) same_stride = same_stride || t == &ms.nsame[l];
       // (its buffer loads address the input with 32-bit byte offsets: tensors of 2 GB and more stay on the list kernel)
-      o.dense = same_stride && o.row_amax && !os_lists && dgr_conv_dense_supported(L.cin, L.cin_pad, L.cout) &&
+      o.dense = same_stride && o.row_amax && o.wbd && !os_lists && dgr_conv_dense_supported(L.cin, L.cin_pad, L.cout) &&
                 cin_map.n_cap * (int64_t)in.ld * 4 < (1ll << 31);
       const char *kname = "sparse_conv_os";
       DGR_CHECK(dgr_conv_os_launch(o, stream, &kname));
