@@ -1,10 +1,15 @@
 """CPU restatement of the two Open3D registration routines behind the reference's safeguard and ICP.
 
-TEST INFRASTRUCTURE (see oracle/__init__.py).  **Parity unpinned**: Open3D (requirements.txt pins
+TEST INFRASTRUCTURE (see oracle/__init__.py).  **Arithmetic unpinned against Open3D**: Open3D (requirements.txt pins
 open3d==0.17.0) is not installed in this image and its source is not under /root/reference, so the
 functions below restate the published algorithm of Open3D 0.17.0
-(cpp/open3d/pipelines/registration/Registration.cpp and TransformationEstimation.cpp) and are anchored
-on the reference's call sites only:
+(cpp/open3d/pipelines/registration/Registration.cpp and TransformationEstimation.cpp).  What IS pinned, by the
+reference's own code: the call sites -- tests/golden/make_golden_register.py runs
+core/deep_global_registration.py:50-64, 302-322 unchanged over a stand-in `open3d` module with Open3D 0.17's
+signatures that records every argument (source / target order, correspondences, 2 * voxel, rigid point-to-point,
+ransac_n = 4, criteria (4000000, 80000 -> confidence 1.0), ICP from T with Open3D's defaults) and computes with the
+functions below (tests/golden/register_e2e_o3d.npz, tests/test_oracle_register_golden.py).  The functions and the
+reference call they stand for:
 
 * `icp_point_to_point`        <- `o3d.pipelines.registration.registration_icp(source, target,
                                  max_correspondence_distance=2*voxel, init=T)` at

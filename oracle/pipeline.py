@@ -3,9 +3,12 @@
 TEST INFRASTRUCTURE (see oracle/__init__.py).  Follows `core/deep_global_registration.py:134-217,238-324`
 stage by stage, including the two Open3D steps: the safeguard RANSAC over the putative correspondences
 (`:50-64, 302-315`) and the final point-to-point ICP (`:317-322`), both through `oracle/open3d_reg.py`
-(restated Open3D 0.17 algorithms -- parity unpinned, see that module).  The learned branch without ICP is pinned by a
-run of the reference's own `register()` (tests/golden/make_golden_register.py -> register_e2e.npz,
-tests/test_oracle_register_golden.py: intermediates exact / 1.5e-6, T 3e-7, bitwise given the same logits).
+(restated Open3D 0.17 algorithms -- their ARITHMETIC is unpinned against Open3D, see that module).  The whole function is
+pinned by runs of the reference's own `register()` (tests/golden/make_golden_register.py): the learned branch without
+ICP (register_e2e.npz: intermediates exact / 1.5e-6, T 3e-7, bitwise given the same logits), and -- through the
+functional Open3D stand-in that records what the reference's lines pass -- learned + ICP and gate-fails -> safeguard
+RANSAC -> ICP (register_e2e_o3d.npz; tests/test_oracle_register_golden.py: the recorded arguments are the ones
+restated below, T bitwise given the same matches / logits).
 """
 import numpy as np
 import torch

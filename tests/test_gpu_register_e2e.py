@@ -166,3 +166,44 @@ def test_register_equals_the_reference_run():
         w[w < float(g['clip_weight_thresh'])] = 0
         assert_refine_parity(g['p0'], g['p1'][idx1], w.astype(np.float32), T[:3, :3], T[:3, 3], dict(dgr.last_stats),
                              break_threshold_ratio=1e-4, quantization_size=2 * float(g['voxel']))
+
+
+def test_register_with_icp_equals_the_reference_run():
+    """`register()` as shipped (`use_icp = True`, the reference's default) against the reference's own run through its
+    ICP call site (:317-322; tests/golden/register_e2e_o3d.npz case `icp`)."""
+    from test_oracle_register_golden import golden_case, golden_o3d
+    g, ck = golden_case()
+    o3 = golden_o3d()
+    dgr = _dgr(ck, clip_weight_thresh=float(g['clip_weight_thresh']))
+    assert dgr.use_icp
+    T = dgr.register(g['xyz0'], g['xyz1'])
+    assert dgr.last_status == 'ok' and T.dtype == np.float64
+    assert np.array_equal(dgr.last_corres_idx1.cpu().numpy().reshape(-1), g['idx1'].reshape(-1))
+    dT = float(np.abs(T - o3['icp_T']).max())
+    print(f'HIP register() + ICP vs the reference run: max|T - T_reference| {dT:.1e}, ICP iterations '
+          f'{dgr.last_icp["iterations"]} (reference {int(o3["icp_call_iterations"])})')
+    assert dT < 1e-4, dT
+
+
+def test_register_safeguard_equals_the_reference_run():
+    """Gate fails -> safeguard RANSAC -> ICP against the reference's own run through both Open3D call sites (:50-64,
+    302-322; case `safeguard` of register_e2e_o3d.npz): same matches, same winning hypothesis and consensus, T to 1e-6."""
+    from test_oracle_register_golden import golden_case, golden_o3d
+    g, ck = golden_case()
+    o3 = golden_o3d()
+    from deepglobalregistration_amd.core.deep_global_registration import DeepGlobalRegistration
+    dgr = DeepGlobalRegistration({'weights': ck, 'clip_weight_thresh': float(g['clip_weight_thresh']),
+                                  'ransac_max_iteration': int(o3['ransac_cap']), 'ransac_seed': int(o3['ransac_seed'])},
+                                 torch.device('cuda'))
+    T = dgr.register(o3['sg_xyz0'], o3['sg_xyz1'])
+    assert dgr.last_status == 'safeguard' and T.dtype == np.float64
+    assert np.array_equal(dgr.last_corres_idx1.cpu().numpy().reshape(-1), o3['sg_idx1'].reshape(-1))
+    dl = np.abs(dgr.last_logit.cpu().numpy().reshape(-1) - o3['sg_logit'].reshape(-1)).max() / np.abs(o3['sg_logit']).max()
+    assert dl < 1e-4, dl
+    assert dgr.last_stats['ransac_hypothesis'] == int(o3['sg_ransac_call_hypothesis'])
+    assert dgr.last_stats['ransac_inliers'] == int(o3['sg_ransac_call_inliers'])
+    assert dgr.last_icp['iterations'] == int(o3['sg_icp_call_iterations'])
+    dT = float(np.abs(T - o3['sg_T']).max())
+    print(f'HIP register() safeguard vs the reference run: hypothesis {dgr.last_stats["ransac_hypothesis"]}, '
+          f'{dgr.last_stats["ransac_inliers"]} inliers, max|T - T_reference| {dT:.1e}')
+    assert dT < 1e-6, dT

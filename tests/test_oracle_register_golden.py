@@ -48,3 +48,74 @@ def test_same_logits_same_bits():
     o = opipe.register(ck, g['xyz0'], g['xyz1'], clip_weight_thresh=float(g['clip_weight_thresh']), use_icp=False,
                        forced_logit_fn=lambda x0, x1, logit: g['logit'])
     assert np.array_equal(o['T'], g['T'])
+
+
+# ---- the Open3D call sites (core/deep_global_registration.py:50-64, 302-322), run by the reference's own lines --------
+GOLDEN_O3D = os.path.join(os.path.dirname(__file__), 'golden', 'register_e2e_o3d.npz')
+
+
+def golden_o3d():
+    return np.load(GOLDEN_O3D)
+
+
+def test_reference_passes_what_the_oracle_assumes():
+    """The arguments the reference's lines handed to Open3D (recorded by the stand-in during the golden run) are the ones
+    oracle/pipeline.py and the HIP `register()` hard-wire."""
+    g, o3 = np.load(GOLDEN), golden_o3d()
+    voxel = float(g['voxel'])
+    # safeguard (:50-64): source = cloud 0, target = cloud 1 (voxelised points, stored as doubles), correspondences
+    # (arange, idx1), 2 voxels, rigid point-to-point, 4-point hypotheses, no checkers, (4000000, 80000 -> confidence 1)
+    assert int(o3['sg_ransac_call_n_source']) == len(o3['sg_p0']) and int(o3['sg_ransac_call_n_target']) == len(o3['sg_p1'])
+    assert str(o3['sg_ransac_call_source_dtype']) == 'float64'
+    assert np.array_equal(o3['sg_ransac_call_corres'][:, 0], np.arange(len(o3['sg_p0'])))
+    assert np.array_equal(o3['sg_ransac_call_corres'][:, 1], o3['sg_idx1'].reshape(-1))
+    assert float(o3['sg_ransac_call_max_correspondence_distance']) == 2 * voxel
+    assert not bool(o3['sg_ransac_call_with_scaling']) and int(o3['sg_ransac_call_ransac_n']) == 4
+    assert int(o3['sg_ransac_call_n_checkers']) == 0
+    assert int(o3['sg_ransac_call_max_iteration']) == 4000000
+    assert float(o3['sg_ransac_call_confidence_given']) == 80000 and float(o3['sg_ransac_call_confidence']) == 1.0
+    # ICP (:317-322) after BOTH branches: source = voxelised cloud 0, target = cloud 1, 2 voxels, init = the branch's T,
+    # Open3D's defaults otherwise (point-to-point, 30 iterations, 1e-6 / 1e-6)
+    for c, p0, p1 in (('icp_call', g['p0'], g['p1']), ('sg_icp_call', o3['sg_p0'], o3['sg_p1'])):
+        assert int(o3[c + '_n_source']) == len(p0) and int(o3[c + '_n_target']) == len(p1)
+        assert np.array_equal(o3[c + '_source_head'], p0[:4].astype(np.float64))
+        assert np.array_equal(o3[c + '_target_head'], p1[:4].astype(np.float64))
+        assert float(o3[c + '_max_correspondence_distance']) == 2 * voxel
+        assert int(o3[c + '_max_iteration']) == 30
+        assert float(o3[c + '_relative_fitness']) == 1e-6 and float(o3[c + '_relative_rmse']) == 1e-6
+    assert np.array_equal(o3['icp_call_init'], g['T'])             # learned branch: ICP starts from the refined T
+
+
+def test_oracle_register_with_icp_equals_the_reference_run():
+    """Learned branch + ICP (the reference's default `use_icp = True`)."""
+    g, ck = golden_case()
+    o3 = golden_o3d()
+    o = opipe.register(ck, g['xyz0'], g['xyz1'], clip_weight_thresh=float(g['clip_weight_thresh']), use_icp=True)
+    assert o['status'] == 'ok'
+    assert o['icp']['iterations'] == int(o3['icp_call_iterations'])
+    dT = float(np.abs(o['T'] - o3['icp_T']).max())
+    print(f'learned + ICP: max |T - T_reference| = {dT:.2e} ({o["icp"]["iterations"]} ICP iterations)')
+    assert dT < 1e-5
+    # given the reference run's logits the whole register() is the reference's to the bit
+    o = opipe.register(ck, g['xyz0'], g['xyz1'], clip_weight_thresh=float(g['clip_weight_thresh']), use_icp=True,
+                       forced_logit_fn=lambda x0, x1, logit: g['logit'])
+    assert np.array_equal(o['T'], o3['icp_T'])
+
+
+def test_oracle_register_safeguard_equals_the_reference_run():
+    """Gate fails -> safeguard RANSAC -> ICP, the small pair of the golden run (236 voxels: the weight sum cannot reach
+    the gate's floor of 200)."""
+    g, ck = golden_case()
+    o3 = golden_o3d()
+    o = opipe.register(ck, o3['sg_xyz0'], o3['sg_xyz1'], clip_weight_thresh=float(g['clip_weight_thresh']), use_icp=True,
+                       ransac_hypotheses=int(o3['ransac_cap']), ransac_seed=int(o3['ransac_seed']))
+    assert o['status'] == 'safeguard' and not o['confident']
+    assert np.array_equal(o['xyz0'], o3['sg_p0']) and np.array_equal(o['coords1'], o3['sg_coords1'])
+    assert np.array_equal(o['idx1'], o3['sg_idx1'].reshape(-1))
+    assert rel(o['logit'].reshape(-1), o3['sg_logit'].reshape(-1)) < 5e-6
+    assert o['ransac']['hypothesis'] == int(o3['sg_ransac_call_hypothesis'])
+    assert o['ransac']['inliers'] == int(o3['sg_ransac_call_inliers'])
+    assert np.array_equal(o['T_before_icp'], o3['sg_icp_call_init'])     # ICP started from the RANSAC result
+    assert o['icp']['iterations'] == int(o3['sg_icp_call_iterations'])
+    assert np.array_equal(o['T'], o3['sg_T'])                            # same matches => same bits all the way
+    assert np.abs(o3['sg_T'] - o3['sg_T_gt']).max() < 2e-2               # and the branch found the planted pose
