@@ -58,6 +58,7 @@ SIGNATURES = {
     'dgr_maps_get_kernel_map': (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int64, vp, vp, C.c_int64,
                                           c_i64p, c_i64p]),
     'dgr_knn1_l2': (C.c_int, [vp, vp, C.c_int64, vp, C.c_int64, C.c_int, C.c_int, vp, vp, vp]),
+    'dgr_knn1_l2_batch': (C.c_int, [vp, vp, c_i64p, vp, c_i64p, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     'dgr_inlier_inputs': (C.c_int, [vp, vp, vp, C.c_int64, vp, vp, C.c_int64, vp, C.c_int, vp, vp, vp]),
     'dgr_sigmoid_clip_sum': (C.c_int, [vp, vp, C.c_int64, C.c_float, vp, c_f64p, vp]),
     'dgr_gather_rows3': (C.c_int, [vp, vp, vp, C.c_int64, vp, vp]),

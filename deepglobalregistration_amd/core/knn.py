@@ -25,16 +25,21 @@ def find_knn_gpu_batch(F0, F1, len_batch, nn_max_n=-1, knn=1, return_distance=Fa
     (dataloader/base_loader.py:63-81).  Returns per-pair lists, or -- with `concat_results` -- single
     tensors whose indices address rows of the concatenated F1."""
     import itertools
-    import torch
+    if knn != 1:
+        raise NotImplementedError('only knn=1 is implemented (the only value the DGR path uses)')
     sizes = [(int(a), int(b)) for a, b in len_batch]
     first0 = [0] + list(itertools.accumulate(n0 for n0, _ in sizes))
     first1 = [0] + list(itertools.accumulate(n1 for _, n1 in sizes))
-    results = [find_knn_gpu(F0[s0:s0 + n0], F1[s1:s1 + n1], nn_max_n=nn_max_n, knn=knn, return_distance=True)
-               for (n0, n1), s0, s1 in zip(sizes, first0, first1)]
-    idx = [i + s1 if concat_results else i for (i, _), s1 in zip(results, first1)]
-    dist = [d for _, d in results]
+    # one library call for the whole batch (dgr_knn1_l2_batch); shapes per pair as find_knn_gpu returns them
+    chunked = nn_max_n > 1
+    idx_all, dist_all = ops.knn1_batch(F0, F1, first0, first1, squared=not chunked, return_distance=True)
+    dist_all = dist_all.unsqueeze(1)
+    if chunked:
+        idx_all = idx_all.unsqueeze(1)
     if concat_results:
-        idx, dist = torch.cat(idx), torch.cat(dist)
+        return (idx_all, dist_all) if return_distance else idx_all
+    idx = [idx_all[s0:s0 + n0] - s1 for (n0, _), s0, s1 in zip(sizes, first0, first1)]
+    dist = [dist_all[s0:s0 + n0] for (n0, _), s0 in zip(sizes, first0)]
     return (idx, dist) if return_distance else idx
 
 

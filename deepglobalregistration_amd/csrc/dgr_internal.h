@@ -289,6 +289,8 @@ int dgr_ctx_collect_profile(dgr_ctx *ctx);
 void dgr_ctx_begin_profile(dgr_ctx *ctx);
 
 // knn.hip / reg.hip / misc.hip internals used by the fused pipeline
+int dgr_knn1_batch_impl(dgr_ctx *ctx, const float *F0, const int64_t *off0, const float *F1, const int64_t *off1,
+                        int npairs, int C, int squared, int64_t *idx_out, float *dist_out, hipStream_t stream);
 int dgr_knn1_impl(dgr_ctx *ctx, const float *F0, int64_t N0, const float *F1, int64_t N1, int C,
                   int squared, int64_t *idx_out, float *dist_out, hipStream_t stream);
 int dgr_inlier_inputs_impl(const int32_t *coords0, const float *xyz0, int64_t N0,

@@ -9,24 +9,48 @@
 // query, and merges the partial results of the F1 splits with one 64-bit atomicMin per query on
 // the packed key (dist_bits << 32 | index): positive floats order like their bit patterns, and
 // ties resolve to the smallest index like torch.min on the CPU.
+//
+// Batched (round 5): every kernel below runs ONCE for all pairs of a batch -- blockIdx.z (packing: blockIdx.y) selects
+// the pair, whose row ranges inside the concatenated feature matrices come from a by-value descriptor table -- instead
+// of 13 launches per pair in a host loop; reference indices are written as rows of the concatenated F1.
 #include "dgr_internal.h"
 
 constexpr int KNN_THREADS = 256;
 constexpr int KNN_TB = 64;  // F1 rows per LDS tile
+constexpr int KNN_MAXP = 32;   // pairs per launch (descriptor table passed by value: no upload, no host buffer to keep alive)
+
+struct KnnPair {
+  int64_t q0, r0;      // first query row (of F0) / first reference row (of F1) of the pair
+  int32_t n0, n1;      // queries / references
+  int32_t qb0, rt0;    // first 32-row block of the pair in the packed query / reference arrays
+};
+struct KnnBatch {
+  KnnPair p[KNN_MAXP];
+  int np;
+};
 
 template <int C, int QPT>
 __global__ void __launch_bounds__(KNN_THREADS)
-    knn1_kernel(const float *__restrict__ F0, int64_t N0, const float *__restrict__ F1, int64_t N1,
-                int rows_per_split, unsigned long long *__restrict__ best, const int32_t *run_flag,
+    knn1_kernel(const float *__restrict__ F0, const float *__restrict__ F1, KnnBatch B, int splits,
+                unsigned long long *__restrict__ best, const int32_t *run_flag,
                 const int32_t *__restrict__ qlist, const int32_t *qcount) {
   __shared__ __attribute__((aligned(16))) float tile[KNN_TB * C];
-  if (run_flag && *run_flag == 0) return;  // fallback launch of the prefiltered path: nothing to redo
-  // optional indirection: only the queries listed in qlist[0 .. *qcount) (prefilter slot overflow)
-  const int64_t n_q = qlist ? (int64_t)*qcount : N0;
+  // blockIdx.z = pair: its rows of F0 / F1 / best (and of qlist), its flag and its list length
+  const KnnPair d = B.p[blockIdx.z];
+  if (run_flag && run_flag[blockIdx.z] == 0) return;  // fallback launch of the prefiltered path: nothing to redo
+  F0 += d.q0 * C;
+  F1 += d.r0 * C;
+  best += d.q0;
+  const int64_t N0 = d.n0, N1 = d.n1;
+  // optional indirection: only the pair's queries listed in qlist[q0 .. q0 + qcount[pair]) (prefilter slot overflow)
+  if (qlist) qlist += d.q0;
+  const int64_t n_q = qlist ? (int64_t)qcount[blockIdx.z] : N0;
   if ((int64_t)blockIdx.x * KNN_THREADS * QPT >= n_q) return;
   const int64_t q0 = ((int64_t)blockIdx.x * KNN_THREADS + threadIdx.x) * QPT;
+  const int rows_per_split = (int)(((N1 + splits - 1) / splits + KNN_TB - 1) / KNN_TB) * KNN_TB;
   const int64_t j_begin = (int64_t)blockIdx.y * rows_per_split;
   const int64_t j_end = min(N1, j_begin + rows_per_split);
+  if (j_begin >= j_end) return;
   float q[QPT][C];
   int64_t qrow[QPT];
 #pragma unroll
@@ -82,19 +106,21 @@ __global__ void __launch_bounds__(KNN_THREADS)
 #pragma unroll
   for (int u = 0; u < QPT; ++u) {
     if (q0 + u < n_q && bi[u] != 0x7fffffff) {
-      const unsigned long long key =
-          ((unsigned long long)__float_as_uint(bd[u]) << 32) | (unsigned int)bi[u];
+      const unsigned long long key =   // the index as a row of the concatenated F1
+          ((unsigned long long)__float_as_uint(bd[u]) << 32) | (unsigned int)(bi[u] + (int)d.r0);
       atomicMin(best + qrow[u], key);
     }
   }
 }
 
-__global__ void knn1_finish(const unsigned long long *__restrict__ best, int64_t N0, int squared,
+__global__ void knn1_finish(const unsigned long long *__restrict__ best, KnnBatch B, int squared,
                             int64_t *__restrict__ idx_out, float *__restrict__ dist_out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N0) return;
+  const KnnPair d = B.p[blockIdx.y];
+  const int64_t li = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (li >= d.n0) return;
+  const int64_t i = d.q0 + li;
   const unsigned long long k = best[i];
-  idx_out[i] = (k == ~0ull) ? 0 : (int64_t)(k & 0xffffffffull);  // all-NaN row: index 0
+  idx_out[i] = (k == ~0ull) ? d.r0 : (int64_t)(k & 0xffffffffull);  // all-NaN row: the pair's reference 0
   if (dist_out) {
     const float d2 = __uint_as_float((unsigned int)(k >> 32));
     dist_out[i] = squared ? d2 : sqrtf(d2 + 1e-7f);  // pdist 'L2', core/metrics.py:64-65
@@ -102,20 +128,25 @@ __global__ void knn1_finish(const unsigned long long *__restrict__ best, int64_t
 }
 
 template <int C>
-static int knn_launch(dgr_ctx *ctx, const float *F0, int64_t N0, const float *F1, int64_t N1,
+static int knn_launch(dgr_ctx *ctx, const float *F0, const float *F1, const KnnBatch &B,
                       unsigned long long *best, const int32_t *run_flag, hipStream_t stream,
                       const int32_t *qlist = nullptr, const int32_t *qcount = nullptr) {
   constexpr int QPT = (C <= 32) ? 4 : 2;
-  const int qblocks = (int)dgr_ceil_div(N0, (int64_t)KNN_THREADS * QPT);
-  // enough (query block, F1 split) workgroups to cover every CU a few times over
-  int splits = (int)dgr_ceil_div((int64_t)ctx->num_cus * 4, qblocks);
-  int64_t max_splits = dgr_ceil_div(N1, KNN_TB);
+  int64_t n0_max = 0, n1_max = 0, qblocks_all = 0;
+  for (int p = 0; p < B.np; ++p) {
+    n0_max = std::max<int64_t>(n0_max, B.p[p].n0);
+    n1_max = std::max<int64_t>(n1_max, B.p[p].n1);
+    qblocks_all += dgr_ceil_div(B.p[p].n0, (int64_t)KNN_THREADS * QPT);
+  }
+  const int qblocks = (int)dgr_ceil_div(n0_max, (int64_t)KNN_THREADS * QPT);
+  // enough (query block, F1 split) workgroups to cover every CU a few times over; a pair with fewer rows than the
+  // largest leaves its surplus blocks / splits empty (they exit at once)
+  int splits = (int)dgr_ceil_div((int64_t)ctx->num_cus * 4, qblocks_all);
+  int64_t max_splits = dgr_ceil_div(n1_max, KNN_TB);
   if (splits > max_splits) splits = (int)max_splits;
   if (splits < 1) splits = 1;
-  int rows_per_split = (int)dgr_ceil_div(dgr_ceil_div(N1, splits), KNN_TB) * KNN_TB;
-  splits = (int)dgr_ceil_div(N1, rows_per_split);
-  dim3 grid(qblocks, splits);
-  knn1_kernel<C, QPT><<<grid, KNN_THREADS, 0, stream>>>(F0, N0, F1, N1, rows_per_split, best, run_flag, qlist, qcount);
+  dim3 grid(qblocks, splits, B.np);
+  knn1_kernel<C, QPT><<<grid, KNN_THREADS, 0, stream>>>(F0, F1, B, splits, best, run_flag, qlist, qcount);
   DGR_LAUNCH_CHECK();
   return DGR_OK;
 }
@@ -123,28 +154,32 @@ static int knn_launch(dgr_ctx *ctx, const float *F0, int64_t N0, const float *F1
 
 // ------------------------------------------------------------------------------------------
 // C = 32: bf16-MFMA prefilter + exact re-evaluation.  Same result as the brute-force kernel above,
-// bit for bit, at ~1/6 of its time:
+// bit for bit, at ~1/8 of its time:
 //   pack     every feature row is split x = hi + lo (+ r, |r| <= 2^-18 |x|) into two bf16 rows, stored
 //            in MFMA operand order (32-row tiles); reference rows are pre-scaled by -2 (exact) and
 //            carry their squared norm nb.
 //   pass 1   d~'(i,j) = nb_i - 2 (hi.hi + hi.lo + lo.hi)  on v_mfma_f32_32x32x16_bf16 (6 per 32 x 32
-//            block, accumulator initialised with nb through the C operand); per-query minimum m~_j.
-//   pass 2   the same products again (identical bits); every (i, j) with d~' <= m~_j + tau_j goes to
-//            a candidate list.  tau_j = 2 c (na_j + max nb), c = 4e-5, bounds twice the worst-case
+//            block, accumulator initialised with nb through the C operand); per-query minimum m~_j -- over a SAMPLE of
+//            the reference tiles (every KNN_SUB-th; round 5): any upper bound of the true minimum will do for the
+//            threshold below, and the minimum over a quarter of the references has expected rank 4 among all of them.
+//   pass 2   the same products for ALL tiles (identical bits where pass 1 ran); every (i, j) with d~' <= m~_j + tau_j
+//            goes to a candidate list.  tau_j = 2 c (na_j + max nb), c = 4e-5, bounds twice the worst-case
 //            difference between d~ and the f32 value the brute-force kernel computes (split residual
 //            3 * 2^-18, f32 accumulation of 96 products, f32 norms), so the brute-force
 //            arg-min -- including its first-index tie-break among equal f32 distances -- is always
-//            in the list.
+//            in the list (m~_j >= the true minimum of d~': the list only grows with the sampling, ~4 entries per query).
 //   exact    one thread per candidate evaluates sum (a - b)^2 exactly like knn1_kernel and merges with
 //            the same 64-bit atomicMin key.
-// A query that collects more than KNN_SLOTS candidates (many near-ties, e.g. repeated structure) is redone by the
-// brute-force kernel through a device-side query list; a non-finite / huge feature makes the brute-force kernel,
-// launched behind, redo the whole search.  No host round trip either way.
+// A query that collects more than KNN_SLOTS candidates (expected rank of the sample minimum 4, P(rank > 32) ~ 1e-4;
+// or many near-ties, e.g. repeated structure) is redone by the brute-force kernel through a device-side query list;
+// a non-finite / huge feature makes the brute-force kernel, launched behind, redo the pair's whole search.  No host
+// round trip either way.
 // ------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 constexpr float KNN_TAU_C = 8e-5f;  // 2 c
-constexpr int KNN_SLOTS = 8;        // candidate slots per query
+constexpr int KNN_SLOTS = 32;       // candidate slots per query
+constexpr int KNN_SUB = 4;          // pass 1 visits every KNN_SUB-th group of KNN_ST reference tiles
 
 __device__ __forceinline__ unsigned short knn_f2bf(float x) {  // round to nearest even
   uint32_t u = __float_as_uint(x);
@@ -163,12 +198,23 @@ __device__ __forceinline__ float knn_unord(uint32_t k) {
 
 // packed[(tile * 4 + f) * 64 + r + 32 g] = 8 bf16: dims 16 (f & 1) + 8 g .. + 7 of row 32 tile + r,
 // f >> 1 = 0: hi, 1: lo.  One thread per (row, g, chunk); the (g = 0, chunk = 0) thread also writes the norm.
+// blockIdx.y = 2 pair + side (0: queries, 1: references -- pre-scaled by -2, padded with infinite norms, maximum norm
+// of the pair left in nb_max[pair]).
 __global__ void __launch_bounds__(256)
-    knn_pack_kernel(const float *__restrict__ F, int64_t N, int64_t n_pad, float scale, float pad_norm,
-                    bf16x8 *__restrict__ packed, float *__restrict__ norms, uint32_t *norm_max, int32_t *fallback) {
+    knn_pack_kernel(const float *__restrict__ F0, const float *__restrict__ F1, KnnBatch B,
+                    bf16x8 *__restrict__ Qp, bf16x8 *__restrict__ Rp, float *__restrict__ na, float *__restrict__ nb,
+                    uint32_t *__restrict__ nb_max, int32_t *__restrict__ fallback) {
+  const int pair = blockIdx.y >> 1, side = blockIdx.y & 1;
+  const KnnPair d = B.p[pair];
+  const int64_t N = side ? d.n1 : d.n0;
+  const int64_t n_pad = (N + 31) / 32 * 32;
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t row = t >> 2;
   if (row >= n_pad) return;
+  const float *F = side ? F1 + d.r0 * 32 : F0 + d.q0 * 32;
+  const float scale = side ? -2.f : 1.f;
+  bf16x8 *packed = side ? Rp + (int64_t)d.rt0 * 256 : Qp + (int64_t)d.qb0 * 256;
+  float *norms = side ? nb + (int64_t)d.rt0 * 32 : na + (int64_t)d.qb0 * 32;
   const int g = (int)(t & 1), ch = (int)((t >> 1) & 1);
   bf16x8 hi, lo;
 #pragma unroll
@@ -179,8 +225,8 @@ __global__ void __launch_bounds__(256)
     const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      // non-finite or huge values (squared norms would overflow): leave the search to the exact kernel
-      if (!(fabsf(x[e]) < 1e18f)) *fallback = 1;
+      // non-finite or huge values (squared norms would overflow): leave the pair's search to the exact kernel
+      if (!(fabsf(x[e]) < 1e18f)) fallback[pair] = 1;
       const unsigned short h = knn_f2bf(x[e]);
       const unsigned short l = knn_f2bf(x[e] - knn_bf2f(h));
       hi[e] = (short)knn_f2bf(knn_bf2f(h) * scale);  // scale is a power of two: exact
@@ -192,11 +238,11 @@ __global__ void __launch_bounds__(256)
   packed[(tile * 4 + ch) * 64 + r + 32 * g] = hi;
   packed[(tile * 4 + 2 + ch) * 64 + r + 32 * g] = lo;
   if (g == 0 && ch == 0) {
-    float n = pad_norm;
+    float n = side ? __builtin_inff() : 0.f;   // padding rows: never a minimum / never a query
     if (row < N) {
       n = 0.f;
       for (int c = 0; c < 32; ++c) n = fmaf(F[row * 32 + c], F[row * 32 + c], n);
-      if (norm_max) atomicMax(norm_max, __float_as_uint(n));  // n >= 0: bit patterns order like values
+      if (side) atomicMax(nb_max + pair, __float_as_uint(n));  // n >= 0: bit patterns order like values
     }
     norms[row] = n;
   }
@@ -205,15 +251,25 @@ __global__ void __launch_bounds__(256)
 // The four waves of a workgroup need the same reference tiles: they are staged through LDS, KNN_ST tiles per
 // stage (16.5 KB), double buffered -- one global read per workgroup instead of one per wave (the per-wave
 // version ran the L1 at ~2/3 of its bandwidth with four identical request streams).
+// Grid: x = groups of 16 query blocks (of the largest pair), y = reference splits, z = pair.  PASS2 = false walks
+// every KNN_SUB-th stage of its split only (the sample), PASS2 = true every stage.
 constexpr int KNN_ST = 4;
 template <bool PASS2>
 __global__ void __launch_bounds__(256, 2)
-    knn_mfma_kernel(const bf16x8 *__restrict__ Q, const bf16x8 *__restrict__ R, const float *__restrict__ nb,
-                    int n_qblocks, int n_rtiles, int tiles_per_split, uint32_t *__restrict__ mt,
-                    const float *__restrict__ na, const uint32_t *__restrict__ nb_max, int64_t N0, int64_t N1,
-                    int32_t *__restrict__ cand, int32_t *__restrict__ cand_cnt, int32_t *overflow) {
+    knn_mfma_kernel(const bf16x8 *__restrict__ Qp, const bf16x8 *__restrict__ Rp, const float *__restrict__ nbp,
+                    KnnBatch B, int splits, uint32_t *__restrict__ mt, const float *__restrict__ nap,
+                    const uint32_t *__restrict__ nb_max, int32_t *__restrict__ cand, int32_t *__restrict__ cand_cnt) {
   __shared__ bf16x8 sA[2][KNN_ST * 4 * 64];
   __shared__ __attribute__((aligned(16))) float sNb[2][KNN_ST * 32];
+  const KnnPair d = B.p[blockIdx.z];
+  const int n_qblocks = (d.n0 + 31) >> 5, n_rtiles = (d.n1 + 31) >> 5;
+  if ((int)blockIdx.x * 16 >= n_qblocks) return;   // a smaller pair than the grid's largest
+  const int64_t N0 = d.n0, N1 = d.n1;
+  const bf16x8 *Q = Qp + (int64_t)d.qb0 * 256, *R = Rp + (int64_t)d.rt0 * 256;
+  const float *nb = nbp + (int64_t)d.rt0 * 32, *na = nap + (int64_t)d.qb0 * 32;
+  mt += d.q0;
+  cand += d.q0 * KNN_SLOTS;
+  cand_cnt += d.q0;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -230,13 +286,19 @@ __global__ void __launch_bounds__(256, 2)
     thr[u] = 0.f;
     if (PASS2) {
       const int64_t q = (int64_t)qb * 32 + (lane & 31);
-      const float nmax = __uint_as_float(*nb_max);
+      const float nmax = __uint_as_float(nb_max[blockIdx.z]);
       thr[u] = (q < N0 && qb0 + u < n_qblocks) ? knn_unord(mt[q]) + KNN_TAU_C * (na[q] + nmax) : -__builtin_inff();
     }
   }
-  const int t_begin = blockIdx.y * tiles_per_split;
-  const int t_end = min(n_rtiles, t_begin + tiles_per_split);
-  if (t_begin >= t_end) return;   // block-uniform
+  // stages (KNN_ST tiles) of this split; pass 1 takes every KNN_SUB-th of them, offset by the split index so that the
+  // sample does not alias with the split length
+  const int n_stages = (n_rtiles + KNN_ST - 1) / KNN_ST;
+  const int sps = (n_stages + splits - 1) / splits;   // stages per split
+  const int s_begin = blockIdx.y * sps, s_end = min(n_stages, s_begin + sps);
+  constexpr int STEP = PASS2 ? 1 : KNN_SUB;
+  // (a pair with fewer than KNN_SUB stages per split still gets one sampled stage per split)
+  const int s_first = PASS2 ? s_begin : s_begin + min((int)(blockIdx.y % KNN_SUB), max(s_end - s_begin - 1, 0));
+  if (s_first >= s_end) return;   // block-uniform
   // stage loader: thread tid fetches piece tid + 256 j of tile t0 + j (contiguous 4 KB per tile) and one norm
   bf16x8 pre[KNN_ST];
   float pre_nb = 0.f;
@@ -250,16 +312,17 @@ __global__ void __launch_bounds__(256, 2)
     for (int j = 0; j < KNN_ST; ++j) sA[buf][j * 256 + tid] = pre[j];
     if (tid < KNN_ST * 32) sNb[buf][tid] = pre_nb;
   };
-  request(t_begin);
+  request(s_first * KNN_ST);
   deposit(0);
   __syncthreads();
   int buf = 0;
-  for (int t0 = t_begin; t0 < t_end; t0 += KNN_ST) {
-    if (t0 + KNN_ST < t_end) request(t0 + KNN_ST);   // lands behind this stage's MFMAs
+  for (int st = s_first; st < s_end; st += STEP) {
+    const int t0 = st * KNN_ST;
+    if (st + STEP < s_end) request((st + STEP) * KNN_ST);   // lands behind this stage's MFMAs
 #pragma unroll
     for (int j = 0; j < KNN_ST; ++j) {
       const int t = t0 + j;
-      if (t >= t_end) break;   // block-uniform
+      if (t >= n_rtiles) break;   // block-uniform
       const bf16x8 a0 = sA[buf][(j * 4 + 0) * 64 + lane], a1 = sA[buf][(j * 4 + 1) * 64 + lane];
       const bf16x8 a2 = sA[buf][(j * 4 + 2) * 64 + lane], a3 = sA[buf][(j * 4 + 3) * 64 + lane];
       f32x16_t c0;
@@ -292,21 +355,21 @@ __global__ void __launch_bounds__(256, 2)
         if (!PASS2) {
           m[u] = fminf(m[u], bm);
         } else {
-          if (!(bm > thr[u])) {   // rare: some reference of this block is within tau of the query's minimum
+          if (!(bm > thr[u])) {   // some reference of this block is within tau of the query's (sampled) minimum
             const int64_t q = (int64_t)(qb0 + u) * 32 + (lane & 31);
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
               const int64_t i = (int64_t)t * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
               if (!(acc[u][e] > thr[u]) && q < N0 && i < N1 && qb0 + u < n_qblocks) {
                 const int slot = atomicAdd(cand_cnt + q, 1);   // per-query counters: no hot address
-                if (slot < KNN_SLOTS) cand[q * KNN_SLOTS + slot] = (int32_t)i;   // beyond: knn_overflow_list
+                if (slot < KNN_SLOTS) cand[q * KNN_SLOTS + slot] = (int32_t)(i + d.r0);   // beyond: knn_overflow_list
               }
             }
           }
         }
       }
     }
-    if (t0 + KNN_ST < t_end) deposit(buf ^ 1);
+    if (st + STEP < s_end) deposit(buf ^ 1);
     __syncthreads();   // the other buffer is complete; this one may be overwritten by the next deposit
     buf ^= 1;
   }
@@ -321,13 +384,15 @@ __global__ void __launch_bounds__(256, 2)
   }
 }
 
+// one thread per candidate slot of every query of the batch; candidates are rows of the concatenated F1
 __global__ void __launch_bounds__(256)
     knn_exact_kernel(const float *__restrict__ F0, const float *__restrict__ F1, const int32_t *__restrict__ cand,
-                     const int32_t *__restrict__ cand_cnt, int64_t N0, unsigned long long *__restrict__ best) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                     const int32_t *__restrict__ cand_cnt, int64_t q_begin, int64_t q_end,
+                     unsigned long long *__restrict__ best) {
+  const int64_t t = q_begin * KNN_SLOTS + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t q = t / KNN_SLOTS;
   const int slot = (int)(t % KNN_SLOTS);
-  if (q >= N0 || slot >= min(cand_cnt[q], KNN_SLOTS)) return;
+  if (q >= q_end || slot >= min(cand_cnt[q], KNN_SLOTS)) return;
   const int i = cand[t];
   const float *a = F0 + q * 32, *b = F1 + (int64_t)i * 32;
   float d0 = 0.f, d1 = 0.f;  // the very chain of knn1_kernel
@@ -347,44 +412,64 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-// queries that collected more candidates than slots (many near-ties): redone exactly by the brute-force kernel
-__global__ void knn_overflow_list(const int32_t *__restrict__ cand_cnt, int64_t N0, int32_t *__restrict__ qlist,
+// queries that collected more candidates than slots (many near-ties): redone exactly by the brute-force kernel.
+// blockIdx.y = pair; the pair's list (row numbers inside the pair) starts at qlist[q0]
+__global__ void knn_overflow_list(const int32_t *__restrict__ cand_cnt, KnnBatch B, int32_t *__restrict__ qlist,
                                   int32_t *qcount) {
+  const KnnPair d = B.p[blockIdx.y];
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (q < N0 && cand_cnt[q] > KNN_SLOTS) qlist[atomicAdd(qcount, 1)] = (int32_t)q;
+  if (q < d.n0 && cand_cnt[d.q0 + q] > KNN_SLOTS) qlist[d.q0 + atomicAdd(qcount + blockIdx.y, 1)] = (int32_t)q;
 }
 
-static int knn_prefiltered(dgr_ctx *ctx, const float *F0, int64_t N0, const float *F1, int64_t N1,
-                           unsigned long long *best, hipStream_t stream) {
+// the pairs of B (all with at least KNN_MIN_REFS references); best is initialised by the caller
+static int knn_prefiltered(dgr_ctx *ctx, const float *F0, const float *F1, KnnBatch B, unsigned long long *best,
+                           hipStream_t stream) {
   DgrArena &arena = ctx->arena;
-  const int n_qblocks = (int)dgr_ceil_div(N0, 32), n_rtiles = (int)dgr_ceil_div(N1, 32);
+  int64_t q_begin = B.p[0].q0, q_end = 0;
+  int n_qb = 0, n_rt = 0, qb_max = 0, rt_max = 0;
+  for (int p = 0; p < B.np; ++p) {
+    KnnPair &d = B.p[p];
+    d.qb0 = n_qb;
+    d.rt0 = n_rt;
+    const int qb = (d.n0 + 31) / 32, rt = (d.n1 + 31) / 32;
+    n_qb += qb;
+    n_rt += rt;
+    qb_max = std::max(qb_max, qb);
+    rt_max = std::max(rt_max, rt);
+    q_begin = std::min(q_begin, d.q0);
+    q_end = std::max(q_end, d.q0 + d.n0);
+  }
+  const int64_t nq = q_end - q_begin;   // query rows covered (the pairs of a batch are consecutive row ranges)
   bf16x8 *Qp, *Rp;
   float *na, *nb;
   uint32_t *mt, *nb_max;
-  int32_t *cand, *cand_cnt;
-  DGR_ALLOC(Qp, arena, bf16x8, (int64_t)n_qblocks * 256);
-  DGR_ALLOC(Rp, arena, bf16x8, (int64_t)n_rtiles * 256);
-  DGR_ALLOC(na, arena, float, (int64_t)n_qblocks * 32);
-  DGR_ALLOC(nb, arena, float, (int64_t)n_rtiles * 32);
-  DGR_ALLOC(mt, arena, uint32_t, N0);
-  int32_t *qlist;
-  DGR_ALLOC(qlist, arena, int32_t, N0);
-  DGR_ALLOC(cand_cnt, arena, int32_t, N0 + 4);   // + [N0]: max nb bits, [N0 + 1]: fallback flag, [N0 + 2]: overflow count
-  DGR_ALLOC(cand, arena, int32_t, N0 * KNN_SLOTS);
-  nb_max = reinterpret_cast<uint32_t *>(cand_cnt + N0);
-  int32_t *fallback = cand_cnt + N0 + 1;
-  DGR_HIP_CHECK(hipMemsetAsync(cand_cnt, 0, (size_t)(N0 + 4) * sizeof(int32_t), stream));
-  DGR_HIP_CHECK(hipMemsetAsync(mt, 0xff, (size_t)N0 * sizeof(uint32_t), stream));
-  const int64_t q_pad = (int64_t)n_qblocks * 32, r_pad = (int64_t)n_rtiles * 32;
-  knn_pack_kernel<<<(int)dgr_ceil_div(q_pad * 4, 256), 256, 0, stream>>>(F0, N0, q_pad, 1.f, 0.f, Qp, na, nullptr,
-                                                                         fallback);
-  knn_pack_kernel<<<(int)dgr_ceil_div(r_pad * 4, 256), 256, 0, stream>>>(F1, N1, r_pad, -2.f, __builtin_inff(), Rp,
-                                                                         nb, nb_max, fallback);
-  DGR_LAUNCH_CHECK();
-  const int qgroups = (int)dgr_ceil_div(n_qblocks, 16);
+  int32_t *cand, *cand_cnt, *qlist;
+  DGR_ALLOC(Qp, arena, bf16x8, (int64_t)n_qb * 256);
+  DGR_ALLOC(Rp, arena, bf16x8, (int64_t)n_rt * 256);
+  DGR_ALLOC(na, arena, float, (int64_t)n_qb * 32);
+  DGR_ALLOC(nb, arena, float, (int64_t)n_rt * 32);
+  DGR_ALLOC(mt, arena, uint32_t, nq);
+  DGR_ALLOC(qlist, arena, int32_t, nq);
+  DGR_ALLOC(cand_cnt, arena, int32_t, nq + 3 * KNN_MAXP);   // + per pair: max nb bits, fallback flag, overflow count
+  DGR_ALLOC(cand, arena, int32_t, nq * KNN_SLOTS);
+  nb_max = reinterpret_cast<uint32_t *>(cand_cnt + nq);
+  int32_t *fallback = cand_cnt + nq + KNN_MAXP, *qcount = cand_cnt + nq + 2 * KNN_MAXP;
+  DGR_HIP_CHECK(hipMemsetAsync(cand_cnt, 0, (size_t)(nq + 3 * KNN_MAXP) * sizeof(int32_t), stream));
+  DGR_HIP_CHECK(hipMemsetAsync(mt, 0xff, (size_t)nq * sizeof(uint32_t), stream));
+  // per-query arrays are addressed by the row of the concatenated F0: shift them so that row q_begin is element 0
+  mt -= q_begin; qlist -= q_begin; cand_cnt -= q_begin; cand -= q_begin * KNN_SLOTS;
+  {
+    const int rows_max = std::max(qb_max, rt_max) * 32;
+    dim3 grid((unsigned)dgr_ceil_div((int64_t)rows_max * 4, 256), 2 * B.np);
+    knn_pack_kernel<<<grid, 256, 0, stream>>>(F0, F1, B, Qp, Rp, na, nb, nb_max, fallback);
+    DGR_LAUNCH_CHECK();
+  }
+  int qgroups_all = 0;
+  for (int p = 0; p < B.np; ++p) qgroups_all += (int)dgr_ceil_div((B.p[p].n0 + 31) / 32, 16);
+  const int qgroups = (int)dgr_ceil_div(qb_max, 16);
   // reference splits chosen so that the grid fills the chip in whole rounds (one resident round when possible):
   // a grid of 1.3 x the resident capacity leaves the second round two thirds empty
-  auto launch = [&](auto kernel) -> int {
+  auto launch = [&](auto kernel, int sub) -> int {
     static int per_cu = 0;
     if (per_cu == 0) {
       int n = 0;
@@ -392,52 +477,107 @@ static int knn_prefiltered(dgr_ctx *ctx, const float *F0, int64_t N0, const floa
       per_cu = n < 1 ? 1 : n;
     }
     const int capacity = ctx->num_cus * per_cu;
-    int splits = capacity / qgroups;
-    if (splits > n_rtiles / KNN_ST) splits = n_rtiles / KNN_ST;
-    if (splits < 1) splits = 1;
-    const int tps = (int)dgr_ceil_div(dgr_ceil_div(n_rtiles, splits), KNN_ST) * KNN_ST;
-    splits = (int)dgr_ceil_div(n_rtiles, tps);
-    dim3 grid(qgroups, splits);
-    kernel<<<grid, 256, 0, stream>>>(Qp, Rp, nb, n_qblocks, n_rtiles, tps, mt, na, nb_max, N0, N1, cand, cand_cnt, fallback);
+    const int stages = (int)dgr_ceil_div(rt_max, KNN_ST);
+    // the split count (<= 16) whose grid fills whole rounds of resident workgroups best; ties -> more splits
+    int splits = 1;
+    double best_fill = 0.;
+    for (int sp = 1; sp <= std::min(16, std::max(1, stages / sub)); ++sp) {
+      const int64_t blocks = (int64_t)qgroups_all * sp;
+      const double fill = (double)blocks / (double)(dgr_ceil_div(blocks, (int64_t)capacity) * capacity);
+      if (fill >= best_fill) { best_fill = fill; splits = sp; }
+    }
+    dim3 grid(qgroups, splits, B.np);
+    kernel<<<grid, 256, 0, stream>>>(Qp, Rp, nb, B, splits, mt, na, nb_max, cand, cand_cnt);
     return DGR_OK;
   };
-  DGR_CHECK(launch(knn_mfma_kernel<false>));
-  DGR_CHECK(launch(knn_mfma_kernel<true>));
+  DGR_CHECK(launch(knn_mfma_kernel<false>, KNN_SUB));
+  DGR_CHECK(launch(knn_mfma_kernel<true>, 1));
   DGR_LAUNCH_CHECK();
-  knn_exact_kernel<<<(int)dgr_ceil_div(N0 * KNN_SLOTS, 256), 256, 0, stream>>>(F0, F1, cand, cand_cnt, N0, best);
+  knn_exact_kernel<<<(int)dgr_ceil_div(nq * KNN_SLOTS, 256), 256, 0, stream>>>(F0, F1, cand, cand_cnt, q_begin, q_end, best);
   DGR_LAUNCH_CHECK();
-  // queries with more near-ties than slots are redone one by one by the brute-force kernel (its blocks beyond
-  // the list length exit at once); non-finite / huge input: the brute-force kernel redoes the whole search
-  int32_t *qcount = cand_cnt + N0 + 2;
-  knn_overflow_list<<<(int)dgr_ceil_div(N0, 256), 256, 0, stream>>>(cand_cnt, N0, qlist, qcount);
-  DGR_CHECK(knn_launch<32>(ctx, F0, N0, F1, N1, best, nullptr, stream, qlist, qcount));
-  return knn_launch<32>(ctx, F0, N0, F1, N1, best, fallback, stream);
+  // queries with more candidates than slots are redone one by one by the brute-force kernel (its blocks beyond
+  // the list length exit at once); non-finite / huge input: the brute-force kernel redoes the pair's whole search
+  {
+    int64_t n0_max = 0;
+    for (int p = 0; p < B.np; ++p) n0_max = std::max<int64_t>(n0_max, B.p[p].n0);
+    dim3 grid((unsigned)dgr_ceil_div(n0_max, 256), B.np);
+    knn_overflow_list<<<grid, 256, 0, stream>>>(cand_cnt, B, qlist, qcount);
+    DGR_LAUNCH_CHECK();
+  }
+  DGR_CHECK(knn_launch<32>(ctx, F0, F1, B, best, nullptr, stream, qlist, qcount));
+  return knn_launch<32>(ctx, F0, F1, B, best, fallback, stream);
+}
+
+// 1-NN of every pair of `B` (row ranges of the concatenated F0 / F1): idx_out[q] = row of F1 (concatenated numbering)
+static int knn_batch(dgr_ctx *ctx, const float *F0, const float *F1, const KnnBatch &B, int C, int squared,
+                     unsigned long long *best, int64_t *idx_out, float *dist_out, hipStream_t stream) {
+  int64_t n0_max = 0;
+  for (int p = 0; p < B.np; ++p) n0_max = std::max<int64_t>(n0_max, B.p[p].n0);
+  switch (C) {
+    case 16: DGR_CHECK(knn_launch<16>(ctx, F0, F1, B, best, nullptr, stream)); break;
+    case 32: {
+      static const bool brute = getenv("DGR_KNN_BRUTE") != nullptr;
+      // small reference sets: the brute-force kernel alone (the prefilter's fixed passes would cost more)
+      KnnBatch big, small;
+      big.np = small.np = 0;
+      for (int p = 0; p < B.np; ++p) {
+        if (brute || B.p[p].n1 < 1024) small.p[small.np++] = B.p[p];
+        else big.p[big.np++] = B.p[p];
+      }
+      if (small.np) DGR_CHECK(knn_launch<32>(ctx, F0, F1, small, best, nullptr, stream));
+      if (big.np) DGR_CHECK(knn_prefiltered(ctx, F0, F1, big, best, stream));
+      break;
+    }
+    case 64: DGR_CHECK(knn_launch<64>(ctx, F0, F1, B, best, nullptr, stream)); break;
+    default:
+      dgr_set_error("find_knn: feature width %d not supported (16, 32, 64)", C);
+      return DGR_EINVAL;
+  }
+  dim3 grid((unsigned)dgr_ceil_div(n0_max, 256), B.np);
+  knn1_finish<<<grid, 256, 0, stream>>>(best, B, squared, idx_out, dist_out);
+  DGR_LAUNCH_CHECK();
+  return DGR_OK;
+}
+
+// Batched entry of the fused pipeline: pair p = rows off0[p] .. off0[p + 1] of F0 against rows off1[p] .. off1[p + 1] of
+// F1; idx_out [off0[npairs]] = rows of F1 in the concatenated numbering (what the 6-D assembly gathers with)
+int dgr_knn1_batch_impl(dgr_ctx *ctx, const float *F0, const int64_t *off0, const float *F1, const int64_t *off1,
+                        int npairs, int C, int squared, int64_t *idx_out, float *dist_out, hipStream_t stream) {
+  const int64_t n0 = off0[npairs];
+  DGR_REQUIRE(off0[0] == 0 && off1[0] == 0, "find_knn: the row offsets start at 0");
+  DGR_REQUIRE(off1[npairs] < (1ll << 31) && n0 < (1ll << 31), "find_knn: N0 / N1 too large");
+  unsigned long long *best;
+  DGR_ALLOC(best, ctx->arena, unsigned long long, n0);
+  DGR_HIP_CHECK(hipMemsetAsync(best, 0xff, (size_t)n0 * sizeof(unsigned long long), stream));
+  for (int p0 = 0; p0 < npairs; p0 += KNN_MAXP) {
+    KnnBatch B;
+    B.np = std::min(KNN_MAXP, npairs - p0);
+    for (int p = 0; p < B.np; ++p) {
+      KnnPair &d = B.p[p];
+      d.q0 = off0[p0 + p]; d.r0 = off1[p0 + p];
+      d.n0 = (int32_t)(off0[p0 + p + 1] - off0[p0 + p]); d.n1 = (int32_t)(off1[p0 + p + 1] - off1[p0 + p]);
+      d.qb0 = d.rt0 = 0;
+      DGR_REQUIRE(d.n0 > 0 && d.n1 > 0, "find_knn: empty feature matrix (N0=%d, N1=%d)", d.n0, d.n1);
+    }
+    const DgrArena::Mark mk = ctx->arena.mark();
+    DGR_CHECK(knn_batch(ctx, F0, F1, B, C, squared, best, idx_out, dist_out, stream));
+    ctx->arena.rewind(mk);
+  }
+  return DGR_OK;
 }
 
 int dgr_knn1_impl(dgr_ctx *ctx, const float *F0, int64_t N0, const float *F1, int64_t N1, int C,
                   int squared, int64_t *idx_out, float *dist_out, hipStream_t stream) {
   DGR_REQUIRE(N0 > 0 && N1 > 0, "find_knn: empty feature matrix (N0=%lld, N1=%lld)", (long long)N0,
               (long long)N1);
-  DGR_REQUIRE(N1 < (1ll << 31), "find_knn: N1 too large");
+  DGR_REQUIRE(N1 < (1ll << 31) && N0 < (1ll << 31), "find_knn: N0 / N1 too large");
   unsigned long long *best;
   DGR_ALLOC(best, ctx->arena, unsigned long long, N0);
   DGR_HIP_CHECK(hipMemsetAsync(best, 0xff, (size_t)N0 * sizeof(unsigned long long), stream));
-  switch (C) {
-    case 16: DGR_CHECK(knn_launch<16>(ctx, F0, N0, F1, N1, best, nullptr, stream)); break;
-    case 32: {
-      static const bool brute = getenv("DGR_KNN_BRUTE") != nullptr;
-      if (brute || N1 < 1024) DGR_CHECK(knn_launch<32>(ctx, F0, N0, F1, N1, best, nullptr, stream));
-      else DGR_CHECK(knn_prefiltered(ctx, F0, N0, F1, N1, best, stream));
-      break;
-    }
-    case 64: DGR_CHECK(knn_launch<64>(ctx, F0, N0, F1, N1, best, nullptr, stream)); break;
-    default:
-      dgr_set_error("find_knn: feature width %d not supported (16, 32, 64)", C);
-      return DGR_EINVAL;
-  }
-  knn1_finish<<<(int)dgr_ceil_div(N0, 256), 256, 0, stream>>>(best, N0, squared, idx_out, dist_out);
-  DGR_LAUNCH_CHECK();
-  return DGR_OK;
+  KnnBatch B;
+  B.np = 1;
+  B.p[0] = KnnPair{0, 0, (int32_t)N0, (int32_t)N1, 0, 0};
+  return knn_batch(ctx, F0, F1, B, C, squared, best, idx_out, dist_out, stream);
 }
 
 extern "C" int dgr_knn1_l2(dgr_ctx *ctx, const float *F0, int64_t N0, const float *F1, int64_t N1, int C,
@@ -446,4 +586,16 @@ extern "C" int dgr_knn1_l2(dgr_ctx *ctx, const float *F0, int64_t N0, const floa
   DGR_HIP_CHECK(hipSetDevice(ctx->device));
   DGR_CHECK(ctx->arena.reset());
   return dgr_knn1_impl(ctx, F0, N0, F1, N1, C, squared, idx_out, dist_out, (hipStream_t)stream);
+}
+
+extern "C" int dgr_knn1_l2_batch(dgr_ctx *ctx, const float *F0, const int64_t *off0, const float *F1,
+                                 const int64_t *off1, int npairs, int C, int squared, int64_t *idx_out,
+                                 float *dist_out, dgr_stream stream) {
+  DGR_REQUIRE(ctx && F0 && F1 && off0 && off1 && idx_out, "dgr_knn1_l2_batch: NULL argument");
+  DGR_REQUIRE(npairs >= 1, "dgr_knn1_l2_batch: npairs=%d", npairs);
+  for (int p = 0; p < npairs; ++p)
+    DGR_REQUIRE(off0[p + 1] > off0[p] && off1[p + 1] > off1[p], "find_knn: pair %d has an empty feature matrix", p);
+  DGR_HIP_CHECK(hipSetDevice(ctx->device));
+  DGR_CHECK(ctx->arena.reset());
+  return dgr_knn1_batch_impl(ctx, F0, off0, F1, off1, npairs, C, squared, idx_out, dist_out, (hipStream_t)stream);
 }

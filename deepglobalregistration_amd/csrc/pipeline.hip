@@ -140,11 +140,6 @@ __global__ void concat_coords_kernel(const int32_t *__restrict__ c0, int64_t n0,
   out[i * 4 + 1] = src[1]; out[i * 4 + 2] = src[2]; out[i * 4 + 3] = src[3];
 }
 
-__global__ void add_offset_kernel(int64_t *idx, int64_t n, int64_t off) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) idx[i] += off;
-}
-
 // ---- fused batched pipeline --------------------------------------------------------------------------
 struct StageTimer {
   dgr_ctx *ctx;
@@ -221,12 +216,8 @@ extern "C" int dgr_register_batch(dgr_ctx *ctx, dgr_net *fcgf, dgr_net *inlier, 
   DGR_CHECK(tm.rec(0, 1));
   // Step 2: coarse correspondences, per pair (corres_idx0 = arange)
   DGR_CHECK(tm.rec(1, 0));
-  for (int p = 0; p < npairs; ++p) {
-    const int64_t m0 = off0[p + 1] - off0[p], m1 = off1[p + 1] - off1[p];
-    DGR_CHECK(dgr_knn1_impl(ctx, F0 + off0[p] * C, m0, F1 + off1[p] * C, m1, C, 0, idx1 + off0[p], nullptr, stream));
-    if (off1[p] != 0)
-      add_offset_kernel<<<(int)dgr_ceil_div(m0, 256), 256, 0, stream>>>(idx1 + off0[p], m0, off1[p]);
-  }
+  // one launch per kernel for all pairs; the indices come out as rows of the concatenated F1
+  DGR_CHECK(dgr_knn1_batch_impl(ctx, F0, off0, F1, off1, npairs, C, 0, idx1, nullptr, stream));
   if (override_idx1)
     override_idx_kernel<<<(int)dgr_ceil_div(n0, 256), 256, 0, stream>>>(idx1, override_idx1, n0);
   DGR_CHECK(tm.rec(1, 1));

@@ -214,6 +214,27 @@ def knn1(F0, F1, squared=False, return_distance=False):
     return (idx, dist) if return_distance else idx
 
 
+def knn1_batch(F0, F1, off0, off1, squared=False, return_distance=False):
+    """1-NN of every pair (rows off0[p]:off0[p+1] of F0 against rows off1[p]:off1[p+1] of F1) in one library call;
+    indices address rows of the concatenated F1."""
+    lib = _lib.load()
+    dev = _dev(F0)
+    F0 = _as(F0, torch.float32, dev)
+    F1 = _as(F1, torch.float32, dev)
+    if F0.dim() != 2 or F1.dim() != 2 or F0.shape[1] != F1.shape[1]:
+        raise ValueError('F0 [N0,C] and F1 [N1,C] must share the feature width')
+    o0 = np.ascontiguousarray(off0, dtype=np.int64)
+    o1 = np.ascontiguousarray(off1, dtype=np.int64)
+    if len(o0) != len(o1) or len(o0) < 2 or o0[0] != 0 or o1[0] != 0 or o0[-1] != F0.shape[0] or o1[-1] != F1.shape[0]:
+        raise ValueError('off0 / off1 must be [npairs+1] row offsets covering F0 / F1')
+    idx = torch.empty(F0.shape[0], dtype=torch.int64, device=dev)
+    dist = torch.empty(F0.shape[0], dtype=torch.float32, device=dev) if return_distance else None
+    check(lib.dgr_knn1_l2_batch(get_ctx(dev), ptr(F0), o0.ctypes.data_as(_lib.c_i64p), ptr(F1),
+                                o1.ctypes.data_as(_lib.c_i64p), len(o0) - 1, F0.shape[1], int(squared), ptr(idx),
+                                ptr(dist), stream_ptr(dev.index)))
+    return (idx, dist) if return_distance else idx
+
+
 def inlier_inputs(coords0, xyz0, coords1, xyz1, idx1, feature_type='coords'):
     lib = _lib.load()
     dev = _dev(xyz0)

@@ -135,6 +135,16 @@ int dgr_maps_get_kernel_map(dgr_maps *maps, int kind, int ts, int32_t *rule_ptr,
 int dgr_knn1_l2(dgr_ctx *ctx, const float *F0, int64_t N0, const float *F1, int64_t N1, int C,
                 int squared, int64_t *idx_out, float *dist_out, dgr_stream stream);
 
+/* ---- the same search for every pair of a collated batch in ONE launch per kernel: replaces
+ * core.knn.find_knn_gpu_batch(F0, F1, len_batch, ...) (core/knn.py:106-140, one find_knn_gpu call per
+ * pair there).  F0 dev f32 [off0[npairs],C] / F1 dev f32 [off1[npairs],C] hold the pairs' rows back to back
+ * (dataloader/base_loader.py:63-81); off0 / off1 HOST int64 [npairs+1], starting at 0, no empty pair.
+ * idx_out dev int64 [off0[npairs]]: rows of the CONCATENATED F1 (the reference's `concat_results`
+ * numbering, core/knn.py:131-134; subtract off1[p] for per-pair indices); dist_out as above or NULL. */
+int dgr_knn1_l2_batch(dgr_ctx *ctx, const float *F0, const int64_t *off0, const float *F1,
+                      const int64_t *off1, int npairs, int C, int squared, int64_t *idx_out,
+                      float *dist_out, dgr_stream stream);
+
 /* ---- 6-D inlier-network input: replaces the torch.cat at core/deep_global_registration.py:261-262
  * and inlier_feature_generation (:185-208).  idx1 dev int64 [N0] (corres_idx1; corres_idx0 is
  * arange(N0)).  feature_type 0='ones' -> feats [N0,1]; 1='coords' -> [N0,6] =

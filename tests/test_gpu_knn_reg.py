@@ -281,3 +281,34 @@ def test_refinement_iteration_matched_parity(n, outliers):
         assert worst[k] < 1e-4, (k, worst)
         assert abs(st['loss'] - so['loss']) <= 1e-4 * abs(so['loss']) + 1e-9, (k, st, so)
     print(f'iteration-matched |dR|,|dt| by iteration count (n={n}): ' + ', '.join(f'{k}: {v:.1e}' for k, v in worst.items()))
+
+
+def test_knn_batch_equals_per_pair_search():
+    """One batched call (`dgr_knn1_l2_batch`: every kernel once for all pairs, sampled first pass) against one search per
+    pair: pairs of different sizes -- larger and smaller than the prefilter's threshold, not multiples of the tile sizes,
+    one with near-ties -- indices and distance bits equal, indices in the concatenated numbering."""
+    from deepglobalregistration_amd import ops
+    rng = np.random.default_rng(11)
+
+    def unit(x):
+        return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+    sizes = [(5003, 4099), (700, 6000), (33, 5), (9000, 1025), (2500, 2500)]
+    F0s = [unit(rng.standard_normal((a, 32))) for a, _ in sizes]
+    F1s = [unit(rng.standard_normal((b, 32))) for _, b in sizes]
+    F1s[4] = unit(F0s[4] + 1e-4 * rng.standard_normal((2500, 32)))          # near-duplicates of the queries
+    F1s[1][3000:] = F1s[1][:3000] + np.float32(1e-7)                          # near-ties among the references
+    off0 = np.concatenate([[0], np.cumsum([a for a, _ in sizes])])
+    off1 = np.concatenate([[0], np.cumsum([b for _, b in sizes])])
+    F0, F1 = torch.from_numpy(np.concatenate(F0s)).cuda(), torch.from_numpy(np.concatenate(F1s)).cuda()
+    idx, dist = ops.knn1_batch(F0, F1, off0, off1, return_distance=True)
+    for p, (a, b) in enumerate(sizes):
+        i1, d1 = ops.knn1(F0[off0[p]:off0[p + 1]], F1[off1[p]:off1[p + 1]], return_distance=True)
+        assert torch.equal(idx[off0[p]:off0[p + 1]], i1 + int(off1[p])), p
+        assert torch.equal(dist[off0[p]:off0[p + 1]].view(torch.int32), d1.view(torch.int32)), p
+    # more pairs than one descriptor table holds (32)
+    n = 40
+    off = np.arange(n + 1) * 1100
+    G0, G1 = torch.from_numpy(unit(rng.standard_normal((n * 1100, 32)))).cuda(), torch.from_numpy(unit(rng.standard_normal((n * 1100, 32)))).cuda()
+    idx = ops.knn1_batch(G0, G1, off, off)
+    for p in (0, 31, 32, 39):
+        assert torch.equal(idx[off[p]:off[p + 1]], ops.knn1(G0[off[p]:off[p + 1]], G1[off[p]:off[p + 1]]) + int(off[p]))
