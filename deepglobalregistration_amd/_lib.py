@@ -47,6 +47,8 @@ SIGNATURES = {
                                  C.POINTER(WeightDesc), C.c_int, C.POINTER(vp)]),
     'dgr_net_destroy': (None, [vp]),
     'dgr_net_param_bytes': (C.c_int64, [vp]),
+    'dgr_net_share': (C.c_int, [vp, vp, C.POINTER(vp)]),
+    'dgr_net_sharers': (C.c_int, [vp]),
     'dgr_resunet_forward': (C.c_int, [vp, vp, vp, vp, C.c_int64, vp, vp]),
     'dgr_net_get_intermediate': (C.c_int, [vp, vp, C.c_char_p, vp, C.c_int64, c_i64p, c_i64p]),
     'dgr_net_layer_stats': (C.c_int, [vp, vp, C.c_int, c_i64p]),

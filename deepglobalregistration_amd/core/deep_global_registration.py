@@ -89,7 +89,13 @@ class DeepGlobalRegistration:
         me_conv = {'kernel_order': _cfg_get(config, 'me_kernel_order', 'first_axis_fastest'),
                    'transposed_mirrored': bool(_cfg_get(config, 'me_transposed_mirrored', False))}
         self.fcgf_model.me_conventions = dict(me_conv)
-        self.fcgf_model.load_state_dict(state['state_dict'])
+        # optional runtime key `share_weights_with`: another DeepGlobalRegistration of the same checkpoint on this device
+        # (one object per HIP stream / library context): its device-resident weights are used, not a second copy
+        shared = _cfg_get(config, 'share_weights_with')
+        if shared is not None:
+            self.fcgf_model.share_weights(shared.fcgf_model)
+        else:
+            self.fcgf_model.load_state_dict(state['state_dict'])
         self.fcgf_model = self.fcgf_model.to(self.device).eval()
 
         # inlier network (:118-131)
@@ -101,7 +107,10 @@ class DeepGlobalRegistration:
                                         conv1_kernel_size=_cfg_get(network_config, 'inlier_conv1_kernel_size'),
                                         normalize_feature=False, D=6)
         self.inlier_model.me_conventions = dict(me_conv)
-        self.inlier_model.load_state_dict(state['state_dict_inlier'])
+        if shared is not None:
+            self.inlier_model.share_weights(shared.inlier_model)
+        else:
+            self.inlier_model.load_state_dict(state['state_dict_inlier'])
         self.inlier_model = self.inlier_model.to(self.device).eval()
         self.nn_max_n = _cfg_get(network_config, 'nn_max_n', 250)
 

@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <map>
+#include <memory>
 #include <string>
 
 #include "dgr_internal.h"
@@ -68,11 +69,32 @@ struct DgrTensorRef {
   const int32_t *canon = nullptr;   // rows of a coarse 6-D map: library numbering -> first-occurrence numbering
 };
 
+// The immutable half of a net: the folded, re-tiled weights in HBM.  Shared (reference-counted) by every dgr_net made
+// from it with dgr_net_share -- one context per HIP stream, ONE weight set per device.
+struct DgrWeights {
+  std::vector<DgrLayer> layers;  // 23 convs in forward order
+  int64_t param_bytes = 0;
+  int device = 0;
+  ~DgrWeights() {
+    (void)hipSetDevice(device);
+    (void)hipDeviceSynchronize();
+    for (auto &l : layers) {
+      if (l.w) (void)hipFree(l.w);
+      if (l.w16) (void)hipFree(l.w16);
+      if (l.wb) (void)hipFree(l.wb);
+      if (l.wc) (void)hipFree(l.wc);
+      if (l.w16b) (void)hipFree(l.w16b);
+      if (l.w16d) (void)hipFree(l.w16d);
+      if (l.shift) (void)hipFree(l.shift);
+    }
+  }
+};
+
+// ... and the per-context half: what the last forward of THIS net object left behind
 struct dgr_net {
   dgr_ctx *ctx;
   int D, cin, cout, conv1_ks, normalize;
-  std::vector<DgrLayer> layers;  // 23 convs in forward order
-  int64_t param_bytes = 0;
+  std::shared_ptr<DgrWeights> W;
   LayerRun runs[23];
   std::map<std::string, DgrTensorRef> inter;
   uint64_t run_generation = 0;   // arena generation `runs` / `inter` point into
@@ -168,7 +190,7 @@ static int make_layer(dgr_net *net, const dgr_weight_desc *descs, int nd, const 
     }
     DGR_HIP_CHECK(hipMalloc(&L.wb, pieces.size() * sizeof(uint16_t)));
     DGR_HIP_CHECK(hipMemcpy(L.wb, pieces.data(), pieces.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-    net->param_bytes += pieces.size() * sizeof(uint16_t);
+    net->W->param_bytes += pieces.size() * sizeof(uint16_t);
   } else {
   const int S = L.cin_pad / 8, NBLK = L.cout_pad / 32;
   const size_t per_k = (size_t)S * NBLK * 256;
@@ -189,7 +211,7 @@ static int make_layer(dgr_net *net, const dgr_weight_desc *descs, int nd, const 
   }
   DGR_HIP_CHECK(hipMalloc((void **)&L.w, tiled.size() * sizeof(float)));
   DGR_HIP_CHECK(hipMemcpy(L.w, tiled.data(), tiled.size() * sizeof(float), hipMemcpyHostToDevice));
-  net->param_bytes += tiled.size() * sizeof(float);
+  net->W->param_bytes += tiled.size() * sizeof(float);
   }
   if (net->D == 3 && K == 27 && L.cin_pad % 16 == 0 && cout % 32 == 0) {
     // second copy in v_mfma_f32_16x16x4_f32 operand order (conv_os.hip): W16[k][g][jb][lane][c]
@@ -210,7 +232,7 @@ static int make_layer(dgr_net *net, const dgr_weight_desc *descs, int nd, const 
     }
     DGR_HIP_CHECK(hipMalloc((void **)&L.w16, t16.size() * sizeof(float)));
     DGR_HIP_CHECK(hipMemcpy(L.w16, t16.data(), t16.size() * sizeof(float), hipMemcpyHostToDevice));
-    net->param_bytes += t16.size() * sizeof(float);
+    net->W->param_bytes += t16.size() * sizeof(float);
     if (cin % 32 == 0) {
       // WB[piece][k][s][jb][lane] = 8 bf16 = piece of W[k][32 s + 8 (lane >> 4) + e][16 jb + (lane & 15)]
       const int S32 = cin / 32;
@@ -232,7 +254,7 @@ static int make_layer(dgr_net *net, const dgr_weight_desc *descs, int nd, const 
       }
       DGR_HIP_CHECK(hipMalloc(&L.w16b, pcs.size() * sizeof(uint16_t)));
       DGR_HIP_CHECK(hipMemcpy(L.w16b, pcs.data(), pcs.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-      net->param_bytes += pcs.size() * sizeof(uint16_t);
+      net->W->param_bytes += pcs.size() * sizeof(uint16_t);
       if (net->D == 3 && K == 27 && dgr_conv_dense_supported(cin, L.cin_pad, cout)) {
         // conv_dense.hip reads its weight operands straight from memory: the quad-coalesced gather hands lane (col, lq)
         // the channels 4 lq .. + 3 and 16 + 4 lq .. + 3 of a 32-channel step, so its 16-byte operand is half (lq & 1) of the
@@ -248,7 +270,7 @@ static int make_layer(dgr_net *net, const dgr_weight_desc *descs, int nd, const 
         }
         DGR_HIP_CHECK(hipMalloc(&L.w16d, pd.size() * sizeof(uint16_t)));
         DGR_HIP_CHECK(hipMemcpy(L.w16d, pd.data(), pd.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-        net->param_bytes += pd.size() * sizeof(uint16_t);
+        net->W->param_bytes += pd.size() * sizeof(uint16_t);
       }
     }
   }
@@ -276,7 +298,7 @@ static int make_layer(dgr_net *net, const dgr_weight_desc *descs, int nd, const 
     DGR_HIP_CHECK(hipMalloc((void **)&L.shift, cout * sizeof(float)));
     DGR_HIP_CHECK(hipMemcpy(L.shift, shift.data(), cout * sizeof(float), hipMemcpyHostToDevice));
   }
-  net->layers.push_back(L);
+  net->W->layers.push_back(L);
   return DGR_OK;
 }
 
@@ -291,6 +313,8 @@ extern "C" int dgr_net_create(dgr_ctx *ctx, int D, int in_channels, int out_chan
   DGR_HIP_CHECK(hipSetDevice(ctx->device));
   dgr_net *net = new dgr_net();
   net->ctx = ctx;
+  net->W = std::make_shared<DgrWeights>();
+  net->W->device = ctx->device;
   net->D = D; net->cin = in_channels; net->cout = out_channels;
   net->conv1_ks = conv1_kernel_size; net->normalize = normalize_feature;
   int k3 = 1, k1 = 1;
@@ -322,21 +346,25 @@ extern "C" int dgr_net_create(dgr_ctx *ctx, int D, int in_channels, int out_chan
 
 extern "C" void dgr_net_destroy(dgr_net *net) {
   if (!net) return;
-  (void)hipDeviceSynchronize();
-  for (auto &l : net->layers) {
-    if (l.w) (void)hipFree(l.w);
-    if (l.w16) (void)hipFree(l.w16);
-    if (l.wb) (void)hipFree(l.wb);
-    if (l.wc) (void)hipFree(l.wc);
-    if (l.w16b) (void)hipFree(l.w16b);
-    if (l.w16d) (void)hipFree(l.w16d);
-    if (l.shift) (void)hipFree(l.shift);
-  }
-  delete net;
+  delete net;   // the weights go with their last sharer (DgrWeights::~DgrWeights synchronises the device first)
 }
 
-extern "C" int64_t dgr_net_param_bytes(const dgr_net *net) { return net ? net->param_bytes : 0; }
-extern "C" int dgr_net_num_layers(const dgr_net *net) { return net ? (int)net->layers.size() : 0; }
+extern "C" int dgr_net_share(dgr_ctx *ctx, const dgr_net *src, dgr_net **out) {
+  DGR_REQUIRE(ctx && src && out, "dgr_net_share: NULL argument");
+  DGR_REQUIRE(ctx->device == src->W->device, "dgr_net_share: the weights live on device %d, the context on device %d",
+              src->W->device, ctx->device);
+  dgr_net *net = new dgr_net();
+  net->ctx = ctx;
+  net->D = src->D; net->cin = src->cin; net->cout = src->cout;
+  net->conv1_ks = src->conv1_ks; net->normalize = src->normalize;
+  net->W = src->W;
+  *out = net;
+  return DGR_OK;
+}
+
+extern "C" int dgr_net_sharers(const dgr_net *net) { return net ? (int)net->W.use_count() : 0; }
+extern "C" int64_t dgr_net_param_bytes(const dgr_net *net) { return net ? net->W->param_bytes : 0; }
+extern "C" int dgr_net_num_layers(const dgr_net *net) { return net ? (int)net->W->layers.size() : 0; }
 
 // ------------------------------------------------------------------------------------------
 // forward
@@ -366,7 +394,7 @@ struct Fwd {
   // one conv: Y[pair] = in[pair_in] W[k] (MFMA), then out[o] = shift (+res) + sum of the row's Y rows
   int conv(int li, const Tensor &in, const DgrKernelMap *km, bool swapped, int lvl_in, int lvl_out,
            const Tensor &out, const Tensor *res) {
-    const DgrLayer &L = net->layers[li];
+    const DgrLayer &L = net->W->layers[li];
     const DgrCoordMap &cin_map = ms.cm[lvl_in], &cout_map = ms.cm[lvl_out];
     DgrConvLaunch a;
     a.in = in.ptr; a.in_ld = in.ld; a.in_relu = in.relu;
@@ -571,7 +599,7 @@ int dgr_resunet_forward_impl(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, 
         {&V4, 14, 128, n4, true}, {&U2, 16, 64, n2, false}, {&V2, 17, 64, n2, true}, {&U1, 19, 64, n1, false},
         {&V1, 20, 64, n1, true}};
     for (auto &e : sp) {
-      if (!net->layers[e.consumer].wb) continue;
+      if (!net->W->layers[e.consumer].wb) continue;
       e.t->split.channels = e.channels;
       e.t->split_only = e.middle;
       DGR_ALLOC(e.t->split.planes, A, unsigned char, (size_t)e.rows * 4 * e.channels);
@@ -601,7 +629,7 @@ int dgr_resunet_forward_impl(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, 
   int li = 0;
   // encoder
   if (conv1_fused) {                                                   // conv1 + norm1
-    const DgrLayer &L0 = net->layers[0];
+    const DgrLayer &L0 = net->W->layers[0];
     int32_t *pc;
     DGR_ALLOC(pc, A, int32_t, 1);
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -765,8 +793,8 @@ extern "C" int dgr_resunet_forward(dgr_ctx *ctx, dgr_net *net, const int32_t *co
 extern "C" int dgr_debug_conv_layer(dgr_ctx *ctx, dgr_net *net, int layer, const int32_t *coords, const float *in,
                                     int in_relu, int64_t N, float *out, dgr_stream stream_) {
   DGR_REQUIRE(ctx && net && coords && in && out && N > 0, "dgr_debug_conv_layer: bad argument");
-  DGR_REQUIRE(layer >= 0 && layer < (int)net->layers.size(), "layer %d out of range", layer);
-  const DgrLayer &L = net->layers[layer];
+  DGR_REQUIRE(layer >= 0 && layer < (int)net->W->layers.size(), "layer %d out of range", layer);
+  const DgrLayer &L = net->W->layers[layer];
   int k3 = 1;
   for (int d = 0; d < net->D; ++d) k3 *= 3;
   DGR_REQUIRE(L.K == k3 && L.cin >= 32, "dgr_debug_conv_layer: layer %s is not a 3^D conv with >= 32 input channels", L.name.c_str());
@@ -829,12 +857,12 @@ extern "C" int dgr_net_get_intermediate(dgr_ctx *ctx, dgr_net *net, const char *
 
 extern "C" int dgr_net_layer_stats(dgr_ctx *ctx, dgr_net *net, int layer, int64_t stats[8]) {
   DGR_REQUIRE(ctx && net && stats, "NULL argument");
-  DGR_REQUIRE(layer >= 0 && layer < (int)net->layers.size(), "layer %d out of range", layer);
+  DGR_REQUIRE(layer >= 0 && layer < (int)net->W->layers.size(), "layer %d out of range", layer);
   const LayerRun &r = net->runs[layer];
   DGR_REQUIRE(r.n_in && r.n_out, "run a forward first");
   DGR_REQUIRE(net->run_generation == ctx->arena.generation,
               "the kernel maps of the last forward are gone: a later call on this context reused its workspace");
-  const DgrLayer &L = net->layers[layer];
+  const DgrLayer &L = net->W->layers[layer];
   DGR_HIP_CHECK(hipDeviceSynchronize());
   int32_t n_in = 0, n_out = 0;
   DGR_HIP_CHECK(hipMemcpy(&n_in, r.n_in, sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -868,13 +896,13 @@ extern "C" int dgr_net_layer_stats(dgr_ctx *ctx, dgr_net *net, int layer, int64_
 // Kernel-tuning instrument; not part of the inference path.
 extern "C" int dgr_net_rerun_layer(dgr_ctx *ctx, dgr_net *net, int layer, int reps, float *gemm_ms, float *reduce_ms) {
   DGR_REQUIRE(ctx && net && gemm_ms && reduce_ms && reps > 0, "bad argument");
-  DGR_REQUIRE(layer >= 0 && layer < (int)net->layers.size(), "layer %d out of range", layer);
+  DGR_REQUIRE(layer >= 0 && layer < (int)net->W->layers.size(), "layer %d out of range", layer);
   const LayerRun &r = net->runs[layer];
   DGR_REQUIRE(r.n_in && r.n_out, "run a forward first");
   DGR_REQUIRE(net->run_generation == ctx->arena.generation,
               "the kernel maps of the last forward are gone: a later call on this context reused its workspace");
   DGR_REQUIRE(!r.fused_pairs, "layer %d ran fused with its neighbour search; not re-runnable", layer);
-  const DgrLayer &L = net->layers[layer];
+  const DgrLayer &L = net->W->layers[layer];
   hipEvent_t e0, e1, e2;
   DGR_HIP_CHECK(hipEventCreate(&e0)); DGR_HIP_CHECK(hipEventCreate(&e1)); DGR_HIP_CHECK(hipEventCreate(&e2));
   float tg = 0.f, tr = 0.f;

@@ -40,6 +40,7 @@ class ResUNet2:
         self._state = me_conventions.convert_state_dict(self._state, self.D, self.me_conventions['kernel_order'],
                                                         self.me_conventions['transposed_mirrored'])
         self._net = None
+        self._share = None
         return self
 
     def to(self, device):
@@ -59,8 +60,25 @@ class ResUNet2:
             raise NotImplementedError('libdgr_hip implements the inference path only (eval-mode batch norm)')
         return self.eval()
 
+    def share_weights(self, other):
+        """Use the device-resident weights of `other` (the same architecture, already loaded) instead of a copy of its
+        own: for one model object per HIP stream / library context over ONE weight set (dgr_net_share)."""
+        if (type(other), other.D, other.in_channels, other.out_channels, other.conv1_kernel_size) != \
+                (type(self), self.D, self.in_channels, self.out_channels, self.conv1_kernel_size):
+            raise ValueError('share_weights: the other model is a different network')
+        self.normalize_feature = other.normalize_feature
+        self._state = None
+        self._share = other
+        self._net = None
+        return self
+
     def _handle(self):
         if self._net is None:
+            share = getattr(self, '_share', None)
+            if share is not None:
+                self._net = ops.NetHandle(None, self.D, self.in_channels, self.out_channels, self.conv1_kernel_size,
+                                          self.normalize_feature, self.device, share_from=share._handle())
+                return self._net
             if self._state is None:
                 raise RuntimeError('load_state_dict() must be called before the first forward')
             self._net = ops.NetHandle(self._state, self.D, self.in_channels, self.out_channels,

@@ -54,13 +54,24 @@ def voxelize(xyz, voxel_size, batch_index=0, device='cuda'):
 
 # ----------------------------------------------------------------------------
 class NetHandle:
-    """Owns a dgr_net (weights resident in HBM)."""
+    """Owns a dgr_net (weights resident in HBM).  The state dict must already be in the library's kernel-offset
+    convention (include/dgr_hip.h at dgr_net_create; model/me_conventions.py converts a checkpoint written under
+    another reading -- `ResUNet2.load_state_dict` does that, this class and the C API do not)."""
 
     def __init__(self, state_dict, D, in_channels, out_channels, conv1_kernel_size,
-                 normalize_feature, device='cuda'):
+                 normalize_feature, device='cuda', share_from=None):
         lib = _lib.load()
         self.device = torch.device(device)
         self.D, self.cin, self.cout = D, in_channels, out_channels
+        if share_from is not None:
+            # a net object for the calling thread's context over the weights `share_from` already holds (dgr_net_share)
+            if (share_from.D, share_from.cin, share_from.cout) != (D, in_channels, out_channels):
+                raise ValueError('share_from is a different network')
+            h = vp()
+            with torch.cuda.device(self.device):
+                check(lib.dgr_net_share(get_ctx(self.device), share_from.handle, C.byref(h)))
+            self.handle = h
+            return
         keep, descs = [], []
         for name, t in state_dict.items():
             if name.endswith('num_batches_tracked'):
@@ -88,6 +99,11 @@ class NetHandle:
     @property
     def param_bytes(self):
         return _lib.load().dgr_net_param_bytes(self.handle)
+
+    @property
+    def sharers(self):
+        """Net objects (one per context) that hold this net's weight set."""
+        return _lib.load().dgr_net_sharers(self.handle)
 
     def forward(self, coords, feats):
         lib = _lib.load()

@@ -93,6 +93,14 @@ int dgr_net_create(dgr_ctx *ctx, int D, int in_channels, int out_channels, int c
                    dgr_net **out);
 void dgr_net_destroy(dgr_net *net);
 int64_t dgr_net_param_bytes(const dgr_net *net);
+/* A second net object bound to `ctx` (another context of the SAME device: one context per HIP stream / host thread)
+ * over the weights `src` already holds in HBM -- the equivalent of several Python threads calling one torch module in
+ * the reference (core/deep_global_registration.py:96-131 builds the models once).  The weights are immutable and
+ * reference-counted: they are freed when the last net sharing them is destroyed; per-forward state (kernel maps,
+ * intermediates) belongs to each net object.  dgr_net_sharers: how many net objects hold `net`'s weights;
+ * dgr_net_param_bytes reports the shared set's bytes (count it once per distinct weight set). */
+int dgr_net_share(dgr_ctx *ctx, const dgr_net *src, dgr_net **out);
+int dgr_net_sharers(const dgr_net *net);
 
 /* ---- sparse ResUNet forward: replaces ME.SparseTensor(feats, coordinates=coords) +
  * ResUNet2.forward (core/deep_global_registration.py:163-169, 210-217; model/resunet.py:598-649).

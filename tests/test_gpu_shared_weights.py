@@ -1,0 +1,49 @@
+"""One weight set per device for several contexts (dgr_net_share): a second `DeepGlobalRegistration` built with
+`share_weights_with` runs in its own library context / HIP stream over the FIRST object's device-resident weights --
+bitwise the same results, no second copy in HBM, and the weights outlive the object that loaded them."""
+import gc
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+VOXEL = 0.05
+
+
+def test_two_contexts_share_one_weight_set():
+    from deepglobalregistration_amd import _lib, synth
+    from deepglobalregistration_amd.core.deep_global_registration import DeepGlobalRegistration
+    dev = torch.device('cuda:0')
+    ck = synth.synth_checkpoint(seed=3, voxel_size=VOXEL, feat_conv1_kernel_size=5)
+    x0, x1, _ = synth.synth_pair(3, n_raw=5000)
+    a = DeepGlobalRegistration({'weights': ck, 'use_icp': False}, dev)
+    Ta = a.register(x0, x1)
+    la = a.last_logit.cpu().numpy().copy()
+    free_before = torch.cuda.mem_get_info(0)[0]
+    ctx2 = _lib.new_ctx(dev)
+    _lib.use_ctx(ctx2)
+    try:
+        with torch.cuda.stream(torch.cuda.Stream(dev)):
+            b = DeepGlobalRegistration({'weights': ck, 'use_icp': False, 'share_weights_with': a}, dev)
+            Tb = b.register(x0, x1)
+            lb = b.last_logit.cpu().numpy().copy()
+            torch.cuda.synchronize()
+            assert b.inlier_model._handle().sharers == 2 and b.fcgf_model._handle().sharers == 2
+            assert b.inlier_model._handle().param_bytes == a.inlier_model._handle().param_bytes > 5e8
+            # no second 0.9-GB weight copy: what the second object cost is its context's workspace only
+            grown = free_before - torch.cuda.mem_get_info(0)[0]
+            assert grown < a.inlier_model._handle().param_bytes / 2, grown
+            assert np.array_equal(la, lb) and np.array_equal(Ta, Tb)
+            # the loader goes away first: the weights stay with the remaining sharer
+            del a
+            gc.collect()
+            assert b.inlier_model._handle().sharers == 1
+            Tc = b.register(x0, x1)
+            assert np.array_equal(Tc, Tb)
+    finally:
+        _lib.use_ctx(None)
+    with pytest.raises(ValueError):
+        other = DeepGlobalRegistration({'weights': synth.synth_checkpoint(seed=3, voxel_size=VOXEL, feat_conv1_kernel_size=7),
+                                        'use_icp': False}, dev)
+        DeepGlobalRegistration({'weights': ck, 'use_icp': False, 'share_weights_with': other}, dev)
