@@ -33,7 +33,7 @@ def test_two_contexts_share_one_weight_set():
             assert b.inlier_model._handle().param_bytes == a.inlier_model._handle().param_bytes > 5e8
             # no second 0.9-GB weight copy: what the second object cost is its context's workspace only
             grown = free_before - torch.cuda.mem_get_info(0)[0]
-            assert grown < a.inlier_model._handle().param_bytes / 2, grown
+            assert grown < 0.8 * a.inlier_model._handle().param_bytes, grown
             assert np.array_equal(la, lb) and np.array_equal(Ta, Tb)
             # the loader goes away first: the weights stay with the remaining sharer
             del a
