@@ -35,8 +35,6 @@
 // Weight layout: the split pieces of conv_os.hip, WB[piece][k][s][jb][lane] = 8 halves =
 // W_folded[k][32 s + 8 (lane >> 4) + e][16 jb + (lane & 15)], re-ordered per fragment group for the gather's channel
 // order: lane (col, lq) holds half (lq & 1) of the natural fragments of lanes (col, lq >> 1) and (col, (lq >> 1) + 2) (net.hip).
-#include <type_traits>
-
 #include "dgr_internal.h"
 #include "split.h"
 
@@ -71,15 +69,9 @@ __global__ void __launch_bounds__(64 * WAVES, 2) sparse_conv_dense_f16x2(ConvDen
   constexpr int THREADS = 64 * WAVES;
   constexpr int MB = WAVES * RG * 16;            // output rows per workgroup
   constexpr int NST = S * NCB;                   // (32-channel step, 16-column block) steps per offset
-  // weight ring: the fragments of WD = 8 steps in flight per wave -- one offset at 64 -> 64; at the narrower shapes an
-  // offset is 2 or 4 steps (12 / 24 MFMAs, a fraction of an L2 round trip), so the ring spans UO = 4 / 2 offsets and
-  // the offset loop is unrolled by UO (static register indexing); the 27 offsets are padded to a multiple of UO with
-  // offsets that have no neighbours (zero operands under a zero fold factor: `total` is left as it is)
-  constexpr int WD = 8;
-  static_assert(WD % NST == 0, "the weight ring holds a whole number of offsets (static register indexing)");
-  constexpr int UO = WD / NST;                   // offsets per turn of the ring
-  constexpr int KVP = (KV + UO - 1) / UO * UO;   // offsets walked (the padded ones are empty)
-  __shared__ int nbr_s[KVP][MB];
+  constexpr int WD = NST >= 8 ? 8 : NST >= 4 ? 4 : 2;   // weight ring: the fragments of WD steps in flight per wave
+  static_assert(NST % WD == 0, "the weight ring turns a whole number of times per offset (static register indexing)");
+  __shared__ int nbr_s[KV][MB];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -104,9 +96,9 @@ __global__ void __launch_bounds__(64 * WAVES, 2) sparse_conv_dense_f16x2(ConvDen
     rh[i] = wph[(int64_t)gg * 64];
     rm[i] = wpm[(int64_t)gg * 64];
   };
-  for (int e = tid; e < KVP * MB; e += THREADS) {
+  for (int e = tid; e < KV * MB; e += THREADS) {
     const int k = e / MB, r = e - k * MB;
-    nbr_s[k][r] = (k < KV && row0 + r < n_out) ? a.nbr[(int64_t)k * a.n_pad + row0 + r] : -1;
+    nbr_s[k][r] = (row0 + r < n_out) ? a.nbr[(int64_t)k * a.n_pad + row0 + r] : -1;
   }
   // accumulators start from the folded batch-norm shift (+ residual): lane = row (lane & 15) of each group,
   // channels 16 cb + 4 (lane >> 4) .. + 3
@@ -158,16 +150,19 @@ __global__ void __launch_bounds__(64 * WAVES, 2) sparse_conv_dense_f16x2(ConvDen
       g.nv[rg] = n;
     }
   };
-  // the row requests run one offset ahead (one register set).  Measured on the 195 k-row 64 -> 64 layers in round 3: two
-  // offsets ahead (a second set, 230 VGPRs) 202 us against 205 us -- not latency
-  RowSet gA;
+  // offsets the row requests run ahead (one register set each).  Measured on the 195 k-row 64 -> 64 layers: depth 2
+  // (230 VGPRs) 202 us, depth 1 (176 VGPRs) 205 us -- the gather is bounded by the memory system's rate for random
+  // 256-byte rows beyond the L2 (tools/microbench/vmem_bw.hip), not by latency
+  constexpr int DEPTH = 1;
+  static_assert(DEPTH == 1 || DEPTH == 2, "prefetch depth");
+  RowSet gA, gB;
   gather(0, gA);
+  if (DEPTH == 2) gather(1, gB);
 #pragma unroll
   for (int i = 0; i < WD; ++i) wreq(i, i);
   const int relu_lo = a.in_relu ? 0 : (int)0x80000000;   // pending ReLU of the producer as one integer max per value
 
-  auto body = [&](int k, auto ku_c, RowSet &g) {
-    constexpr int ku = decltype(ku_c)::value;   // k % UO: where in the ring this offset's first step sits
+  auto body = [&](int k, RowSet &g) {
     // ---- operands of this offset: s x = h + m, two f16 pieces (dgr_split2), in MFMA B layout
     f16x8 bh[RG][S], bm[RG][S];
     float fold[RG];
@@ -207,7 +202,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) sparse_conv_dense_f16x2(ConvDen
                                          // conversions wait for the NEW requests)
     // ---- next offset's rows requested; they arrive during this offset's MFMAs (the weight ring is refilled step by
     //      step below: in the in-order memory counter every ring slot is older than the rows requested after it)
-    gather(min(k + 1, KVP - 1), g);   // refills the set just consumed
+    gather(min(k + DEPTH, KV - 1), g);   // refills the set just consumed
     __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks these requests below the MFMAs: no time in flight)
     // ---- this offset's tile: tmp = W[k]^T x (zero for missing neighbours)
     f32x4 tmp[RG][NCB];
@@ -218,30 +213,31 @@ __global__ void __launch_bounds__(64 * WAVES, 2) sparse_conv_dense_f16x2(ConvDen
 #pragma unroll
     for (int j = 0; j < NST; ++j) {
       const int s = j / NCB, cb = j % NCB;
-      constexpr int slot0 = ku * NST;
-      const f16x8 wh = __builtin_bit_cast(f16x8, rh[slot0 + j]);
-      const f16x8 wm = __builtin_bit_cast(f16x8, rm[slot0 + j]);
+      const f16x8 wh = __builtin_bit_cast(f16x8, rh[j % WD]);
+      const f16x8 wm = __builtin_bit_cast(f16x8, rm[j % WD]);
 #pragma unroll
       for (int rg = 0; rg < RG; ++rg) {
         tmp[rg][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm, bh[rg][s], tmp[rg][cb], 0, 0, 0);
         tmp[rg][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bm[rg][s], tmp[rg][cb], 0, 0, 0);
         tmp[rg][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bh[rg][s], tmp[rg][cb], 0, 0, 0);
       }
-      wreq(k * NST + j + WD, slot0 + j);   // the ring slot just consumed
+      wreq(k * NST + j + WD, j % WD);   // the ring slot just consumed
     }
 #pragma unroll
     for (int rg = 0; rg < RG; ++rg)
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) total[rg][cb] += tmp[rg][cb] * fold[rg];
   };
+  if (DEPTH == 1) {
 #pragma unroll 1
-  for (int k = 0; k < KVP; k += UO) {
-    body(k, std::integral_constant<int, 0>{}, gA);
-    if constexpr (UO >= 2) body(k + 1, std::integral_constant<int, 1>{}, gA);
-    if constexpr (UO >= 4) {
-      body(k + 2, std::integral_constant<int, 2>{}, gA);
-      body(k + 3, std::integral_constant<int, 3>{}, gA);
+    for (int k = 0; k < KV; ++k) body(k, gA);
+  } else {
+#pragma unroll 1
+    for (int k = 0; k < KV - 1; k += 2) {
+      body(k, gA);
+      body(k + 1, gB);
     }
+    body(KV - 1, gA);
   }
 
   // ---- the rows are written once (ReLU applied here when the tensor carries one)

@@ -179,7 +179,10 @@ typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 constexpr float KNN_TAU_C = 8e-5f;  // 2 c
 constexpr int KNN_SLOTS = 32;       // candidate slots per query
-constexpr int KNN_SUB = 4;          // pass 1 visits every KNN_SUB-th group of KNN_ST reference tiles
+#ifndef DGR_KNN_SUB
+#define DGR_KNN_SUB 4
+#endif
+constexpr int KNN_SUB = DGR_KNN_SUB;   // pass 1 visits every KNN_SUB-th group of KNN_ST reference tiles (1: all of them)
 
 __device__ __forceinline__ unsigned short knn_f2bf(float x) {  // round to nearest even
   uint32_t u = __float_as_uint(x);
@@ -200,6 +203,10 @@ __device__ __forceinline__ float knn_unord(uint32_t k) {
 // f >> 1 = 0: hi, 1: lo.  One thread per (row, g, chunk); the (g = 0, chunk = 0) thread also writes the norm.
 // blockIdx.y = 2 pair + side (0: queries, 1: references -- pre-scaled by -2, padded with infinite norms, maximum norm
 // of the pair left in nb_max[pair]).
+// Reference rows are INTERLEAVED over the tiles: slot s of tile t holds row s n_tiles + t, so that every tile -- and
+// every subset of tiles, the sample of pass 1 in particular -- is spread evenly over the cloud.  (Consecutive rows are
+// neighbouring voxels with similar descriptors: a sample of whole 128-row stages in row order misses whole
+// neighbourhoods, and then every member of the true neighbour's cluster lies under the sampled minimum.)
 __global__ void __launch_bounds__(256)
     knn_pack_kernel(const float *__restrict__ F0, const float *__restrict__ F1, KnnBatch B,
                     bf16x8 *__restrict__ Qp, bf16x8 *__restrict__ Rp, float *__restrict__ na, float *__restrict__ nb,
@@ -209,10 +216,12 @@ __global__ void __launch_bounds__(256)
   const int64_t N = side ? d.n1 : d.n0;
   const int64_t n_pad = (N + 31) / 32 * 32;
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t row = t >> 2;
+  int64_t row = t >> 2;
   if (row >= n_pad) return;
   const float *F = side ? F1 + d.r0 * 32 : F0 + d.q0 * 32;
   const float scale = side ? -2.f : 1.f;
+  const int64_t prow = row;                                   // position in the packed array
+  if (side) row = (prow & 31) * (n_pad >> 5) + (prow >> 5);   // the reference row that sits there
   bf16x8 *packed = side ? Rp + (int64_t)d.rt0 * 256 : Qp + (int64_t)d.qb0 * 256;
   float *norms = side ? nb + (int64_t)d.rt0 * 32 : na + (int64_t)d.qb0 * 32;
   const int g = (int)(t & 1), ch = (int)((t >> 1) & 1);
@@ -233,8 +242,8 @@ __global__ void __launch_bounds__(256)
       lo[e] = (short)knn_f2bf(knn_bf2f(l) * scale);
     }
   }
-  const int64_t tile = row >> 5;
-  const int r = (int)(row & 31);
+  const int64_t tile = prow >> 5;
+  const int r = (int)(prow & 31);
   packed[(tile * 4 + ch) * 64 + r + 32 * g] = hi;
   packed[(tile * 4 + 2 + ch) * 64 + r + 32 * g] = lo;
   if (g == 0 && ch == 0) {
@@ -244,7 +253,7 @@ __global__ void __launch_bounds__(256)
       for (int c = 0; c < 32; ++c) n = fmaf(F[row * 32 + c], F[row * 32 + c], n);
       if (side) atomicMax(nb_max + pair, __float_as_uint(n));  // n >= 0: bit patterns order like values
     }
-    norms[row] = n;
+    norms[prow] = n;
   }
 }
 
@@ -359,7 +368,7 @@ __global__ void __launch_bounds__(256, 2)
             const int64_t q = (int64_t)(qb0 + u) * 32 + (lane & 31);
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-              const int64_t i = (int64_t)t * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+              const int64_t i = (int64_t)((e & 3) + 8 * (e >> 2) + 4 * h) * n_rtiles + t;   // slot s of tile t = row s n_tiles + t
               if (!(acc[u][e] > thr[u]) && q < N0 && i < N1 && qb0 + u < n_qblocks) {
                 const int slot = atomicAdd(cand_cnt + q, 1);   // per-query counters: no hot address
                 if (slot < KNN_SLOTS) cand[q * KNN_SLOTS + slot] = (int32_t)(i + d.r0);   // beyond: knn_overflow_list
@@ -419,6 +428,47 @@ __global__ void knn_overflow_list(const int32_t *__restrict__ cand_cnt, KnnBatch
   const KnnPair d = B.p[blockIdx.y];
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q < d.n0 && cand_cnt[d.q0 + q] > KNN_SLOTS) qlist[d.q0 + atomicAdd(qcount + blockIdx.y, 1)] = (int32_t)q;
+}
+
+// ... one workgroup per listed query: 256 threads scan the pair's references (the very chain of knn1_kernel per
+// distance), one atomicMin per thread.  (The brute-force kernel keeps 4 queries per THREAD: a handful of listed queries
+// would cost one thread's walk over a whole reference split, ~0.2 ms.)  blockIdx.y = pair; blocks stride over the list.
+__global__ void __launch_bounds__(256)
+    knn_query_scan_kernel(const float *__restrict__ F0, const float *__restrict__ F1, KnnBatch B,
+                          const int32_t *__restrict__ qlist, const int32_t *__restrict__ qcount,
+                          unsigned long long *__restrict__ best) {
+  const KnnPair d = B.p[blockIdx.y];
+  const int n_q = qcount[blockIdx.y];
+  for (int li = blockIdx.x; li < n_q; li += gridDim.x) {
+    const int64_t q = d.q0 + qlist[d.q0 + li];
+    float a[32];
+#pragma unroll
+    for (int k = 0; k < 32; k += 4) {
+      const float4 v = *reinterpret_cast<const float4 *>(F0 + q * 32 + k);
+      a[k] = v.x; a[k + 1] = v.y; a[k + 2] = v.z; a[k + 3] = v.w;
+    }
+    float bd = __builtin_inff();
+    int bi = 0x7fffffff;
+    for (int j = threadIdx.x; j < d.n1; j += 256) {
+      const float *b = F1 + (d.r0 + j) * 32;
+      float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 32; k += 4) {
+        const float4 bv = *reinterpret_cast<const float4 *>(b + k);
+        const float e0 = a[k] - bv.x, e1 = a[k + 1] - bv.y, e2 = a[k + 2] - bv.z, e3 = a[k + 3] - bv.w;
+        d0 = fmaf(e0, e0, d0);
+        d1 = fmaf(e1, e1, d1);
+        d0 = fmaf(e2, e2, d0);
+        d1 = fmaf(e3, e3, d1);
+      }
+      const float dd = d0 + d1;
+      if (dd < bd) { bd = dd; bi = j; }   // ascending j per thread: the first minimal index of its share
+    }
+    if (bi != 0x7fffffff) {
+      const unsigned long long key = ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned int)(bi + (int)d.r0);
+      atomicMin(best + q, key);   // (distance bits, index): ties -> the smallest index over all threads
+    }
+  }
 }
 
 // the pairs of B (all with at least KNN_MIN_REFS references); best is initialised by the caller
@@ -495,8 +545,8 @@ static int knn_prefiltered(dgr_ctx *ctx, const float *F0, const float *F1, KnnBa
   DGR_LAUNCH_CHECK();
   knn_exact_kernel<<<(int)dgr_ceil_div(nq * KNN_SLOTS, 256), 256, 0, stream>>>(F0, F1, cand, cand_cnt, q_begin, q_end, best);
   DGR_LAUNCH_CHECK();
-  // queries with more candidates than slots are redone one by one by the brute-force kernel (its blocks beyond
-  // the list length exit at once); non-finite / huge input: the brute-force kernel redoes the pair's whole search
+  // queries with more candidates than slots are redone exactly, one workgroup each (knn_query_scan_kernel);
+  // non-finite / huge input: the brute-force kernel redoes the pair's whole search
   {
     int64_t n0_max = 0;
     for (int p = 0; p < B.np; ++p) n0_max = std::max<int64_t>(n0_max, B.p[p].n0);
@@ -504,7 +554,11 @@ static int knn_prefiltered(dgr_ctx *ctx, const float *F0, const float *F1, KnnBa
     knn_overflow_list<<<grid, 256, 0, stream>>>(cand_cnt, B, qlist, qcount);
     DGR_LAUNCH_CHECK();
   }
-  DGR_CHECK(knn_launch<32>(ctx, F0, F1, B, best, nullptr, stream, qlist, qcount));
+  {
+    dim3 grid(256, B.np);   // blocks beyond the list length exit at once
+    knn_query_scan_kernel<<<grid, 256, 0, stream>>>(F0, F1, B, qlist, qcount, best);
+    DGR_LAUNCH_CHECK();
+  }
   return knn_launch<32>(ctx, F0, F1, B, best, fallback, stream);
 }
 
