@@ -160,27 +160,30 @@ static int knn_launch(dgr_ctx *ctx, const float *F0, const float *F1, const KnnB
 //            carry their squared norm nb.
 //   pass 1   d~'(i,j) = nb_i - 2 (hi.hi + hi.lo + lo.hi)  on v_mfma_f32_32x32x16_bf16 (6 per 32 x 32
 //            block, accumulator initialised with nb through the C operand); per-query minimum m~_j -- over a SAMPLE of
-//            the reference tiles (every KNN_SUB-th; round 5): any upper bound of the true minimum will do for the
-//            threshold below, and the minimum over a quarter of the references has expected rank 4 among all of them.
+//            the reference tiles (every KNN_SUB-th stage; round 5): any upper bound of the true minimum will do for the
+//            threshold below, and the minimum over half of the references has expected rank 2 among all of them.
+//            Measured per 4-pair batch (BASELINE configs[1], one box): every stage 0.92 ms, every 2nd 0.83, every 4th
+//            1.16 -- the second pass slows down with the number of candidates it has to emit (0.52 -> 0.66 ms) and
+//            0.5-2 % of the queries overflow their slots, so the sampling stops paying at a half.
 //   pass 2   the same products for ALL tiles (identical bits where pass 1 ran); every (i, j) with d~' <= m~_j + tau_j
 //            goes to a candidate list.  tau_j = 2 c (na_j + max nb), c = 4e-5, bounds twice the worst-case
 //            difference between d~ and the f32 value the brute-force kernel computes (split residual
 //            3 * 2^-18, f32 accumulation of 96 products, f32 norms), so the brute-force
 //            arg-min -- including its first-index tie-break among equal f32 distances -- is always
-//            in the list (m~_j >= the true minimum of d~': the list only grows with the sampling, ~4 entries per query).
+//            in the list (m~_j >= the true minimum of d~': the list only grows with the sampling, ~2 entries per query).
 //   exact    one thread per candidate evaluates sum (a - b)^2 exactly like knn1_kernel and merges with
 //            the same 64-bit atomicMin key.
-// A query that collects more than KNN_SLOTS candidates (expected rank of the sample minimum 4, P(rank > 32) ~ 1e-4;
-// or many near-ties, e.g. repeated structure) is redone by the brute-force kernel through a device-side query list;
+// A query that collects more than KNN_SLOTS candidates (the sample minimum ranks low, or many near-ties, e.g. repeated
+// structure) is redone exactly by one workgroup (knn_query_scan_kernel) through a device-side query list;
 // a non-finite / huge feature makes the brute-force kernel, launched behind, redo the pair's whole search.  No host
 // round trip either way.
 // ------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 constexpr float KNN_TAU_C = 8e-5f;  // 2 c
-constexpr int KNN_SLOTS = 32;       // candidate slots per query
+constexpr int KNN_SLOTS = 16;       // candidate slots per query
 #ifndef DGR_KNN_SUB
-#define DGR_KNN_SUB 4
+#define DGR_KNN_SUB 2
 #endif
 constexpr int KNN_SUB = DGR_KNN_SUB;   // pass 1 visits every KNN_SUB-th group of KNN_ST reference tiles (1: all of them)
 
@@ -246,13 +249,18 @@ __global__ void __launch_bounds__(256)
   const int r = (int)(prow & 31);
   packed[(tile * 4 + ch) * 64 + r + 32 * g] = hi;
   packed[(tile * 4 + 2 + ch) * 64 + r + 32 * g] = lo;
+  // squared norm of the row: the four threads of a row (consecutive lanes) each sum their eight values, fixed order
+  float n = 0.f;
+  if (row < N) {
+    const float *src = F + row * 32 + 16 * ch + 8 * g;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) n = fmaf(src[e], src[e], n);
+  }
+  n += __shfl_xor(n, 1, 64);
+  n += __shfl_xor(n, 2, 64);
   if (g == 0 && ch == 0) {
-    float n = side ? __builtin_inff() : 0.f;   // padding rows: never a minimum / never a query
-    if (row < N) {
-      n = 0.f;
-      for (int c = 0; c < 32; ++c) n = fmaf(F[row * 32 + c], F[row * 32 + c], n);
-      if (side) atomicMax(nb_max + pair, __float_as_uint(n));  // n >= 0: bit patterns order like values
-    }
+    if (row >= N) n = side ? __builtin_inff() : 0.f;   // padding rows: never a minimum / never a query
+    else if (side) atomicMax(nb_max + pair, __float_as_uint(n));  // n >= 0: bit patterns order like values
     norms[prow] = n;
   }
 }

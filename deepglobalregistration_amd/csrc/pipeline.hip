@@ -247,6 +247,11 @@ extern "C" int dgr_register_batch(dgr_ctx *ctx, dgr_net *fcgf, dgr_net *inlier, 
   DGR_HIP_CHECK(hipMemcpyAsync(res.data(), res_dev, (size_t)npairs * sizeof(DgrRegResult), hipMemcpyDeviceToHost, stream));
   DGR_HIP_CHECK(hipStreamSynchronize(stream));
   DGR_CHECK(dgr_ctx_check_flag(ctx, stream));
+  for (int p = 0; p < npairs; ++p)
+    if (res[p].status == DGR_STATUS_EXCHANGE_TIMEOUT) {
+      dgr_set_error("registration of pair %d: the workgroups sharing the pair lost each other (exchange timed out)", p);
+      return DGR_EINTERNAL;
+    }
   for (int p = 0; p < npairs; ++p) {
     float *T = T_out + p * 16;
     const DgrRegResult &r = res[p];
