@@ -734,10 +734,63 @@ __global__ void __launch_bounds__(256)
   for (int q = 0; q < 8; ++q) dst[q] = f32x4{acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
 }
 
-int dgr_conv_small_cin(const float *in, int in_ld, int in_relu, int cin, const float *w_tiled, const float *shift,
-                       const DgrKernelMap &km, const int32_t *n_out_dev, int64_t n_out_cap, float *out, int out_ld,
-                       hipStream_t stream) {
+// Cin = 6 (the 'coords' features of the inlier net): a QUAD of lanes per output voxel, lane q of the quad computing output
+// channels 8 q .. 8 q + 7.  What the thread-per-voxel kernel above spends its time on is fetching W[k] -- 64 16-byte
+// loads per pair and thread, every lane of an instruction at another offset's kilobyte: 64 cache lines per
+// instruction through the CU's address path.  Here W[k] is stored quad-major (wq[k][i][q][4], i = 2 ci + half: the four
+// lanes of a quad read 64 CONTIGUOUS bytes per instruction, one request), 12 loads per pair and lane.  The fma chain of
+// a (pair, output channel) and the order of the pairs are those of the kernel above: bit-identical results.
+__global__ void __launch_bounds__(256)
+    conv_cin6_quad_kernel(const float *__restrict__ in, int in_ld, int in_relu, const float *__restrict__ wq,
+                          const float *__restrict__ shift, const int32_t *__restrict__ out_ptr,
+                          const int32_t *__restrict__ out_pos, const int32_t *__restrict__ pair_in,
+                          const uint16_t *__restrict__ pair_k, const int32_t *n_out_dev, float *__restrict__ out,
+                          int out_ld) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t o = t >> 2;
+  const int q = (int)(t & 3);
+  if (o >= *n_out_dev) return;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = shift ? shift[8 * q + e] : 0.f;
+  const int end = out_ptr[o + 1];
+  for (int j = out_ptr[o]; j < end; ++j) {
+    const int pos = out_pos[j];
+    const int row = pair_in[pos];
+    const f32x4 *wk = reinterpret_cast<const f32x4 *>(wq + (int64_t)pair_k[pos] * 192) + q;
+    float x[6];
+#pragma unroll
+    for (int ci = 0; ci < 6; ++ci) {
+      x[ci] = in[(int64_t)row * in_ld + ci];
+      if (in_relu) x[ci] = fmaxf(x[ci], 0.f);
+    }
+    float tt[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) tt[e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {   // ci = i / 2 ascending: per output channel the chain x0 w0, x1 w1, ... of the kernel above
+      const f32x4 wv = wk[4 * i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tt[4 * (i & 1) + e] = fmaf(x[i >> 1], wv[e], tt[4 * (i & 1) + e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += tt[e];
+  }
+  f32x4 *dst = reinterpret_cast<f32x4 *>(out + o * out_ld + 8 * q);
+  dst[0] = f32x4{acc[0], acc[1], acc[2], acc[3]};
+  dst[1] = f32x4{acc[4], acc[5], acc[6], acc[7]};
+}
+
+int dgr_conv_small_cin(const float *in, int in_ld, int in_relu, int cin, const float *w_tiled, const float *w_quad,
+                       const float *shift, const DgrKernelMap &km, const int32_t *n_out_dev, int64_t n_out_cap, float *out,
+                       int out_ld, hipStream_t stream) {
   DGR_REQUIRE(cin >= 1 && cin <= 8, "small-Cin conv: cin=%d", cin);
+  if ((out_ld & 3) == 0 && cin == 6 && w_quad) {
+    conv_cin6_quad_kernel<<<(int)dgr_ceil_div(n_out_cap * 4, 256), 256, 0, stream>>>(
+        in, in_ld, in_relu, w_quad, shift, km.out_ptr, km.out_pos, km.pair_in, km.pair_k, n_out_dev, out, out_ld);
+    DGR_LAUNCH_CHECK();
+    return DGR_OK;
+  }
   if ((out_ld & 3) == 0 && (cin == 6 || cin == 1)) {   // the inlier net's input widths ('coords' / 'ones' features)
     const int rb = (int)dgr_ceil_div(n_out_cap, 256);
     if (cin == 6)

@@ -217,9 +217,9 @@ int dgr_reduce_rows(const float *y, int cout, const int32_t *ptr, const int32_t 
                     int64_t n_cap, float *out, int out_ld, const float *shift, const float *res, int res_ld,
                     int res_relu, hipStream_t stream, const DgrSplitRows *split = nullptr, int out_relu = 0);
 // output-stationary conv for Cin <= 8, Cout == 32 (conv1): no product rows, no reduction pass
-int dgr_conv_small_cin(const float *in, int in_ld, int in_relu, int cin, const float *w_tiled, const float *shift,
-                       const DgrKernelMap &km, const int32_t *n_out_dev, int64_t n_out_cap, float *out, int out_ld,
-                       hipStream_t stream);
+int dgr_conv_small_cin(const float *in, int in_ld, int in_relu, int cin, const float *w_tiled, const float *w_quad,
+                       const float *shift, const DgrKernelMap &km, const int32_t *n_out_dev, int64_t n_out_cap, float *out,
+                       int out_ld, hipStream_t stream);
 // output-stationary fused conv (conv_os.hip): out[o] = shift (+ res[o]) + sum_k in[nbr[k][o]] W[k], ascending k,
 // accumulated in LDS -- no product rows, no reduction pass.  w16 = the layer's weights in 16x16x4 fragment order.
 struct DgrConvOsLaunch {

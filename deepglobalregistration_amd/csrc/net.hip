@@ -34,6 +34,7 @@ struct DgrLayer {
   void *w16d = nullptr;    // device, the pieces once more in the channel order of the dense-tile kernel's gather (conv_dense.hip)
   int64_t w16b_piece = 0;
   float *wc = nullptr;     // device, conv1 weights in the operand order of conv1_grid_mfma (3-D conv1 with one input channel)
+  float *wq = nullptr;     // device, conv1 weights quad-major for conv_cin6_quad_kernel (6-D conv1 with six input channels)
   void *wb = nullptr;      // device, two f16 pieces in 32x32x16 fragment order (wide layers, conv_wide.hip)
   int64_t wb_piece = 0;    // 16-byte units per piece
   int pieces = 2;          // wb / w16b: two f16 pieces of 2^e W; w_unscale = 2^-e
@@ -83,6 +84,7 @@ struct DgrWeights {
       if (l.w16) (void)hipFree(l.w16);
       if (l.wb) (void)hipFree(l.wb);
       if (l.wc) (void)hipFree(l.wc);
+      if (l.wq) (void)hipFree(l.wq);
       if (l.w16b) (void)hipFree(l.w16b);
       if (l.w16d) (void)hipFree(l.w16d);
       if (l.shift) (void)hipFree(l.shift);
@@ -294,6 +296,20 @@ static int make_layer(dgr_net *net, const dgr_weight_desc *descs, int nd, const 
     DGR_HIP_CHECK(hipMalloc((void **)&L.wc, wc.size() * sizeof(float)));
     DGR_HIP_CHECK(hipMemcpy(L.wc, wc.data(), wc.size() * sizeof(float), hipMemcpyHostToDevice));
   }
+  if (name == "conv1" && cin == 6 && cout == 32 && K > 1) {
+    // conv_cin6_quad_kernel (conv.hip): wq[k][i][q][e] = W[k][i / 2][8 q + 4 (i % 2) + e], batch norm folded in
+    std::vector<float> wq((size_t)K * 192);
+    for (int k = 0; k < K; ++k)
+      for (int i = 0; i < 12; ++i)
+        for (int q = 0; q < 4; ++q)
+          for (int e = 0; e < 4; ++e) {
+            const int ci = i >> 1, co = 8 * q + 4 * (i & 1) + e;
+            wq[(size_t)k * 192 + (i * 4 + q) * 4 + e] = kd->data[((size_t)k * cin + ci) * cout + co] * scale[co];
+          }
+    DGR_HIP_CHECK(hipMalloc((void **)&L.wq, wq.size() * sizeof(float)));
+    DGR_HIP_CHECK(hipMemcpy(L.wq, wq.data(), wq.size() * sizeof(float), hipMemcpyHostToDevice));
+    net->W->param_bytes += wq.size() * sizeof(float);
+  }
   if (has_shift) {
     DGR_HIP_CHECK(hipMalloc((void **)&L.shift, cout * sizeof(float)));
     DGR_HIP_CHECK(hipMemcpy(L.shift, shift.data(), cout * sizeof(float), hipMemcpyHostToDevice));
@@ -485,10 +501,10 @@ struct Fwd {
     }
     const bool small_cin = km && !swapped && !res && L.cin <= 8 && L.cout == 32 && L.cin_pad == 8;
     // (Cin = 6 / 1 -- the inlier net's two input widths -- run the thread-per-voxel variant, conv.hip)
-    const char *kname = (L.cin == 6 || L.cin == 1) ? "conv_small_cin_row_kernel" : "conv_small_cin_kernel";
+    const char *kname = (L.cin == 6 && L.wq) ? "conv_cin6_quad_kernel" : L.cin == 1 ? "conv_small_cin_row_kernel" : "conv_small_cin_kernel";
     const bool wide = L.wb && km;
     if (small_cin)
-      DGR_CHECK(dgr_conv_small_cin(in.ptr, in.ld, in.relu, L.cin, L.w, L.shift, *km, cout_map.n_dev, cout_map.n_cap,
+      DGR_CHECK(dgr_conv_small_cin(in.ptr, in.ld, in.relu, L.cin, L.w, L.wq, L.shift, *km, cout_map.n_dev, cout_map.n_cap,
                                    out.ptr, out.ld, stream));
     else if (wide) {
       DGR_REQUIRE(in.split.planes, "layer %s: the wide-layer kernel needs its input as split rows", L.name.c_str());
@@ -911,7 +927,7 @@ extern "C" int dgr_net_rerun_layer(dgr_ctx *ctx, dgr_net *net, int layer, int re
     if (r.os)
       DGR_CHECK(dgr_conv_os_launch(r.os_launch, nullptr));
     else if (r.small_cin)
-      DGR_CHECK(dgr_conv_small_cin(r.launch.in, r.launch.in_ld, r.launch.in_relu, L.cin, L.w, L.shift, r.km, r.n_out,
+      DGR_CHECK(dgr_conv_small_cin(r.launch.in, r.launch.in_ld, r.launch.in_relu, L.cin, L.w, L.wq, L.shift, r.km, r.n_out,
                                    r.n_out_cap, r.launch.out, r.launch.out_ld, nullptr));
     else if (L.wb && r.has_reduce)
       DGR_CHECK(dgr_conv_wide_launch(r.launch, r.split_in, L.wb, L.wb_piece, L.w_unscale, ctx->num_cus, nullptr));

@@ -35,7 +35,7 @@ constexpr int REG_WAVES = REG_THREADS / 64;
 
 constexpr int REG_CLMAX = 8;      // workgroups per pair at most
 constexpr int REG_XG = 34;        // granules a member publishes per exchange (17 doubles)
-constexpr int REG_SPIN_LIMIT = 4000000;   // polls of one granule before the kernel gives up (seconds; see reg_poll)
+constexpr int REG_SPIN_LIMIT = 4000000;   // polls of one granule before the kernel gives up (seconds; see reg_poll2)
 // workgroups that share a pair: by its row count only (batch-invariant results)
 #ifndef DGR_REG_CLUSTER_MAX   // (build-time A/B: -DDGR_REG_CLUSTER_MAX=1 is the one-workgroup kernel of round 4)
 #define DGR_REG_CLUSTER_MAX REG_CLMAX
@@ -125,18 +125,20 @@ __device__ __forceinline__ void block_sum_butterfly(const double (&vin)[NV], dou
   }
 }
 
-__device__ __forceinline__ uint32_t reg_poll(const unsigned long long *p, uint32_t tag, int &fail) {
-  unsigned long long v;
+// both words of a published double: the two granules are requested together, until both carry the tag
+__device__ __forceinline__ double reg_poll2(const unsigned long long *p, uint32_t tag, int &fail) {
+  unsigned long long v0, v1;
   int spins = 0;
   for (;;) {
-    v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if ((uint32_t)(v >> 32) == tag) break;
+    v0 = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    v1 = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if ((uint32_t)(v0 >> 32) == tag && (uint32_t)(v1 >> 32) == tag) break;
     // the members of a cluster are consecutive workgroups of one launch and become resident together; the limit only
     // turns a broken assumption into an error code instead of a hang
     if (++spins > REG_SPIN_LIMIT) { fail = 1; break; }
     __builtin_amdgcn_s_sleep(2);
   }
-  return (uint32_t)v;
+  return __longlong_as_double((long long)((v1 << 32) | (v0 & 0xffffffffull)));
 }
 
 // Cluster-wide sum of the NV workgroup totals tot[0 .. NV) (LDS, written before the last barrier): every thread of
@@ -158,9 +160,8 @@ __device__ __forceinline__ void cluster_sum(const double *tot, int CL, int j, un
   if (tid < CL * NV) {
     const int jj = tid / NV, i = tid - jj * NV;
     int fail = 0;
-    const uint32_t lo = reg_poll(buf + jj * REG_XG + 2 * i, seq, fail);
-    const uint32_t hi = reg_poll(buf + jj * REG_XG + 2 * i + 1, seq, fail);
-    xl[jj * 17 + i] = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    // (this member's own totals come back the same way: `tot` is another wave's LDS write, with no barrier in between)
+    xl[jj * 17 + i] = reg_poll2(buf + jj * REG_XG + 2 * i, seq, fail);
     if (fail) *fail_s = 1;
   }
   __syncthreads();

@@ -9,7 +9,7 @@ import json
 import sqlite3
 import sys
 
-LAYER_KERNELS = ('sparse_conv_mfma', 'conv_small_cin_kernel', 'conv_small_cin_row_kernel', 'identity_conv_kernel', 'conv1_grid_kernel', 'conv1_grid_mfma', 'conv1_probe_kernel')
+LAYER_KERNELS = ('sparse_conv_mfma', 'conv_small_cin_kernel', 'conv_small_cin_row_kernel', 'conv_cin6_quad_kernel', 'identity_conv_kernel', 'conv1_grid_kernel', 'conv1_grid_mfma', 'conv1_probe_kernel')
 
 
 def sums(db, counter):
