@@ -74,7 +74,8 @@ SIGNATURES = {
     'dgr_icp_point_to_point': (C.c_int, [vp, vp, C.c_int64, vp, C.c_int64, C.c_double, c_f64p, C.c_int, C.c_double,
                                           C.c_double, c_f64p, c_f64p, vp]),
     'dgr_ransac_correspondence': (C.c_int, [vp, vp, vp, C.c_int64, C.c_double, C.c_int64, C.c_uint32, c_f64p, c_f64p, vp]),
-    'dgr_ctx_stage_times': (C.c_int, [vp, c_f32p, C.c_int, C.POINTER(C.c_int)]),
+    'dgr_ctx_stage_times': (C.c_int, [vp, c_f32p]),
+    'dgr_ctx_stage_times_v2': (C.c_int, [vp, c_f32p, C.c_int, C.POINTER(C.c_int)]),
     'dgr_ctx_conv_launches': (C.c_int64, [vp]),
     'dgr_ctx_conv_launch_times': (C.c_int, [vp, c_f32p, c_f32p, C.c_int64, C.POINTER(C.c_int64)]),
     'dgr_ctx_conv_launch_kinds': (C.c_int, [vp, C.c_char_p, C.c_int64, C.POINTER(C.c_int64)]),

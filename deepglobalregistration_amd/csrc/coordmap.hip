@@ -364,16 +364,37 @@ __global__ void bucket_count_kernel(const int32_t *__restrict__ keys4, const int
 // entry of a bucket: the row's SECOND half (x1, y1, z1) and the row itself, contiguous per bucket -- the kernel-map search
 // scans a bucket's entries with sequential 16-byte reads instead of an index read + a dependent coordinate read per row.
 // Coarse levels (`coords_new` given) are RENUMBERED on the way: the row's position in bucket order becomes its row number
-// (dgr_build_half_buckets below): its coordinates move there, canon[new] = old, inv[old] = new.
+// (dgr_build_half_buckets below): its coordinates move there, canon[new] = old, inv[old] = new; inside a bucket the
+// rows keep their original order (`members`), so the numbering does not depend on the order the atomics were served in.
+// Renumbered levels: the members of every bucket first (in whatever order the atomics hand out), so that the fill can
+// RANK a row among its bucket's members by row number -- the new numbering is then the same in every run (pair lists,
+// product rows and everything a LayerRun keeps of a coarse level are reproducible), at one short extra pass: a bucket
+// has one member at the finest level and tens to hundreds at stride 8.
+__global__ void bucket_members_kernel(const int32_t *__restrict__ row_bucket, const int32_t *n_dev,
+                                      const int32_t *__restrict__ start, int32_t *cursor, int32_t *__restrict__ members) {
+  int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= *n_dev) return;
+  const int b = row_bucket[r];
+  members[start[b] + atomicAdd(&cursor[b], 1)] = (int32_t)r;
+}
+
 __global__ void bucket_fill_kernel(const int32_t *__restrict__ row_bucket, const int32_t *n_dev,
                                    const int32_t *__restrict__ start, int32_t *cursor,
+                                   const int32_t *__restrict__ members,
                                    const int32_t *__restrict__ coords7, int4 *__restrict__ second,
                                    int32_t *__restrict__ coords_new, int32_t *__restrict__ canon, int32_t *__restrict__ inv) {
   int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= *n_dev) return;
   const int b = row_bucket[r];
   const int32_t *c = coords7 + r * 7;
-  const int p = start[b] + atomicAdd(&cursor[b], 1);   // order inside a bucket is irrelevant
+  int p;
+  if (members) {   // deterministic: position = rank of the row number inside the bucket
+    int rank = 0;
+    for (int e = start[b], end = start[b + 1]; e < end; ++e) rank += members[e] < (int32_t)r;
+    p = start[b] + rank;
+  } else {
+    p = start[b] + atomicAdd(&cursor[b], 1);   // not renumbered: the order inside a bucket is never seen
+  }
   if (coords_new) {
 #pragma unroll
     for (int d = 0; d < 7; ++d) coords_new[(int64_t)p * 7 + d] = c[d];
@@ -488,8 +509,13 @@ int dgr_build_half_buckets(DgrArena &arena, DgrCoordMap *cm, DgrHalfBuckets *hb,
       max_cap = std::max<int64_t>(max_cap, rj.cap[nrj]);
       ++nrj;
     }
-    bucket_fill_kernel<<<grid_for(n), 256, 0, stream>>>(row_bucket[l], cm[l].n_dev, hb[l].start, cursor[l], cm[l].coords,
-                                                        hb[l].second, coords_new, canon, inv);
+    const int32_t *members = nullptr;
+    if (coords_new) {   // (rank[l] is free again: the bucket ranks went into the hash table)
+      bucket_members_kernel<<<grid_for(n), 256, 0, stream>>>(row_bucket[l], cm[l].n_dev, hb[l].start, cursor[l], rank[l]);
+      members = rank[l];
+    }
+    bucket_fill_kernel<<<grid_for(n), 256, 0, stream>>>(row_bucket[l], cm[l].n_dev, hb[l].start, cursor[l], members,
+                                                        cm[l].coords, hb[l].second, coords_new, canon, inv);
     if (coords_new) { cm[l].coords = coords_new; cm[l].canon = canon; }
     hb[l].built = true;
   }

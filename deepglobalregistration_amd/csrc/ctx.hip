@@ -14,7 +14,7 @@ void dgr_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *dgr_last_error(void) { return g_err; }
-extern "C" const char *dgr_version(void) { return "dgr_hip 0.2 (gfx950)"; }
+extern "C" const char *dgr_version(void) { return "dgr_hip 0.3 (gfx950)"; }
 
 // ------------------------------------------------------------------------------------------
 // arena: sized for 288 GB of HBM -- worst-case kernel-map capacities are reserved instead of
@@ -143,7 +143,15 @@ extern "C" int dgr_ctx_set_profiling(dgr_ctx *ctx, int enable) {
   return DGR_OK;
 }
 
-extern "C" int dgr_ctx_stage_times(dgr_ctx *ctx, float *times_ms, int capacity, int *n) {
+// the version-0.1 entry point under its old name and with its old meaning: exactly the first eight stage times into a bare
+// float[8] (a caller built against the 0.1 header keeps working and is never overrun)
+extern "C" int dgr_ctx_stage_times(dgr_ctx *ctx, float *times_ms) {
+  DGR_REQUIRE(ctx != nullptr && times_ms != nullptr, "bad argument");
+  memcpy(times_ms, ctx->stage_ms, (size_t)8 * sizeof(float));
+  return DGR_OK;
+}
+
+extern "C" int dgr_ctx_stage_times_v2(dgr_ctx *ctx, float *times_ms, int capacity, int *n) {
   DGR_REQUIRE(ctx != nullptr && times_ms != nullptr && capacity >= 0, "bad argument");
   static_assert(sizeof(ctx->stage_ms) == DGR_NUM_STAGE_TIMES * sizeof(float), "stage list and header disagree");
   const int m = capacity < DGR_NUM_STAGE_TIMES ? capacity : DGR_NUM_STAGE_TIMES;

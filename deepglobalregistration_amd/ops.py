@@ -378,7 +378,10 @@ def register_batch(fcgf, inlier, coords0, xyz0, off0, coords1, xyz1, off1, voxel
                    forced_logit=None, override_idx1=None, safeguard=False, use_icp=False, ransac_hypotheses=4000000,
                    ransac_seed=0):
     """Fused pipeline over a batch of voxelised pairs (dgr_register_batch).  Returns
-    T [npairs,4,4] float32, status [npairs] int32, stats [npairs,4] float32."""
+    T [npairs,4,4] float32, status [npairs] int32, stats [npairs,4] float32.  `status` is a CODE plus FLAG bits:
+    `status & _lib.STATUS_MASK` is 0 ok / 1 low confidence / 2 SVD failed / 3 safeguard (T from the RANSAC), and
+    `_lib.STATUS_FLAG_ICP_SKIPPED` (0x100) is OR-ed on when `use_icp` was asked for but the final ICP could not run on the
+    pair -- compare the masked code, not the raw word."""
     lib = _lib.load()
     dev = fcgf.device
     npairs = len(off0) - 1
@@ -437,7 +440,7 @@ def set_profiling(device, enable):
 def stage_times(device):
     t = (C.c_float * 16)()
     n = C.c_int(0)
-    check(_lib.load().dgr_ctx_stage_times(get_ctx(device), t, 16, C.byref(n)))
+    check(_lib.load().dgr_ctx_stage_times_v2(get_ctx(device), t, 16, C.byref(n)))
     names = ['fcgf', 'knn', 'inlier_inputs', 'inlier_net', 'registration', 'maps_3d', 'maps_6d', 'conv_kernels', 'o3d_steps']
     out = dict(zip(names, [float(v) for v in t[:n.value]]))
     out['conv_launches'] = int(_lib.load().dgr_ctx_conv_launches(get_ctx(device)))

@@ -257,10 +257,11 @@ int dgr_register_batch_output(dgr_ctx *ctx, int which, void *dst_dev, int64_t ca
  * maps_3d, maps_6d, conv_kernels_total, safeguard RANSAC + ICP steps (dgr_params.safeguard / use_icp)].  Synchronises. */
 int dgr_ctx_set_profiling(dgr_ctx *ctx, int enable);
 #define DGR_NUM_STAGE_TIMES 9
-/* writes min(capacity, DGR_NUM_STAGE_TIMES) values and the number written to *n (nullable).  (Versions before 0.2 took a
- * bare float[8] / float[9]: the explicit capacity is what keeps a caller built against an older header from being
- * overrun when the list grows.) */
-int dgr_ctx_stage_times(dgr_ctx *ctx, float *times_ms, int capacity, int *n);
+/* writes min(capacity, DGR_NUM_STAGE_TIMES) values and the number written to *n (nullable): the explicit capacity is
+ * what keeps a caller built against an older header from being overrun when the list grows. */
+int dgr_ctx_stage_times_v2(dgr_ctx *ctx, float *times_ms, int capacity, int *n);
+/* the version-0.1 entry point, kept under its name with its original contract: the first eight values into float[8] */
+int dgr_ctx_stage_times(dgr_ctx *ctx, float *times_ms);
 /* number of sparse-conv kernel launches covered by times_ms[7] */
 int64_t dgr_ctx_conv_launches(dgr_ctx *ctx);
 /* duration (ms) of every sparse-conv layer launch of the last profiled batch, in launch order (FCGF layers

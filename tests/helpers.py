@@ -132,3 +132,28 @@ def assert_iteration_matched(X, Y, w, tol=1e-4, **kw):
     else:
         assert abs(r['loss'] - r['loss_oracle']) <= 2e-3 * abs(r['loss_oracle']) + 1e-9, r
     return d, band
+
+
+def harness_dgr(config, device):
+    """`DeepGlobalRegistration` with the parity tests' hooks: `harness_matches(xyz0, xyz1, idx1) -> idx1` replaces matches
+    after the search ran, `harness_logits(xyz0, xyz1_matched, logit) -> logit` replaces logits after the inlier net ran
+    (device tensors in and out; None = the product's behaviour), intermediates kept.  The product class only has the two
+    identity extension points these override."""
+    from deepglobalregistration_amd import ops
+    from deepglobalregistration_amd.core.deep_global_registration import DeepGlobalRegistration
+
+    class HarnessDGR(DeepGlobalRegistration):
+        harness_matches = None
+        harness_logits = None
+
+        def _post_matching(self, xyz0, xyz1, corres_idx1):
+            if self.harness_matches is None:
+                return corres_idx1
+            return self.harness_matches(xyz0, xyz1, corres_idx1).long().reshape(-1)
+
+        def _post_inlier_prediction(self, xyz0, xyz1, corres_idx1, logit):
+            if self.harness_logits is None:
+                return logit
+            return self.harness_logits(xyz0, ops.gather_rows3(xyz1, corres_idx1), logit).float().reshape(-1, 1)
+
+    return HarnessDGR(dict(config, keep_intermediates=True), device)

@@ -16,7 +16,7 @@ def test_stated_convention_equals_converted_checkpoint():
     x0, x1, _ = synth.synth_pair(9, n_raw=4000)
 
     def run(ckpt, **keys):
-        dgr = DeepGlobalRegistration(dict({'weights': ckpt, 'use_icp': False, 'clip_weight_thresh': 0.0}, **keys), torch.device('cuda'))
+        dgr = DeepGlobalRegistration(dict({'weights': ckpt, 'use_icp': False, 'clip_weight_thresh': 0.0, 'keep_intermediates': True}, **keys), torch.device('cuda'))
         T = dgr.register(x0, x1)
         return T, dgr.last_logit.cpu().numpy().copy(), dgr.last_corres_idx1.cpu().numpy().copy(), dgr.last_wsum
 

@@ -55,8 +55,8 @@ def _gt_matches(T_gt, seed):
 
 
 def _dgr(ck, **cfg):
-    from deepglobalregistration_amd.core.deep_global_registration import DeepGlobalRegistration
-    return DeepGlobalRegistration(dict({'weights': ck, 'ransac_max_iteration': HYP, 'ransac_seed': 3}, **cfg), torch.device('cuda'))
+    from helpers import harness_dgr
+    return harness_dgr(dict({'weights': ck, 'ransac_max_iteration': HYP, 'ransac_seed': 3}, **cfg), torch.device('cuda'))
 
 
 @pytest.mark.parametrize('gt_share', [False, True])
@@ -192,7 +192,7 @@ def test_register_safeguard_equals_the_reference_run():
     g, ck = golden_case()
     o3 = golden_o3d()
     from deepglobalregistration_amd.core.deep_global_registration import DeepGlobalRegistration
-    dgr = DeepGlobalRegistration({'weights': ck, 'clip_weight_thresh': float(g['clip_weight_thresh']),
+    dgr = DeepGlobalRegistration({'weights': ck, 'clip_weight_thresh': float(g['clip_weight_thresh']), 'keep_intermediates': True,
                                   'ransac_max_iteration': int(o3['ransac_cap']), 'ransac_seed': int(o3['ransac_seed'])},
                                  torch.device('cuda'))
     T = dgr.register(o3['sg_xyz0'], o3['sg_xyz1'])

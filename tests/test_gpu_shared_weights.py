@@ -18,14 +18,14 @@ def test_two_contexts_share_one_weight_set():
     dev = torch.device('cuda:0')
     ck = synth.synth_checkpoint(seed=3, voxel_size=VOXEL, feat_conv1_kernel_size=5)
     x0, x1, _ = synth.synth_pair(3, n_raw=5000)
-    a = DeepGlobalRegistration({'weights': ck, 'use_icp': False}, dev)
+    a = DeepGlobalRegistration({'weights': ck, 'use_icp': False, 'keep_intermediates': True}, dev)
     Ta = a.register(x0, x1)
     la = a.last_logit.cpu().numpy().copy()
     ctx2 = _lib.new_ctx(dev)
     _lib.use_ctx(ctx2)
     try:
         with torch.cuda.stream(torch.cuda.Stream(dev)):
-            b = DeepGlobalRegistration({'weights': ck, 'use_icp': False, 'share_weights_with': a}, dev)
+            b = DeepGlobalRegistration({'weights': ck, 'use_icp': False, 'keep_intermediates': True, 'share_weights_with': a}, dev)
             Tb = b.register(x0, x1)
             lb = b.last_logit.cpu().numpy().copy()
             torch.cuda.synchronize()

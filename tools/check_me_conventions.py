@@ -43,7 +43,7 @@ def main():
         weights = torch.load(weights, map_location='cpu', weights_only=False)     # read once, convert four times
     rows = []
     for order, mirrored in itertools.product(mc.KERNEL_ORDERS, (False, True)):
-        dgr = DeepGlobalRegistration({'weights': weights, 'use_icp': False, 'me_kernel_order': order,
+        dgr = DeepGlobalRegistration({'weights': weights, 'use_icp': False, 'keep_intermediates': True, 'me_kernel_order': order,
                                       'me_transposed_mirrored': mirrored}, torch.device('cuda'))
         T = dgr.register(np.asarray(xyz0, np.float64), np.asarray(xyz1, np.float64))
         wsum, thr = dgr.last_wsum
