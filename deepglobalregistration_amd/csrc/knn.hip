@@ -174,14 +174,14 @@ static int knn_launch(dgr_ctx *ctx, const float *F0, const float *F1, const KnnB
 //   exact    one thread per candidate evaluates sum (a - b)^2 exactly like knn1_kernel and merges with
 //            the same 64-bit atomicMin key.
 // A query that collects more than KNN_SLOTS candidates (the sample minimum ranks low, or many near-ties, e.g. repeated
-// structure) is redone exactly by one workgroup (knn_query_scan_kernel) through a device-side query list;
+// structure) is redone exactly through a device-side query list (a few: knn_query_scan_kernel; many: knn1_kernel);
 // a non-finite / huge feature makes the brute-force kernel, launched behind, redo the pair's whole search.  No host
 // round trip either way.
 // ------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 constexpr float KNN_TAU_C = 8e-5f;  // 2 c
-constexpr int KNN_SLOTS = 16;       // candidate slots per query
+constexpr int KNN_SLOTS = 32;       // candidate slots per query (every 2nd stage sampled: at most 16 seen on the benchmark's features)
 #ifndef DGR_KNN_SUB
 #define DGR_KNN_SUB 2
 #endif
@@ -401,32 +401,42 @@ __global__ void __launch_bounds__(256, 2)
   }
 }
 
-// one thread per candidate slot of every query of the batch; candidates are rows of the concatenated F1
+// one thread per query of the batch walks its candidate slots (two on average); candidates are rows of the concatenated F1
 __global__ void __launch_bounds__(256)
     knn_exact_kernel(const float *__restrict__ F0, const float *__restrict__ F1, const int32_t *__restrict__ cand,
                      const int32_t *__restrict__ cand_cnt, int64_t q_begin, int64_t q_end,
                      unsigned long long *__restrict__ best) {
-  const int64_t t = q_begin * KNN_SLOTS + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t q = t / KNN_SLOTS;
-  const int slot = (int)(t % KNN_SLOTS);
-  if (q >= q_end || slot >= min(cand_cnt[q], KNN_SLOTS)) return;
-  const int i = cand[t];
-  const float *a = F0 + q * 32, *b = F1 + (int64_t)i * 32;
-  float d0 = 0.f, d1 = 0.f;  // the very chain of knn1_kernel
+  const int64_t q = q_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= q_end) return;
+  const int cnt = min(cand_cnt[q], KNN_SLOTS);
+  if (cnt <= 0) return;
+  float a[32];
 #pragma unroll
   for (int k = 0; k < 32; k += 4) {
-    const float4 av = *reinterpret_cast<const float4 *>(a + k), bv = *reinterpret_cast<const float4 *>(b + k);
-    const float e0 = av.x - bv.x, e1 = av.y - bv.y, e2 = av.z - bv.z, e3 = av.w - bv.w;
-    d0 = fmaf(e0, e0, d0);
-    d1 = fmaf(e1, e1, d1);
-    d0 = fmaf(e2, e2, d0);
-    d1 = fmaf(e3, e3, d1);
+    const float4 v = *reinterpret_cast<const float4 *>(F0 + q * 32 + k);
+    a[k] = v.x; a[k + 1] = v.y; a[k + 2] = v.z; a[k + 3] = v.w;
   }
-  const float d = d0 + d1;
-  if (d < __builtin_inff()) {
-    const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)i;
-    atomicMin(best + q, key);
+  unsigned long long key = ~0ull;
+  for (int slot = 0; slot < cnt; ++slot) {
+    const int i = cand[q * KNN_SLOTS + slot];
+    const float *b = F1 + (int64_t)i * 32;
+    float d0 = 0.f, d1 = 0.f;  // the very chain of knn1_kernel
+#pragma unroll
+    for (int k = 0; k < 32; k += 4) {
+      const float4 bv = *reinterpret_cast<const float4 *>(b + k);
+      const float e0 = a[k] - bv.x, e1 = a[k + 1] - bv.y, e2 = a[k + 2] - bv.z, e3 = a[k + 3] - bv.w;
+      d0 = fmaf(e0, e0, d0);
+      d1 = fmaf(e1, e1, d1);
+      d0 = fmaf(e2, e2, d0);
+      d1 = fmaf(e3, e3, d1);
+    }
+    const float d = d0 + d1;
+    if (d < __builtin_inff()) {   // (distance bits, index): the order of the slots does not matter
+      const unsigned long long k2 = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)i;
+      key = k2 < key ? k2 : key;
+    }
   }
+  if (key != ~0ull) atomicMin(best + q, key);
 }
 
 // queries that collected more candidates than slots (many near-ties): redone exactly by the brute-force kernel.
@@ -438,16 +448,24 @@ __global__ void knn_overflow_list(const int32_t *__restrict__ cand_cnt, KnnBatch
   if (q < d.n0 && cand_cnt[d.q0 + q] > KNN_SLOTS) qlist[d.q0 + atomicAdd(qcount + blockIdx.y, 1)] = (int32_t)q;
 }
 
-// ... one workgroup per listed query: 256 threads scan the pair's references (the very chain of knn1_kernel per
-// distance), one atomicMin per thread.  (The brute-force kernel keeps 4 queries per THREAD: a handful of listed queries
-// would cost one thread's walk over a whole reference split, ~0.2 ms.)  blockIdx.y = pair; blocks stride over the list.
+// ... SHORT lists (<= KNN_SCAN_MAX queries of a pair) by parallelism over the references: workgroup (x, pair) owns
+// the x-th of KNN_SCAN_SPLITS slices of the pair's references and, for every listed query in turn, evaluates its slice
+// one reference per thread (the very chain of knn1_kernel per distance), reduces the (distance bits, index) keys over
+// the workgroup and issues ONE atomicMin.  (The brute-force kernel keeps 4 queries per THREAD: a handful of listed
+// queries would cost it one thread's walk over a whole reference split, ~0.1-0.2 ms.)  Longer lists -- many near-ties,
+// e.g. repeated structure -- go to the brute-force kernel, which amortises its tiles over 1024 queries per workgroup.
+constexpr int KNN_SCAN_MAX = 64, KNN_SCAN_SPLITS = 16;
 __global__ void __launch_bounds__(256)
     knn_query_scan_kernel(const float *__restrict__ F0, const float *__restrict__ F1, KnnBatch B,
                           const int32_t *__restrict__ qlist, const int32_t *__restrict__ qcount,
                           unsigned long long *__restrict__ best) {
+  __shared__ unsigned long long wkey[4];
   const KnnPair d = B.p[blockIdx.y];
   const int n_q = qcount[blockIdx.y];
-  for (int li = blockIdx.x; li < n_q; li += gridDim.x) {
+  if (n_q <= 0 || n_q > KNN_SCAN_MAX) return;
+  const int per = (d.n1 + KNN_SCAN_SPLITS - 1) / KNN_SCAN_SPLITS;
+  const int j_begin = blockIdx.x * per, j_end = min(d.n1, j_begin + per);
+  for (int li = 0; li < n_q; ++li) {
     const int64_t q = d.q0 + qlist[d.q0 + li];
     float a[32];
 #pragma unroll
@@ -455,9 +473,8 @@ __global__ void __launch_bounds__(256)
       const float4 v = *reinterpret_cast<const float4 *>(F0 + q * 32 + k);
       a[k] = v.x; a[k + 1] = v.y; a[k + 2] = v.z; a[k + 3] = v.w;
     }
-    float bd = __builtin_inff();
-    int bi = 0x7fffffff;
-    for (int j = threadIdx.x; j < d.n1; j += 256) {
+    unsigned long long key = ~0ull;
+    for (int j = j_begin + (int)threadIdx.x; j < j_end; j += 256) {
       const float *b = F1 + (d.r0 + j) * 32;
       float d0 = 0.f, d1 = 0.f;
 #pragma unroll
@@ -470,13 +487,30 @@ __global__ void __launch_bounds__(256)
         d1 = fmaf(e3, e3, d1);
       }
       const float dd = d0 + d1;
-      if (dd < bd) { bd = dd; bi = j; }   // ascending j per thread: the first minimal index of its share
+      if (dd < __builtin_inff()) {
+        const unsigned long long k2 = ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned int)(j + (int)d.r0);
+        key = k2 < key ? k2 : key;   // (distance bits, index): equal distances -> the smallest index
+      }
     }
-    if (bi != 0x7fffffff) {
-      const unsigned long long key = ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned int)(bi + (int)d.r0);
-      atomicMin(best + q, key);   // (distance bits, index): ties -> the smallest index over all threads
+#pragma unroll
+    for (int s2 = 32; s2 > 0; s2 >>= 1) {
+      const unsigned long long o = __shfl_xor(key, s2, 64);
+      key = o < key ? o : key;
     }
+    if ((threadIdx.x & 63) == 0) wkey[threadIdx.x >> 6] = key;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned long long k3 = wkey[0];
+      for (int w = 1; w < 4; ++w) k3 = wkey[w] < k3 ? wkey[w] : k3;
+      if (k3 != ~0ull) atomicMin(best + q, k3);
+    }
+    __syncthreads();
   }
+}
+
+// brute-force kernel behind the LONG lists: its run flag per pair
+__global__ void knn_long_list_flags(const int32_t *__restrict__ qcount, int np, int32_t *__restrict__ flags) {
+  if ((int)threadIdx.x < np) flags[threadIdx.x] = qcount[threadIdx.x] > KNN_SCAN_MAX;
 }
 
 // the pairs of B (all with at least KNN_MIN_REFS references); best is initialised by the caller
@@ -508,11 +542,11 @@ static int knn_prefiltered(dgr_ctx *ctx, const float *F0, const float *F1, KnnBa
   DGR_ALLOC(nb, arena, float, (int64_t)n_rt * 32);
   DGR_ALLOC(mt, arena, uint32_t, nq);
   DGR_ALLOC(qlist, arena, int32_t, nq);
-  DGR_ALLOC(cand_cnt, arena, int32_t, nq + 3 * KNN_MAXP);   // + per pair: max nb bits, fallback flag, overflow count
+  DGR_ALLOC(cand_cnt, arena, int32_t, nq + 4 * KNN_MAXP);   // + per pair: max nb bits, fallback flag, overflow count, long-list flag
   DGR_ALLOC(cand, arena, int32_t, nq * KNN_SLOTS);
   nb_max = reinterpret_cast<uint32_t *>(cand_cnt + nq);
   int32_t *fallback = cand_cnt + nq + KNN_MAXP, *qcount = cand_cnt + nq + 2 * KNN_MAXP;
-  DGR_HIP_CHECK(hipMemsetAsync(cand_cnt, 0, (size_t)(nq + 3 * KNN_MAXP) * sizeof(int32_t), stream));
+  DGR_HIP_CHECK(hipMemsetAsync(cand_cnt, 0, (size_t)(nq + 4 * KNN_MAXP) * sizeof(int32_t), stream));
   DGR_HIP_CHECK(hipMemsetAsync(mt, 0xff, (size_t)nq * sizeof(uint32_t), stream));
   // per-query arrays are addressed by the row of the concatenated F0: shift them so that row q_begin is element 0
   mt -= q_begin; qlist -= q_begin; cand_cnt -= q_begin; cand -= q_begin * KNN_SLOTS;
@@ -551,7 +585,7 @@ static int knn_prefiltered(dgr_ctx *ctx, const float *F0, const float *F1, KnnBa
   DGR_CHECK(launch(knn_mfma_kernel<false>, KNN_SUB));
   DGR_CHECK(launch(knn_mfma_kernel<true>, 1));
   DGR_LAUNCH_CHECK();
-  knn_exact_kernel<<<(int)dgr_ceil_div(nq * KNN_SLOTS, 256), 256, 0, stream>>>(F0, F1, cand, cand_cnt, q_begin, q_end, best);
+  knn_exact_kernel<<<(int)dgr_ceil_div(nq, 256), 256, 0, stream>>>(F0, F1, cand, cand_cnt, q_begin, q_end, best);
   DGR_LAUNCH_CHECK();
   // queries with more candidates than slots are redone exactly, one workgroup each (knn_query_scan_kernel);
   // non-finite / huge input: the brute-force kernel redoes the pair's whole search
@@ -563,9 +597,12 @@ static int knn_prefiltered(dgr_ctx *ctx, const float *F0, const float *F1, KnnBa
     DGR_LAUNCH_CHECK();
   }
   {
-    dim3 grid(256, B.np);   // blocks beyond the list length exit at once
+    dim3 grid(KNN_SCAN_SPLITS, B.np);   // short lists (the normal case: empty)
     knn_query_scan_kernel<<<grid, 256, 0, stream>>>(F0, F1, B, qlist, qcount, best);
+    int32_t *long_flags = cand_cnt + q_begin + nq + 3 * KNN_MAXP;
+    knn_long_list_flags<<<1, 64, 0, stream>>>(qcount, B.np, long_flags);
     DGR_LAUNCH_CHECK();
+    DGR_CHECK(knn_launch<32>(ctx, F0, F1, B, best, long_flags, stream, qlist, qcount));   // long lists
   }
   return knn_launch<32>(ctx, F0, F1, B, best, fallback, stream);
 }
