@@ -69,6 +69,7 @@ SIGNATURES = {
                                  c_f32p, c_f32p, c_i32p, c_f32p, c_i32p, vp]),
     'dgr_register_batch': (C.c_int, [vp, vp, vp, vp, vp, c_i64p, vp, vp, c_i64p, C.c_int,
                                      C.POINTER(Params), vp, vp, c_f32p, c_i32p, c_f32p, vp]),
+    'dgr_register_batch_f64': (C.c_int, [vp, c_f64p, C.c_int64, c_i64p]),
     'dgr_register_batch_output': (C.c_int, [vp, C.c_int, vp, C.c_int64, c_i64p, vp]),
     'dgr_ctx_set_profiling': (C.c_int, [vp, C.c_int]),
     'dgr_icp_point_to_point': (C.c_int, [vp, vp, C.c_int64, vp, C.c_int64, C.c_double, c_f64p, C.c_int, C.c_double,

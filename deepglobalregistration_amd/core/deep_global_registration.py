@@ -294,5 +294,5 @@ class DeepGlobalRegistration:
             skip_refinement=skip_refinement, forced_logit=forced_logits, override_idx1=override_idx1,
             safeguard=safeguard, use_icp=icp, ransac_hypotheses=self.ransac_max_iteration,
             ransac_seed=self.ransac_seed)
-        T = T.astype(np.float64)
+        T = T.astype(np.float64)   # (already float64 when the safeguard / ICP stages ran: their results at full width)
         return T, status, stats

@@ -273,6 +273,7 @@ struct dgr_ctx {
   float stage_ms[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // [8] = the Open3D-equivalent steps of dgr_register_batch
   int64_t conv_launches = 0;  // conv kernel launches covered by stage_ms[7]
   DgrBatchOutputs last;
+  std::vector<double> last_T64;   // the transforms of the last dgr_register_batch in float64 (host), 16 per pair
   DgrEventPool events;
   // event spans recorded while profiling; resolved by dgr_ctx_collect_profile after a sync
   std::vector<std::pair<hipEvent_t, hipEvent_t>> conv_spans, gemm_spans, map3_spans, map6_spans;

@@ -270,6 +270,10 @@ extern "C" int dgr_register_batch(dgr_ctx *ctx, dgr_net *fcgf, dgr_net *inlier, 
       stats_out[p * 4 + 3] = r.wsum;
     }
   }
+  // the same transforms in float64 (the reference returns np.float64, :290-291, and Open3D's results are doubles): the
+  // network estimate is f32 arithmetic widened exactly; the RANSAC / ICP results below replace their pairs at full width
+  ctx->last_T64.assign((size_t)npairs * 16, 0.0);
+  for (int i = 0; i < npairs * 16; ++i) ctx->last_T64[i] = (double)T_out[i];
   ctx->last.ptr[0] = idx1;    ctx->last.numel[0] = n0;
   ctx->last.ptr[1] = logit;   ctx->last.numel[1] = n0;
   ctx->last.ptr[2] = weights; ctx->last.numel[2] = n0;
@@ -316,7 +320,10 @@ extern "C" int dgr_register_batch(dgr_ctx *ctx, dgr_net *fcgf, dgr_net *inlier, 
       DGR_HIP_CHECK(hipStreamSynchronize(stream));
       for (int p = 0; p < npairs; ++p)
         if (rs[p])
-          for (int i = 0; i < 16; ++i) T_out[p * 16 + i] = (float)rsh[(size_t)p * DGR_RANSAC_RESULT_DOUBLES + i];
+          for (int i = 0; i < 16; ++i) {
+            ctx->last_T64[(size_t)p * 16 + i] = rsh[(size_t)p * DGR_RANSAC_RESULT_DOUBLES + i];
+            T_out[p * 16 + i] = (float)rsh[(size_t)p * DGR_RANSAC_RESULT_DOUBLES + i];
+          }
       if (prm->use_icp) {
         std::vector<char> ran(npairs, 0);
         for (int p = 0; p < npairs; ++p) {
@@ -333,7 +340,10 @@ extern "C" int dgr_register_batch(dgr_ctx *ctx, dgr_net *fcgf, dgr_net *inlier, 
           if (!ran[p]) continue;
           double Td[16];
           dgr_icp_finish(&jobs[p], Td, nullptr);
-          for (int i = 0; i < 16; ++i) T_out[p * 16 + i] = (float)Td[i];
+          for (int i = 0; i < 16; ++i) {
+            ctx->last_T64[(size_t)p * 16 + i] = Td[i];
+            T_out[p * 16 + i] = (float)Td[i];
+          }
         }
       }
       return DGR_OK;
@@ -350,6 +360,18 @@ extern "C" int dgr_register_batch(dgr_ctx *ctx, dgr_net *fcgf, dgr_net *inlier, 
     DGR_HIP_CHECK(hipStreamSynchronize(stream));
     DGR_HIP_CHECK(hipEventElapsedTime(&ctx->stage_ms[8], tm.e[8][0], tm.e[8][1]));
     DGR_CHECK(dgr_ctx_collect_profile(ctx));
+  }
+  return DGR_OK;
+}
+
+extern "C" int dgr_register_batch_f64(dgr_ctx *ctx, double *T_out, int64_t capacity_pairs, int64_t *npairs) {
+  DGR_REQUIRE(ctx && npairs, "dgr_register_batch_f64: NULL argument");
+  const int64_t n = (int64_t)(ctx->last_T64.size() / 16);
+  DGR_REQUIRE(n > 0, "no dgr_register_batch has run on this ctx");
+  *npairs = n;
+  if (T_out) {
+    DGR_REQUIRE(capacity_pairs >= n, "destination buffer too small");
+    memcpy(T_out, ctx->last_T64.data(), (size_t)n * 16 * sizeof(double));
   }
   return DGR_OK;
 }

@@ -378,7 +378,8 @@ def register_batch(fcgf, inlier, coords0, xyz0, off0, coords1, xyz1, off1, voxel
                    forced_logit=None, override_idx1=None, safeguard=False, use_icp=False, ransac_hypotheses=4000000,
                    ransac_seed=0):
     """Fused pipeline over a batch of voxelised pairs (dgr_register_batch).  Returns
-    T [npairs,4,4] float32, status [npairs] int32, stats [npairs,4] float32.  `status` is a CODE plus FLAG bits:
+    T [npairs,4,4] (float32; float64 when the safeguard / ICP stages ran), status [npairs] int32, stats [npairs,4] float32.
+    `status` is a CODE plus FLAG bits:
     `status & _lib.STATUS_MASK` is 0 ok / 1 low confidence / 2 SVD failed / 3 safeguard (T from the RANSAC), and
     `_lib.STATUS_FLAG_ICP_SKIPPED` (0x100) is OR-ed on when `use_icp` was asked for but the final ICP could not run on the
     pair -- compare the masked code, not the raw word."""
@@ -395,7 +396,7 @@ def register_batch(fcgf, inlier, coords0, xyz0, off0, coords1, xyz1, off1, voxel
                       {'ones': 0, 'coords': 1}[inlier_feature_type], int(max_iter), int(max_break_count),
                       float(break_threshold_ratio), int(bool(skip_refinement)), int(bool(safeguard)),
                       int(ransac_hypotheses), int(ransac_seed) & 0xffffffff, int(bool(use_icp)))
-    T = np.empty((npairs, 16), np.float32)   # (float32 at the ABI; the ICP / RANSAC stages compute in float64 inside)
+    T = np.empty((npairs, 16), np.float32)   # (float32 at this entry point; float64 through dgr_register_batch_f64 below)
     status = np.empty(npairs, np.int32)
     stats = np.empty((npairs, 4), np.float32)
     fl = None
@@ -412,6 +413,13 @@ def register_batch(fcgf, inlier, coords0, xyz0, off0, coords1, xyz1, off1, voxel
                                  ptr(coords1), ptr(xyz1), o1, npairs, C.byref(prm), ptr(ov), ptr(fl),
                                  T.ctypes.data_as(_lib.c_f32p), status.ctypes.data_as(_lib.c_i32p),
                                  stats.ctypes.data_as(_lib.c_f32p), stream_ptr(dev.index)))
+    if safeguard or use_icp:
+        # the RANSAC / ICP stages compute in float64 like Open3D: fetch their results at full width (the reference's
+        # register() returns np.float64); without them the f32 estimate widens exactly either way
+        T64 = np.empty((npairs, 16), np.float64)
+        n = C.c_int64(0)
+        check(lib.dgr_register_batch_f64(get_ctx(dev), T64.ctypes.data_as(_lib.c_f64p), npairs, C.byref(n)))
+        return T64.reshape(npairs, 4, 4), status, stats
     return T.reshape(npairs, 4, 4), status, stats
 
 

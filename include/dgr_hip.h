@@ -251,6 +251,11 @@ int dgr_register_batch(dgr_ctx *ctx, dgr_net *fcgf, dgr_net *inlier, const int32
  * not NULL the data is copied (device to device, on `stream`) into dst_dev (capacity in bytes). */
 int dgr_register_batch_output(dgr_ctx *ctx, int which, void *dst_dev, int64_t capacity_bytes,
                               int64_t *numel, dgr_stream stream);
+/* The transforms of the last dgr_register_batch on this context as float64, HOST [npairs,16] (what the reference's
+ * register() returns, :290-291, 317-322: T is np.float64, Open3D's results are doubles).  The learned estimate is the f32
+ * result widened; a pair that went through the safeguard RANSAC or the final ICP carries that stage's float64 result,
+ * which dgr_register_batch's float T_out rounds.  T_out may be NULL (only *npairs is returned). */
+int dgr_register_batch_f64(dgr_ctx *ctx, double *T_out, int64_t capacity_pairs, int64_t *npairs);
 
 /* per-stage device time (ms, HIP events) of the last dgr_register_batch when profiling was
  * enabled with dgr_ctx_set_profiling(ctx, 1): [fcgf, knn, inlier_inputs, inlier_net, registration,

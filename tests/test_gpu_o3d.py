@@ -174,5 +174,7 @@ def test_register_equals_the_fused_call():
     xa, ca, _ = dgr.preprocess(x0)
     xb, cb, _ = dgr.preprocess(x1)
     Tf, status, _ = dgr.register_voxelized(ca, xa, [0, len(xa)], cb, xb, [0, len(xb)], safeguard=True, icp=True)
-    assert status.tolist() == [3 if dgr.last_status == 'safeguard' else 0]
-    assert np.abs(Tf[0] - T).max() < 1e-6          # the batched call returns float32 at the ABI
+    assert status.tolist() == [3 if dgr.last_status == 'safeguard' else 0]     # (code, no flag: the ICP ran)
+    # the fused call hands the float64 results of its RANSAC / ICP stages on (dgr_register_batch_f64): the same
+    # arithmetic as the step-by-step register() -- equal to rounding of the f32 -> f64 hand-over of the initial T
+    assert Tf.dtype == np.float64 and np.abs(Tf[0] - T).max() < 1e-9
