@@ -34,7 +34,8 @@ constexpr int REG_THREADS = DGR_REG_THREADS;
 constexpr int REG_WAVES = REG_THREADS / 64;
 
 constexpr int REG_CLMAX = 8;      // workgroups per pair at most
-constexpr int REG_XG = 34;        // granules a member publishes per exchange (17 doubles)
+constexpr int REG_XG = 64;        // granules of a member's slot per exchange buffer: 34 used (17 doubles), padded to 512 bytes
+                                  // so that the members' slots -- polled by every member -- do not share cache lines
 constexpr int REG_SPIN_LIMIT = 4000000;   // polls of one granule before the kernel gives up (seconds; see reg_poll2)
 // workgroups that share a pair: by its row count only (batch-invariant results)
 #ifndef DGR_REG_CLUSTER_MAX   // (build-time A/B: -DDGR_REG_CLUSTER_MAX=1 is the one-workgroup kernel of round 4)
