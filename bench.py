@@ -274,7 +274,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--pairs-per-step', type=int, default=4, help='pairs per batch (one dgr_register_batch)')
+    ap.add_argument('--pairs-per-step', type=int, default=6, help='pairs per batch (one dgr_register_batch); round 5: 6 '
+                    '(3 x 6 measured 365 pairs/s against 353 for 3 x 4 on one box, and every conv layer runs nearer its roofline)')
     ap.add_argument('--total-pairs', type=int, default=0, help='strong-scaling mode: this many pairs in total, dealt '
                     'over the ranks by cost; a step = one pass over all of them (BASELINE configs[3]: 512)')
     ap.add_argument('--n-raw', type=int, default=50000, help='raw points per fragment')
@@ -633,11 +634,13 @@ def main():
         # the same per-stream workload (tools/evidence.sh), committed under profiles/ -- not measurable from inside
         # this process; quoted only when kernel name and workload label match this run
         pmc, pmc_file = None, None
-        for cand in ('r04_dominant_pmc.json', 'r03_dominant_pmc.json'):
+        for cand in ('r05_dominant_pmc.json', 'r04_dominant_pmc.json'):
             ppath = os.path.join(ROOT, 'profiles', cand)
             if os.path.exists(ppath):
                 pj = json.load(open(ppath))
-                if dominant and pj.get('kernel') and pj['kernel'] in dominant['name'] and pj.get('workload') == cfg_label(args):
+                # (a launch covers one layer of a whole batch: the counters belong to a batch size)
+                if dominant and pj.get('kernel') and pj['kernel'] in dominant['name'] and \
+                        pj.get('workload') in (f'{cfg_label(args)}, {B} pairs per batch',) + ((cfg_label(args),) if B == 4 else ()):
                     pmc, pmc_file = pj, cand
                     break
         split = bool(dominant and 'f16x2' in dominant['name'])     # the dominant kernel issues on the f16 pipe
@@ -681,12 +684,13 @@ def main():
                          'pipe': 'dense f16 MFMA (v_mfma_f32_32x32x16_f16)' if split else 'f32 MFMA (v_mfma_f32_32x32x2_f32)',
                          'products_per_mac': products, 'algorithmic_tflops': alg,
                          'limited_by': 'not the matrix pipe: the memory system -- one gathered and one product KB per pair (rule-major '
-                                       'tiles of 64 pairs) are ~7.7 GB per launch through HBM / MALL at ~4.3 TB/s, against a measured '
-                                       '3.6-5.2 TB/s for random 256-byte rows; row order irrelevant (DESIGN.md 4.2)'
+                                       'tiles of 64 pairs) leave L2 at ~4.3 TB/s, against a measured 3.6-5.2 TB/s for random '
+                                       '256-byte rows; row order irrelevant (DESIGN.md 4.2)'
                                        if split else None,
                          'traffic': pmc.get('hbm_bytes_per_launch') if pmc else None,
                          'traffic_source': (f'profiles/{pmc_file}: separate rocprofv3 --pmc passes of the one-stream command, '
-                                            '2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, per launch') if pmc else None,
+                                            '2 x FETCH_SIZE (gfx950 correction, calibrated on a 2-GB read: profiles/r05_mall_probe_counters.txt) '
+                                            '+ WRITE_SIZE, per launch; L2 <-> fabric bytes: Infinity-Cache hits are counted') if pmc else None,
                          'mfma_busy_from_profiles': pmc.get('mfma_busy') if pmc else None,
                          'kernel': dominant['name'] if dominant else 'sparse conv (all variants)',
                          'launches_per_batch': dominant['launches_per_batch'] if dominant else n_launch,

@@ -24,12 +24,13 @@ def main():
                 dur.append(avg)
     per = {k: c[k] / max(1, disp[k]) for k in c}
     out = {'kernel': pat, 'workload': workload, 'dispatches_per_pass': disp,
-           'command': 'rocprofv3 --kernel-trace --pmc <set> -- python bench.py --streams 1 --pairs-per-step 4 --steps 2 '
-                      '--warmup 1 --no-parity (one pass per counter set, tools/evidence.sh)',
+           'command': 'rocprofv3 --kernel-trace --pmc <set> -- python bench.py --streams 1 --steps 2 --warmup 1 --no-parity '
+                      '[--pairs-per-step as the workload label says] (one pass per counter set, tools/evidence.sh)',
            'per_dispatch': per, 'avg_duration_us_profiled': sum(dur) / max(1, len(dur)) / 1e3}
     if 'FETCH_SIZE' in per and 'WRITE_SIZE' in per:
         out['hbm_bytes_per_launch'] = (2.0 * per['FETCH_SIZE'] + per['WRITE_SIZE']) * 1024.0
-        out['hbm_note'] = '2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, KB -> bytes'
+        out['hbm_note'] = ('2 x FETCH_SIZE (gfx950 correction; exact on a 2-GB streaming read, profiles/r05_mall_probe_counters.txt) + '
+                           'WRITE_SIZE, KB -> bytes; both count what crosses L2 <-> fabric, Infinity-Cache hits included')
     if 'SQ_VALU_MFMA_BUSY_CYCLES' in per and 'GRBM_GUI_ACTIVE' in per:
         cyc = per['GRBM_GUI_ACTIVE'] / 8.0
         out['active_cycles_per_xcd'] = cyc
