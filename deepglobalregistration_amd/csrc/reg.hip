@@ -48,6 +48,7 @@ __host__ __device__ inline int reg_cluster_size(int n) {
 
 struct RegArgs {
   unsigned long long *xbuf;   // [npairs][2][REG_CLMAX][REG_XG] exchange granules, zeroed before the launch
+  int pair_base;              // first pair of this launch (a batch is launched in slices, launch_registration)
   const float *xyz0, *xyz1;
   const int64_t *idx1;  // may be null: xyz1 is already gathered (row aligned with xyz0)
   const float *lw;      // logits (is_logit) or weights
@@ -272,7 +273,7 @@ __global__ void __launch_bounds__(REG_THREADS) registration_kernel(RegArgs a) {
   __shared__ double xl[REG_CLMAX * 17];   // the members' totals of one exchange
   __shared__ double wg_tot[17];           // this workgroup's totals, as published
   __shared__ int fail_s;
-  const int p = blockIdx.x / REG_CLMAX, cj = blockIdx.x % REG_CLMAX;   // pair, member of its cluster
+  const int p = a.pair_base + blockIdx.x / REG_CLMAX, cj = blockIdx.x % REG_CLMAX;   // pair, member of its cluster
   const int64_t r0 = a.off0[p];
   const int n = (int)(a.off0[p + 1] - r0);
   const int CL = reg_cluster_size(n);
@@ -562,9 +563,16 @@ __global__ void __launch_bounds__(REG_THREADS) registration_kernel(RegArgs a) {
   }
 }
 
-// needs 2 x float4 x total_rows of scratch; allocated by the callers below from the ctx arena
+// needs 2 x float4 x total_rows of scratch; allocated here from the ctx arena.
+// off0_host (nullable): the pairs' row offsets on the host, for slicing the batch.  The members of a cluster SPIN while
+// they wait for each other, and a member lands on the XCD its workgroup index selects -- exactly one member of an
+// 8-cluster per XCD.  Two such launches on different streams could fill each other's slots with spinners (an XCD holds
+// 64 workgroups of this kernel) if a launch carried dozens of clusters; a launch therefore carries at most
+// REG_MAX_SPINNERS members of multi-member clusters (8 pairs of 27 k rows: at most 8 of an XCD's 64 slots), the rest
+// of the batch follows in the next launch on the same stream.  Without the host offsets every pair counts as 8 members.
+constexpr int REG_MAX_SPINNERS = 64;
 static int launch_registration(dgr_ctx *ctx, const float *xyz0, const float *xyz1, const int64_t *idx1,
-                               const float *lw, int is_logit, float clip, const int64_t *off0_dev,
+                               const float *lw, int is_logit, float clip, const int64_t *off0_dev, const int64_t *off0_host,
                                int npairs, int64_t total_rows, float q, int max_iter, int max_break,
                                double ratio, int skip_refine, int gate, float eps, float *weights_out,
                                DgrRegResult *results_dev, hipStream_t stream) {
@@ -580,18 +588,30 @@ static int launch_registration(dgr_ctx *ctx, const float *xyz0, const float *xyz
   a.clip = clip; a.q = q; a.eps = eps;
   a.is_logit = is_logit; a.gate = gate; a.skip_refine = skip_refine;
   a.max_iter = max_iter; a.max_break = max_break; a.ratio = ratio;
-  // REG_CLMAX consecutive workgroups per pair; those beyond the pair's cluster size exit at once
-  registration_kernel<<<npairs * REG_CLMAX, REG_THREADS, 0, stream>>>(a);
-  DGR_LAUNCH_CHECK();
+  for (int p0 = 0; p0 < npairs;) {
+    int p1 = p0, spinners = 0;
+    while (p1 < npairs && p1 - p0 < 4096) {
+      const int cl = off0_host ? reg_cluster_size((int)(off0_host[p1 + 1] - off0_host[p1])) : REG_CLMAX;
+      const int add = cl > 1 ? cl : 0;
+      if (p1 > p0 && spinners + add > REG_MAX_SPINNERS) break;
+      spinners += add;
+      ++p1;
+    }
+    a.pair_base = p0;
+    // REG_CLMAX consecutive workgroups per pair; those beyond the pair's cluster size exit at once
+    registration_kernel<<<(p1 - p0) * REG_CLMAX, REG_THREADS, 0, stream>>>(a);
+    DGR_LAUNCH_CHECK();
+    p0 = p1;
+  }
   return DGR_OK;
 }
 
 int dgr_registration_launch_ctx(dgr_ctx *ctx, const float *xyz0, const float *xyz1, const int64_t *idx1,
                                 const float *lw, int is_logit, float clip, const int64_t *off0_dev,
-                                int npairs, int64_t total_rows, float q, int max_iter, int max_break,
+                                const int64_t *off0_host, int npairs, int64_t total_rows, float q, int max_iter, int max_break,
                                 double ratio, int skip_refine, int gate, float eps, float *weights_out,
                                 DgrRegResult *results_dev, hipStream_t stream) {
-  return launch_registration(ctx, xyz0, xyz1, idx1, lw, is_logit, clip, off0_dev, npairs, total_rows, q,
+  return launch_registration(ctx, xyz0, xyz1, idx1, lw, is_logit, clip, off0_dev, off0_host, npairs, total_rows, q,
                              max_iter, max_break, ratio, skip_refine, gate, eps, weights_out, results_dev,
                              stream);
 }
@@ -610,7 +630,7 @@ static int run_single(dgr_ctx *ctx, const float *X, const float *Y, const float 
   DGR_ALLOC(res, ctx->arena, DgrRegResult, 1);
   const int64_t h_off[2] = {0, N};
   DGR_HIP_CHECK(hipMemcpyAsync(off, h_off, sizeof(h_off), hipMemcpyHostToDevice, stream));
-  DGR_CHECK(launch_registration(ctx, X, Y, nullptr, w, 0, 0.f, off, 1, N, q, max_iter, max_break, ratio,
+  DGR_CHECK(launch_registration(ctx, X, Y, nullptr, w, 0, 0.f, off, h_off, 1, N, q, max_iter, max_break, ratio,
                                 skip_refine, 0, eps, nullptr, res, stream));
   DGR_HIP_CHECK(hipMemcpyAsync(host_res, res, sizeof(DgrRegResult), hipMemcpyDeviceToHost, stream));
   DGR_HIP_CHECK(hipStreamSynchronize(stream));
