@@ -135,6 +135,7 @@ __device__ __forceinline__ unsigned long long hit_pack(int k, int64_t o, int64_t
 // wave and places its pairs directly (positions depend on the bit matrix only).  Arena per output row: 0.9 KB
 // (symmetric maps) / 1.7 KB (strided maps).
 constexpr int KM_REGION = 512;
+constexpr int KM_JOBS6 = 8;   // kernel maps per multi-job launch of the 6-D builder (blockIdx.y = map)
 struct HitList {
   unsigned long long *recs;   // [waves][region]
   int32_t *wave_count;        // [waves]; -1: the region overflowed, replay the wave
@@ -227,9 +228,23 @@ __device__ __forceinline__ void pruned_search6(const PrunedArgs &a, int64_t t, E
   }
 }
 
+// The searches of ALL maps of a sparse tensor in one launch (round 5; round 4 launched map after map: seven grids of
+// 38-250 us each with their tails idle): blockIdx.y = map, blockIdx.x = the map's search block (surplus blocks of the
+// smaller maps exit at once).
+struct Bits6Jobs {
+  PrunedArgs pa[KM_JOBS6];
+  uint32_t *mask_out[KM_JOBS6], *mask_in[KM_JOBS6];
+  HitList hl[KM_JOBS6];
+  int blocks[KM_JOBS6];
+};
 __global__ void __launch_bounds__(KM_THREADS)
-    kmap_bits_pruned6(PrunedArgs a, int KW, uint32_t *mask_out, uint32_t *mask_in, HitList hl) {
+    kmap_bits_pruned6(Bits6Jobs J, int KW) {
   __shared__ int hit_cur[KM_THREADS / 64];
+  const int jm = blockIdx.y;
+  if ((int)blockIdx.x >= J.blocks[jm]) return;
+  const PrunedArgs a = J.pa[jm];
+  uint32_t *const mask_out = J.mask_out[jm], *const mask_in = J.mask_in[jm];
+  const HitList hl = J.hl[jm];
   hit_begin(hit_cur);
   const int wid = (int)(blockIdx.x * (KM_THREADS / 64) + (threadIdx.x >> 6));
   // (no early return: every wave leaves its record count behind)
@@ -256,11 +271,25 @@ __global__ void __launch_bounds__(KM_THREADS)
 // (offset, 256-row block) cell.  A pair's position = cell base (exclusive scan of counts) + the pairs of the earlier
 // groups of the same block (here) + its rank inside the group's ballot (place_pair).
 constexpr int KM_KMAX = 736;
+struct Colmask6Jobs {   // blockIdx.y = map, blockIdx.x = 256-row block of the map
+  const uint32_t *mask_out[KM_JOBS6];
+  const int32_t *n_out_dev[KM_JOBS6];
+  int RB[KM_JOBS6];
+  int4 *cell[KM_JOBS6];
+  int32_t *counts[KM_JOBS6], *row_cnt[KM_JOBS6];
+  unsigned short *wpre[KM_JOBS6];
+};
 __global__ void __launch_bounds__(KM_THREADS)
-    kmap_colmask(const uint32_t *__restrict__ mask_out, const int32_t *n_out_dev, int K, int KW, int RB,
-                 int4 *__restrict__ cell, int32_t *__restrict__ counts, int32_t *__restrict__ row_cnt,
-                 unsigned short *__restrict__ wpre) {
+    kmap_colmask(Colmask6Jobs J, int K, int KW) {
   __shared__ unsigned long long bal[KM_THREADS / 64][KM_KMAX];
+  const int jm = blockIdx.y;
+  const int RB = J.RB[jm];
+  if ((int)blockIdx.x >= RB) return;
+  const uint32_t *__restrict__ mask_out = J.mask_out[jm];
+  const int32_t *n_out_dev = J.n_out_dev[jm];
+  int4 *__restrict__ cell = J.cell[jm];
+  int32_t *__restrict__ counts = J.counts[jm], *__restrict__ row_cnt = J.row_cnt[jm];
+  unsigned short *__restrict__ wpre = J.wpre[jm];
   const int rb = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n_out = *n_out_dev;
@@ -329,10 +358,23 @@ __device__ __forceinline__ void place_pair(const PlaceArgs &p, int k, int64_t o,
 
 // one wave per region of the hit list: one lane per record places the pair; a wave whose region overflowed during the
 // search (count -1) repeats that wave's search and places what it finds
+struct Place6Jobs {   // blockIdx.y = map; the map's blocks stride over its hit-list regions
+  HitList h[KM_JOBS6];
+  PlaceArgs p[KM_JOBS6];
+  PrunedArgs replay[KM_JOBS6];
+  int n_waves[KM_JOBS6], blocks[KM_JOBS6];
+};
 __global__ void __launch_bounds__(KM_THREADS)
-    kmap_place_hits(HitList h, int n_waves, PlaceArgs p, PrunedArgs replay) {
+    kmap_place_hits(Place6Jobs J) {
+  const int jm = blockIdx.y;
+  const int nblk = J.blocks[jm];
+  if ((int)blockIdx.x >= nblk) return;
+  const HitList h = J.h[jm];
+  const PlaceArgs p = J.p[jm];
+  const PrunedArgs replay = J.replay[jm];
+  const int n_waves = J.n_waves[jm];
   const int lane = threadIdx.x & 63;
-  for (int r = blockIdx.x * (KM_THREADS / 64) + (threadIdx.x >> 6); r < n_waves; r += gridDim.x * (KM_THREADS / 64)) {
+  for (int r = blockIdx.x * (KM_THREADS / 64) + (threadIdx.x >> 6); r < n_waves; r += nblk * (KM_THREADS / 64)) {
     const int n = h.wave_count[r];
     if (n < 0) {
       pruned_search6(replay, (int64_t)r * 64 + lane, [&](int k, int64_t o, int in) {
@@ -614,18 +656,29 @@ static int build_kernel_maps6(DgrArena &arena, const Kmap6Job *jobs, int nj, int
     r.wpre_in = nullptr;
     if (J.need_in_csr) DGR_ALLOC(r.wpre_in, arena, unsigned short, (r.n_in_cap + 1) * KW);
   }
-  // ---- search (bits + hit records), transpose / count
-  for (int m = 0; m < nj; ++m) {
-    const Kmap6Job &J = jobs[m];
-    Tr &r = t[m];
-    {
-      const PrunedArgs pa{J.out->coords, J.out->n_dev, J.hb_out->second, r.n_cap, *J.hb, J.in->ts, r.symmetric};
-      kmap_bits_pruned6<<<(int)(r.hit_waves / (KM_THREADS / 64)), KM_THREADS, 0, stream>>>(pa, KW, r.mask_out, r.mask_in, r.hl);
+  // ---- search (bits + hit records) of all maps in one launch, then the transposing / counting passes in one launch
+  static_assert(KM_JOBS6 >= KM_MAXJOBS, "multi-job launch tables");
+  {
+    Bits6Jobs bj = {};
+    Colmask6Jobs cj = {};
+    int max_sb = 0, max_rb = 0;
+    for (int m = 0; m < nj; ++m) {
+      const Kmap6Job &J = jobs[m];
+      Tr &r = t[m];
+      bj.pa[m] = PrunedArgs{J.out->coords, J.out->n_dev, J.hb_out->second, r.n_cap, *J.hb, J.in->ts, r.symmetric};
+      bj.mask_out[m] = r.mask_out; bj.mask_in[m] = r.mask_in; bj.hl[m] = r.hl;
+      bj.blocks[m] = (int)(r.hit_waves / (KM_THREADS / 64));
+      max_sb = std::max(max_sb, bj.blocks[m]);
+      cj.mask_out[m] = r.mask_out; cj.n_out_dev[m] = J.out->n_dev; cj.RB[m] = r.RB; cj.cell[m] = r.cell;
+      cj.counts[m] = r.counts; cj.row_cnt[m] = r.cnt_out; cj.wpre[m] = r.wpre_out;
+      max_rb = std::max(max_rb, r.RB);
     }
-    kmap_colmask<<<r.RB, KM_THREADS, 0, stream>>>(r.mask_out, J.out->n_dev, K, KW, r.RB, r.cell, r.counts, r.cnt_out, r.wpre_out);
-    if (J.need_in_csr)
-      mask_count_kernel<<<(int)dgr_ceil_div(r.n_in_cap + 1, 256), 256, 0, stream>>>(r.mask_in, KW, J.in->n_dev, r.n_in_cap + 1,
-                                                                                  r.cnt_in, r.wpre_in);
+    kmap_bits_pruned6<<<dim3((unsigned)max_sb, (unsigned)nj), KM_THREADS, 0, stream>>>(bj, KW);
+    kmap_colmask<<<dim3((unsigned)max_rb, (unsigned)nj), KM_THREADS, 0, stream>>>(cj, K, KW);
+    for (int m = 0; m < nj; ++m)
+      if (jobs[m].need_in_csr)
+        mask_count_kernel<<<(int)dgr_ceil_div(t[m].n_in_cap + 1, 256), 256, 0, stream>>>(t[m].mask_in, KW, jobs[m].in->n_dev,
+                                                                                       t[m].n_in_cap + 1, t[m].cnt_in, t[m].wpre_in);
   }
   DGR_LAUNCH_CHECK();
   // ---- every scan of every map: CSR row pointers (out rows; in rows for maps used swapped) and the cell bases
@@ -649,17 +702,24 @@ static int build_kernel_maps6(DgrArena &arena, const Kmap6Job *jobs, int nj, int
   }
   kmap_finalize<<<nj, 1024, 0, stream>>>(fj);
   tile_desc_kernel<<<dim3((unsigned)dgr_ceil_div(max_tiles, 256), nj), 256, 0, stream>>>(fj);
-  // ---- place
-  for (int m = 0; m < nj; ++m) {
-    const Kmap6Job &J = jobs[m];
-    Tr &r = t[m];
-    DgrKernelMap *km = J.km;
-    const PlaceArgs pl{K, KW, r.RB, r.mask_out, km->out_ptr, r.cell, r.base, km->pair_in, km->pair_out, km->pair_k, km->out_pos,
-                       km->pair_cap, overflow, r.mask_in, km->in_ptr, km->in_pos, r.wpre_out, r.wpre_in};
-    const PrunedArgs pa{J.out->coords, J.out->n_dev, J.hb_out->second, r.n_cap, *J.hb, J.in->ts, r.symmetric};
-    const int blocks = (int)std::min<int64_t>(dgr_ceil_div(r.hit_waves, KM_THREADS / 64), 16384);
-    kmap_place_hits<<<blocks, KM_THREADS, 0, stream>>>(r.hl, (int)r.hit_waves, pl, pa);
-    km->built = true;
+  // ---- place: all maps in one launch
+  {
+    Place6Jobs pj = {};
+    int max_pb = 0;
+    for (int m = 0; m < nj; ++m) {
+      const Kmap6Job &J = jobs[m];
+      Tr &r = t[m];
+      DgrKernelMap *km = J.km;
+      pj.p[m] = PlaceArgs{K, KW, r.RB, r.mask_out, km->out_ptr, r.cell, r.base, km->pair_in, km->pair_out, km->pair_k, km->out_pos,
+                          km->pair_cap, overflow, r.mask_in, km->in_ptr, km->in_pos, r.wpre_out, r.wpre_in};
+      pj.replay[m] = PrunedArgs{J.out->coords, J.out->n_dev, J.hb_out->second, r.n_cap, *J.hb, J.in->ts, r.symmetric};
+      pj.h[m] = r.hl;
+      pj.n_waves[m] = (int)r.hit_waves;
+      pj.blocks[m] = (int)std::min<int64_t>(dgr_ceil_div(r.hit_waves, KM_THREADS / 64), 16384);
+      max_pb = std::max(max_pb, pj.blocks[m]);
+      km->built = true;
+    }
+    kmap_place_hits<<<dim3((unsigned)max_pb, (unsigned)nj), KM_THREADS, 0, stream>>>(pj);
   }
   DGR_LAUNCH_CHECK();
   arena.rewind(mk);
