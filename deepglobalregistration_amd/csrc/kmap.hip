@@ -731,46 +731,64 @@ static int build_kernel_maps6(DgrArena &arena, const Kmap6Job *jobs, int nj, int
 // offsets (9 probes issued together).  SIGN = +1: q = o + delta_k * ts (same-stride and strided convs,
 // out = the output map's rows); SIGN = -1: q = f - delta_k * ts (transposed convs: fine output row f,
 // coarse input c with f = c + delta_k * ts_fine).  Rows beyond the device-side count get -1.
-template <int SIGN>
-__global__ void __launch_bounds__(KM_THREADS)
-    nbr_search3(const int32_t *__restrict__ out_coords, const int32_t *n_out_dev,
-                const int32_t *__restrict__ in_coords, const int32_t *__restrict__ in_table, uint32_t in_mask,
-                int ts, int64_t n_pad, int32_t *__restrict__ nbr) {
+// All ten tables of a 3-D sparse tensor in ONE launch (round 5; round 4: ten launches of 11-130 us with idle tails):
+// blockIdx.z = table, blockIdx.y = z-slab, blockIdx.x = row block of the table (surplus blocks of the smaller tables exit).
+constexpr int NBR_JOBS = 10;
+struct NbrJobs {
+  const int32_t *out_coords[NBR_JOBS], *n_out_dev[NBR_JOBS], *in_coords[NBR_JOBS], *in_table[NBR_JOBS];
+  uint32_t in_mask[NBR_JOBS];
+  int ts[NBR_JOBS];        // signed: +ts for q = o + delta ts, -ts for q = f - delta ts (transposed convs)
+  long long n_pad[NBR_JOBS];
+  int32_t *nbr[NBR_JOBS];
+};
+__global__ void __launch_bounds__(KM_THREADS) nbr_search3(NbrJobs J) {
+  const int jm = blockIdx.z;
+  const int64_t n_pad = J.n_pad[jm];
   const int64_t o = (int64_t)blockIdx.x * KM_THREADS + threadIdx.x;
   if (o >= n_pad) return;
+  int32_t *__restrict__ nbr = J.nbr[jm];
   const int kz = blockIdx.y;
-  if (o >= *n_out_dev) {
+  if (o >= *J.n_out_dev[jm]) {
 #pragma unroll
     for (int u = 0; u < 9; ++u) nbr[(int64_t)(9 * kz + u) * n_pad + o] = -1;
     return;
   }
-  const int4 c = *reinterpret_cast<const int4 *>(out_coords + o * 4);
+  const int sts = J.ts[jm];
+  const int4 c = *reinterpret_cast<const int4 *>(J.out_coords[jm] + o * 4);
   int32_t q[9][4];
 #pragma unroll
   for (int u = 0; u < 9; ++u) {   // offset index k = x + 3 y + 9 z (first spatial dimension fastest: offset_of)
     q[u][0] = c.x;
-    q[u][1] = c.y + SIGN * ((u % 3) - 1) * ts;
-    q[u][2] = c.z + SIGN * ((u / 3) - 1) * ts;
-    q[u][3] = c.w + SIGN * (kz - 1) * ts;
+    q[u][1] = c.y + ((u % 3) - 1) * sts;
+    q[u][2] = c.z + ((u / 3) - 1) * sts;
+    q[u][3] = c.w + (kz - 1) * sts;
   }
   int hit[9];
-  dgr_lookup_many<4, 9>(in_table, in_mask, in_coords, q, hit);
+  dgr_lookup_many<4, 9>(J.in_table[jm], J.in_mask[jm], J.in_coords[jm], q, hit);
 #pragma unroll
   for (int u = 0; u < 9; ++u) nbr[(int64_t)(9 * kz + u) * n_pad + o] = hit[u];
 }
 
+// queue one table (allocation here, the search in nbr_tables_launch)
 static int build_nbr_table(DgrArena &arena, const DgrCoordMap &in, const DgrCoordMap &out, int ts, int sign,
-                           DgrNbrTable *t, hipStream_t stream) {
+                           DgrNbrTable *t, NbrJobs *jobs, int *nj) {
   t->K = 27;
   t->n_pad = dgr_ceil_div(out.n_cap, DGR_OS_ROWS) * DGR_OS_ROWS;
   DGR_ALLOC(t->nbr, arena, int32_t, t->n_pad * 27);
-  dim3 grid((unsigned)dgr_ceil_div(t->n_pad, KM_THREADS), 3);
-  if (sign > 0)
-    nbr_search3<1><<<grid, KM_THREADS, 0, stream>>>(out.coords, out.n_dev, in.coords, in.table, in.table_mask, ts, t->n_pad, t->nbr);
-  else
-    nbr_search3<-1><<<grid, KM_THREADS, 0, stream>>>(out.coords, out.n_dev, in.coords, in.table, in.table_mask, ts, t->n_pad, t->nbr);
-  DGR_LAUNCH_CHECK();
+  DGR_REQUIRE(*nj < NBR_JOBS, "neighbour tables: more than %d per launch", NBR_JOBS);
+  const int m = (*nj)++;
+  jobs->out_coords[m] = out.coords; jobs->n_out_dev[m] = out.n_dev; jobs->in_coords[m] = in.coords;
+  jobs->in_table[m] = in.table; jobs->in_mask[m] = in.table_mask; jobs->ts[m] = sign > 0 ? ts : -ts;
+  jobs->n_pad[m] = t->n_pad; jobs->nbr[m] = t->nbr;
   t->built = true;
+  return DGR_OK;
+}
+static int nbr_tables_launch(const NbrJobs &jobs, int nj, hipStream_t stream) {
+  long long n_max = 0;
+  for (int m = 0; m < nj; ++m) n_max = std::max(n_max, jobs.n_pad[m]);
+  if (nj == 0) return DGR_OK;
+  nbr_search3<<<dim3((unsigned)dgr_ceil_div(n_max, KM_THREADS), 3, (unsigned)nj), KM_THREADS, 0, stream>>>(jobs);
+  DGR_LAUNCH_CHECK();
   return DGR_OK;
 }
 
@@ -816,14 +834,17 @@ int dgr_build_maps(DgrArena &arena, const int32_t *coords, int64_t N, int D, int
   }
   DGR_CHECK(dgr_build_coord_maps(arena, coords, N, ms, stream));
   if (nbr_tables) {
-    // D = 3 network forward: ten dense neighbour tables, one launch each -- no pair lists, no CSR, no scans
+    // D = 3 network forward: ten dense neighbour tables, ONE launch for all of them -- no pair lists, no CSR, no scans
     DGR_REQUIRE(D == 3, "neighbour tables are a D = 3 structure");
     ms->use_nbr = true;
-    for (int l = 0; l < 4; ++l) DGR_CHECK(build_nbr_table(arena, ms->cm[l], ms->cm[l], ms->cm[l].ts, +1, &ms->nsame[l], stream));
+    NbrJobs nbj = {};
+    int n_nbj = 0;
+    for (int l = 0; l < 4; ++l) DGR_CHECK(build_nbr_table(arena, ms->cm[l], ms->cm[l], ms->cm[l].ts, +1, &ms->nsame[l], &nbj, &n_nbj));
     for (int l = 0; l < 3; ++l) {
-      DGR_CHECK(build_nbr_table(arena, ms->cm[l], ms->cm[l + 1], ms->cm[l].ts, +1, &ms->ndown[l], stream));
-      DGR_CHECK(build_nbr_table(arena, ms->cm[l + 1], ms->cm[l], ms->cm[l].ts, -1, &ms->nup[l], stream));
+      DGR_CHECK(build_nbr_table(arena, ms->cm[l], ms->cm[l + 1], ms->cm[l].ts, +1, &ms->ndown[l], &nbj, &n_nbj));
+      DGR_CHECK(build_nbr_table(arena, ms->cm[l + 1], ms->cm[l], ms->cm[l].ts, -1, &ms->nup[l], &nbj, &n_nbj));
     }
+    DGR_CHECK(nbr_tables_launch(nbj, n_nbj, stream));
     if (lean) {   // the network forward needs nothing else (conv1 runs fused with its neighbour search)
       if (conv1_ks != 3 && !skip_conv1_map)
         DGR_CHECK(build_kernel_map3(arena, ms->cm[0], ms->cm[0], conv1_ks, 1024, false, false, true, &ms->conv1, ms->overflow,
