@@ -336,28 +336,18 @@ __global__ void __launch_bounds__(256, 2)
   for (int st = s_first; st < s_end; st += STEP) {
     const int t0 = st * KNN_ST;
     if (st + STEP < s_end) request((st + STEP) * KNN_ST);   // lands behind this stage's MFMAs
-    // the fragments and norms of a tile are read from LDS one tile AHEAD (the candidate test at the end of a tile is a
-    // branch the compiler does not move loads across; the buffer always holds KNN_ST tiles, valid or not)
-    bf16x8 an[4];
-    float4 cn[4];
-    auto fetch = [&](int j) {
-#pragma unroll
-      for (int f = 0; f < 4; ++f) an[f] = sA[buf][(j * 4 + f) * 64 + lane];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) cn[g] = *reinterpret_cast<const float4 *>(&sNb[buf][j * 32 + 8 * g + 4 * h]);
-    };
-    fetch(0);
 #pragma unroll
     for (int j = 0; j < KNN_ST; ++j) {
       const int t = t0 + j;
       if (t >= n_rtiles) break;   // block-uniform
-      const bf16x8 a0 = an[0], a1 = an[1], a2 = an[2], a3 = an[3];
+      const bf16x8 a0 = sA[buf][(j * 4 + 0) * 64 + lane], a1 = sA[buf][(j * 4 + 1) * 64 + lane];
+      const bf16x8 a2 = sA[buf][(j * 4 + 2) * 64 + lane], a3 = sA[buf][(j * 4 + 3) * 64 + lane];
       f32x16_t c0;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        c0[4 * g] = cn[g].x; c0[4 * g + 1] = cn[g].y; c0[4 * g + 2] = cn[g].z; c0[4 * g + 3] = cn[g].w;
+        const float4 v = *reinterpret_cast<const float4 *>(&sNb[buf][j * 32 + 8 * g + 4 * h]);
+        c0[4 * g] = v.x; c0[4 * g + 1] = v.y; c0[4 * g + 2] = v.z; c0[4 * g + 3] = v.w;
       }
-      if (j + 1 < KNN_ST) fetch(j + 1);
       // the six MFMAs of a block form a dependent chain: the four blocks are interleaved step by step so that
       // every MFMA has three independent ones between itself and its predecessor
       f32x16_t acc[4];
@@ -373,32 +363,23 @@ __global__ void __launch_bounds__(256, 2)
       for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bq[u][0], acc[u], 0, 0, 0);
 #pragma unroll
       for (int u = 0; u < 4; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, bq[u][1], acc[u], 0, 0, 0);
-      float bmu[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         float bm = fminf(fminf(acc[u][0], acc[u][1]), fminf(acc[u][2], acc[u][3]));
 #pragma unroll
         for (int e = 4; e < 16; e += 4)
           bm = fminf(bm, fminf(fminf(acc[u][e], acc[u][e + 1]), fminf(acc[u][e + 2], acc[u][e + 3])));
-        bmu[u] = bm;
-        if (!PASS2) m[u] = fminf(m[u], bm);
-      }
-      if (PASS2) {
-        // ONE wave-level test per tile for all four query blocks (round 5: four data-dependent branches per tile kept
-        // the next tile's LDS reads behind them; a tile holds a candidate for ~one wave in five)
-        const bool any = !(bmu[0] > thr[0]) || !(bmu[1] > thr[1]) || !(bmu[2] > thr[2]) || !(bmu[3] > thr[3]);
-        if (__ballot(any)) {
+        if (!PASS2) {
+          m[u] = fminf(m[u], bm);
+        } else {
+          if (!(bm > thr[u])) {   // some reference of this block is within tau of the query's (sampled) minimum
+            const int64_t q = (int64_t)(qb0 + u) * 32 + (lane & 31);
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            if (!(bmu[u] > thr[u])) {   // some reference of this block is within tau of the query's (sampled) minimum
-              const int64_t q = (int64_t)(qb0 + u) * 32 + (lane & 31);
-#pragma unroll
-              for (int e = 0; e < 16; ++e) {
-                const int64_t i = (int64_t)((e & 3) + 8 * (e >> 2) + 4 * h) * n_rtiles + t;   // slot s of tile t = row s n_tiles + t
-                if (!(acc[u][e] > thr[u]) && q < N0 && i < N1 && qb0 + u < n_qblocks) {
-                  const int slot = atomicAdd(cand_cnt + q, 1);   // per-query counters: no hot address
-                  if (slot < KNN_SLOTS) cand[q * KNN_SLOTS + slot] = (int32_t)(i + d.r0);   // beyond: knn_overflow_list
-                }
+            for (int e = 0; e < 16; ++e) {
+              const int64_t i = (int64_t)((e & 3) + 8 * (e >> 2) + 4 * h) * n_rtiles + t;   // slot s of tile t = row s n_tiles + t
+              if (!(acc[u][e] > thr[u]) && q < N0 && i < N1 && qb0 + u < n_qblocks) {
+                const int slot = atomicAdd(cand_cnt + q, 1);   // per-query counters: no hot address
+                if (slot < KNN_SLOTS) cand[q * KNN_SLOTS + slot] = (int32_t)(i + d.r0);   // beyond: knn_overflow_list
               }
             }
           }
