@@ -8,7 +8,7 @@
 
 int dgr_registration_launch_ctx(dgr_ctx *ctx, const float *xyz0, const float *xyz1, const int64_t *idx1,
                                 const float *lw, int is_logit, float clip, const int64_t *off0_dev,
-                                const int64_t *off0_host, int npairs, int64_t total_rows, float q, int max_iter, int max_break,
+                                int npairs, int64_t total_rows, float q, int max_iter, int max_break,
                                 double ratio, int skip_refine, int gate, float eps, float *weights_out,
                                 DgrRegResult *results_dev, hipStream_t stream);
 int dgr_ctx_new_flag(dgr_ctx *ctx, hipStream_t stream);
@@ -238,7 +238,7 @@ extern "C" int dgr_register_batch(dgr_ctx *ctx, dgr_net *fcgf, dgr_net *inlier, 
   DGR_CHECK(tm.rec(4, 0));
   const float eps = 1.1920928955078125e-07f;
   DGR_CHECK(dgr_registration_launch_ctx(ctx, xyz0, xyz1, idx1, forced_logit ? forced_logit : logit, 1,
-                                        prm->clip_weight_thresh, off0_dev, off0, npairs, n0, 2.f * prm->voxel_size,
+                                        prm->clip_weight_thresh, off0_dev, npairs, n0, 2.f * prm->voxel_size,
                                         prm->max_iter, prm->max_break_count, prm->break_threshold_ratio,
                                         prm->skip_refinement, 1, eps, weights, res_dev, stream));
   DGR_CHECK(tm.rec(4, 1));
@@ -247,11 +247,6 @@ extern "C" int dgr_register_batch(dgr_ctx *ctx, dgr_net *fcgf, dgr_net *inlier, 
   DGR_HIP_CHECK(hipMemcpyAsync(res.data(), res_dev, (size_t)npairs * sizeof(DgrRegResult), hipMemcpyDeviceToHost, stream));
   DGR_HIP_CHECK(hipStreamSynchronize(stream));
   DGR_CHECK(dgr_ctx_check_flag(ctx, stream));
-  for (int p = 0; p < npairs; ++p)
-    if (res[p].status == DGR_STATUS_EXCHANGE_TIMEOUT) {
-      dgr_set_error("registration of pair %d: the workgroups sharing the pair lost each other (exchange timed out)", p);
-      return DGR_EINTERNAL;
-    }
   for (int p = 0; p < npairs; ++p) {
     float *T = T_out + p * 16;
     const DgrRegResult &r = res[p];

@@ -3,5 +3,5 @@
 # competitor): every run bit for bit the first one, no exchange time-out
 set -x
 cd $GRAFT_REPO_ROOT
-VARIANTS=base NREG=2000 NCOMP=600 bash tools/contention_reg.sh > gpurun_out/r5_10_contention.txt 2>&1
-cat gpurun_out/r5_10_contention.txt
+VARIANTS="base base base" NREG=2000 NCOMP=600 bash tools/contention_reg.sh > gpurun_out/r5_10h_contention.txt 2>&1
+cat gpurun_out/r5_10h_contention.txt
