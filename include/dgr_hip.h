@@ -105,7 +105,10 @@ int dgr_net_sharers(const dgr_net *net);
 /* ---- sparse ResUNet forward: replaces ME.SparseTensor(feats, coordinates=coords) +
  * ResUNet2.forward (core/deep_global_registration.py:163-169, 210-217; model/resunet.py:598-649).
  * coords: dev int32 [N,1+D] (batch column first, unique rows); feats: dev f32 [N,Cin];
- * out: dev f32 [N,Cout], row i belongs to coords row i.  Asynchronous. */
+ * out: dev f32 [N,Cout], row i belongs to coords row i.  Asynchronous.
+ * Precondition for a 3-D net with ONE input channel (the FCGF net): feats are finite numbers -- its first layer keeps
+ * the input values in a dense grid whose empty cells hold the NaN bit pattern 0xffffffff, so an input with exactly those
+ * bits would be read as an empty voxel (the reference feeds ones, core/deep_global_registration.py:160). */
 int dgr_resunet_forward(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, const float *feats,
                         int64_t N, float *out, dgr_stream stream);
 /* after a forward: copy an intermediate activation ("s1","s2","s4","s8","s4_tr","s2_tr","s1_tr")

@@ -22,7 +22,8 @@ a = np.load(fs[0])
 for f in fs[1:]:
     b = np.load(f)
     print(f, 'logit bitwise equal:', bool((a['logit'] == b['logit']).all()), 'F bitwise equal:', bool((a['F'] == b['F']).all()),
-          'max dlogit', float(np.abs(a['logit'] - b['logit']).max()))
+          'max dlogit', float(np.abs(a['logit'] - b['logit']).max()),
+          'relative to max |logit|', float(np.abs(a['logit'] - b['logit']).max() / max(1e-30, np.abs(a['logit']).max())))
     for k in a.files:
         if k.startswith('i6_') and k in b.files:
             print('   ', k, 'max |d| / max |a| =', float(np.abs(a[k] - b[k]).max() / max(1e-30, np.abs(a[k]).max())), 'bitwise', bool((a[k] == b[k]).all()))
