@@ -7,8 +7,8 @@ One "step" = one pass of the hot path (FCGF x2 -> 1-NN -> 6-D inputs -> 6-D inli
 weighted Procrustes -> SE(3) refinement; `dgr_register_batch`) over synthetic 3DMatch-shaped pairs
 (BASELINE.json configs[1]: 50k raw points per fragment, 5 cm voxels, conv1 k=7) whose voxelised
 coordinates are already resident in HBM.  Per GPU: S HIP streams, each driven by its own host thread
-with its own library context, each registering batches of B pairs (pairs are independent units,
-streams never exchange data).
+with its own library context over ONE shared weight set, each registering batches of B pairs (pairs are independent
+units, streams never exchange data).  Defaults: S = 3, B = 6.
 
 * default (weak scaling): every rank registers its own S x B pairs per step;
 * `--total-pairs P` (strong scaling, BASELINE configs[3] with P = 512): P pairs are dealt over the
