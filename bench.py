@@ -116,6 +116,13 @@ def roofline_time_own_pipe_s(s, kind):
     return roofline_time_s(s)
 
 
+def _group_launches(launches):
+    g = {}
+    for kind, main_ms, total_ms in launches:
+        g.setdefault(kind, []).append((main_ms, total_ms))
+    return g
+
+
 def layer_gather_bytes(s):
     """SURVEY.md 8d's secondary figure: what a gather -> GEMM -> scatter-add implementation moves,
     4 P (Cin + 2 Cout) + 8 P + 4 K_ne Cin Cout."""
@@ -164,17 +171,18 @@ def oracle_parity_and_baseline(ck, args, pair0, do_baseline):
         net_runs['inlier_net'].append(time.time() - t0)
     t['fcgf'] = float(np.median(net_runs['fcgf']))
     t['inlier_net'] = float(np.median(net_runs['inlier_net']))
-    parity = {'pair': 0, 'voxels': [n0, n1],
+    parity = {'pair': pair0.get('pair', 0), 'voxels': [n0, n1],
               'dF': float(max(np.abs(pair0['F0'] - oF0).max(), np.abs(pair0['F1'] - oF1).max())),
               'dlogit_rel': float(np.abs(pair0['logit'] - ologit).max() / max(1e-12, np.abs(ologit).max())),
               'tolerance': 1e-4,
-              'what': 'F0/F1 and the 6-D logits of pair 0 of the timed batch (HIP, dgr_register_batch) vs '
+              'what': 'F0/F1 and the 6-D logits of ONE pair of the stream\'s last timed batch (HIP, dgr_register_batch) vs '
                       'oracle.resunet.resunet_forward on identical voxels / correspondences; R/t: the HIP refinement '
                       '(dgr_se3_refine) vs oracle.registration.global_registration on the same correspondences and '
                       'weights, both forced to the oracle\'s free-running iteration count (oracle/parity.py); computed '
-                      'outside the timed region'}
-    # R / t (parity TE / RE): iteration-matched, plus how far the reference moves from itself at that
-    # iteration count under a row permutation / a few-ulp change of its inputs (the band)
+                      'outside the timed region', 'stream': pair0.get('stream', 0)}
+    # R / t (parity TE / RE): iteration-matched against the f32 reference; where that exceeds 1e-4 an F64
+    # ARBITER (the reference algorithm evaluated in float64, oracle/parity.py) says which side is off -- the rule of
+    # tests/helpers.py::assert_iteration_matched
     w, wsum, thr = opipe.confidence_gate(pair0['forced'])
     X, Y = p0, p1[pair0['idx1']]
     q = 2 * args.voxel
@@ -183,27 +191,42 @@ def oracle_parity_and_baseline(ck, args, pair0, do_baseline):
     def hip_refine(Xa, Ya, wa, max_iter, max_break):
         return ops.se3_refine(torch.from_numpy(Xa).to(dev), torch.from_numpy(Ya).to(dev), torch.from_numpy(wa).to(dev),
                               q, max_iter, max_break, 1e-4)
+
+    def hip_refine_from(Xa, Ya, wa, state, max_iter):
+        return ops.se3_refine_from(torch.from_numpy(Xa).to(dev), torch.from_numpy(Ya).to(dev), torch.from_numpy(wa).to(dev),
+                                   state, max_iter, q, 10 ** 9, 1e-4)
     if wsum >= thr and not args.no_refine:
-        rp = oparity.iteration_matched(X, Y, w, hip_refine, always_band=True, band_counts='short', band_ulps=4,
-                                       break_threshold_ratio=1e-4, quantization_size=q)
-        Ro, to = rp.pop('R_oracle'), rp.pop('t_oracle')
-        R = np.asarray(hip_refine(np.asarray(X, np.float32), np.asarray(Y, np.float32),
-                                  np.asarray(w, np.float32).reshape(-1, 1), rp['iterations'], 10 ** 9)[0], np.float64)
-        c = (np.trace(R.T @ Ro.astype(np.float64)) - 1) / 2
+        okw = dict(break_threshold_ratio=1e-4, quantization_size=q)
+        Xn, Yn, wn = np.asarray(X, np.float32), np.asarray(Y, np.float32), np.asarray(w, np.float32).reshape(-1, 1)
+        rp = oparity.iteration_matched(Xn, Yn, wn, hip_refine, tol=10.0, **okw)
+        Ro, to = rp['R_oracle'], rp['t_oracle']
+        c = (np.trace(rp['R_impl'].T @ Ro.astype(np.float64)) - 1) / 2
+        d = max(rp['dR'], rp['dt'])
         parity.update({'dR': rp['dR'], 'dt': rp['dt'], 'refinement_iterations': rp['iterations'],
-                       'reference_band': rp['band'], 'parity_RE_deg': float(np.degrees(np.arccos(np.clip(c, -1, 1)))),
-                       'parity_TE_m': rp['dt'] * rp['t_scale'],
-                       'band_what': 'largest |dR|, |dt| of the oracle against ITSELF at the same iteration counts '
-                                    '(k, k-15) on a row permutation and 4 few-ulp perturbations of its input'})
-        # two separate statements: the stated tolerance (north_star: R / t within 1e-4), and the band criterion that is
-        # accepted where the reference does not reproduce ITSELF to 1e-4 on this input
-        parity['rt_within_1e-4'] = bool(max(rp['dR'], rp['dt']) <= 1e-4)
-        parity['rt_within_3x_reference_band'] = bool(max(rp['dR'], rp['dt']) <= 3 * (rp['band'] or 0.0))
-        parity['rt_ok'] = bool(parity['rt_within_1e-4'] or parity['rt_within_3x_reference_band'])
-        if not parity['rt_within_1e-4']:
-            parity['rt_note'] = ('R / t exceed the stated 1e-4 at equal iteration counts; accepted because the reference '
-                                 f'moves by {rp["band"]:.1e} from itself under a row permutation / few-ulp input changes '
-                                 '(Adam from a stationary start, core/registration.py:161-194; DESIGN.md section 2)')
+                       'parity_RE_deg': float(np.degrees(np.arccos(np.clip(c, -1, 1)))), 'parity_TE_m': rp['dt'] * rp['t_scale']})
+        parity['rt_within_1e-4'] = bool(d <= 1e-4)
+        parity['rt_ok'] = parity['rt_within_1e-4']
+        if not parity['rt_within_1e-4'] or do_baseline:
+            arb = oparity.f64_arbiter(Xn, Yn, wn, rp['iterations'], rp['R_impl'], rp['t_impl'], Ro, to, rp['t_scale'],
+                                      family=not parity['rt_within_1e-4'], n_ulps=4, **okw)
+            parity['f64_arbiter'] = dict(arb, what='|HIP - f64|, |f32 reference - f64| (and the f32 reference on a row permutation / '
+                                                   '+-1..4 ulp inputs) at the same iteration count; f64 = oracle.registration.'
+                                                   'global_registration(dtype=float64)')
+            if not parity['rt_within_1e-4']:
+                eh, e32, ef = arb['err_impl_f64'], arb['err_f32_f64'], arb['err_family_f64']
+                parity['rt_not_farther_from_f64_than_reference'] = bool(eh <= max(1e-4, 1.5 * e32))
+                ok = parity['rt_not_farther_from_f64_than_reference']
+                if not ok:
+                    rows = oparity.window_accuracy(Xn, Yn, wn, hip_refine_from, **okw)
+                    a = np.array([r for r in rows if r[0] > 0], np.float64).reshape(-1, 3)
+                    r32, rh = float(np.sqrt((a[:, 1] ** 2).mean())), float(np.sqrt((a[:, 2] ** 2).mean()))
+                    parity['window_accuracy'] = {'rms_f32_ref_vs_f64': r32, 'rms_hip_vs_f64': rh, 'windows': len(a)}
+                    ok = bool(eh <= max(1e-4, 1.5 * ef) and rh <= 2.0 * r32 + 1e-7)
+                    parity['rt_note'] = ('R / t exceed 1e-4 at equal iteration counts on a chaotic input (Adam from a stationary '
+                                         'start, core/registration.py:161-194): accepted iff the f32 reference on perturbed inputs '
+                                         'lands as far from the f64 arbiter AND four HIP steps from any reference state are not '
+                                         'farther from four f64 steps than the reference\'s own (DESIGN.md section 2)')
+                parity['rt_ok'] = ok
     parity['features_logits_within_1e-4'] = bool(parity['dF'] < 1e-4 and parity['dlogit_rel'] < 1e-4)
     parity['within_1e-4'] = bool(parity['features_logits_within_1e-4'] and parity.get('rt_within_1e-4', True))
     parity['ok'] = bool(parity['features_logits_within_1e-4'] and parity.get('rt_ok', True))
@@ -285,6 +308,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true', help='skip the oracle comparison of pair 0 (about 30 s of CPU)')
     ap.add_argument('--no-refine', action='store_true', help='ablation: stop after weighted Procrustes')
+    ap.add_argument('--no-exact-leg', action='store_true', help='skip the short DGR_EXACT_F32=1 leg (a child process after the '
+                    'timed region; it only runs together with the parity leg)')
     ap.add_argument('--from-host', action='store_true', help='PCIe-inclusive variant (NOT the headline): every step '
                     'starts from the raw float64 host points (H2D copy + GPU voxelisation inside the timed region)')
     ap.add_argument('--streams', type=int, default=3, help='HIP streams per GPU, each driven by its own host '
@@ -487,6 +512,20 @@ def main():
                 for _ in range(n):
                     self.step()
 
+        def run_profiled(self, n):
+            """n more steps with HIP events around every sparse-conv launch ON THIS WORKER'S STREAM (the library's
+            profiling mode), all workers of the rank at once: the per-launch durations of the TIMED stream configuration."""
+            self.prof_launches = []   # (kind, main-kernel ms, main + reduction ms) of every conv launch
+            with self:
+                ops.set_profiling(device, True)
+                for _ in range(n):
+                    self.step()
+                    lm, gm = ops.conv_launch_times(device)
+                    kd = ops.conv_launch_kinds(device)
+                    if len(lm) == len(kd):
+                        self.prof_launches += list(zip(kd, gm, lm))
+                ops.set_profiling(device, False)
+
     workers = [Worker(w, ids) for w, ids in enumerate(per_stream) if ids]
     for w in workers:
         w.prepare(shared_with=None if (w is workers[0] or os.environ.get('DGR_BENCH_PRIVATE_WEIGHTS')) else workers[0])
@@ -528,6 +567,13 @@ def main():
     last_bt = w0.last_bt
     with torch.cuda.stream(w0.stream):
         hip_out = {k: ops.batch_output(device, k).cpu().numpy() for k in ('idx1', 'logit', 'F0', 'F1')}
+    # ... and of every other stream's last call (the parity leg checks one pair per stream)
+    stream_outs = [(w0.last_bt, hip_out)]
+    for w in workers[1:]:
+        _lib.use_ctx(w.ctx)
+        with torch.cuda.stream(w.stream):
+            stream_outs.append((w.last_bt, {k: ops.batch_output(device, k).cpu().numpy() for k in ('idx1', 'logit', 'F0', 'F1')}))
+    _lib.use_ctx(w0.ctx)
     T = np.concatenate([r[0] for w in workers for r in w.results])
     status = np.concatenate([r[1] for w in workers for r in w.results])
     stats = np.concatenate([r[2] for w in workers for r in w.results])
@@ -537,7 +583,23 @@ def main():
                                         np.zeros(len(ids_local), np.int32), np.zeros((len(ids_local), 4), np.float32),
                                         dst=0, device=coll_dev)
 
-    # ---- profiled re-run of stream 0's first batch: HIP events around every sparse-conv launch ----
+    # ---- the same stream configuration once more, profiled: every worker at once, HIP events around every conv launch on
+    #      the worker's own stream (roofline.frac is quoted from HERE: the configuration the headline was timed in)
+    n_prof_c = min(args.steps, 6)
+    if len(workers) == 1:
+        workers[0].run_profiled(n_prof_c)
+    else:
+        threads = [threading.Thread(target=w.run_profiled, args=(n_prof_c,)) for w in workers]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+    torch.cuda.synchronize()
+    timed_cfg_launches = [x for w in workers for x in w.prof_launches]
+    log(f'profiled region in the timed stream configuration done ({len(timed_cfg_launches)} conv launches)')
+
+    # ---- profiled re-run of stream 0's first batch alone: HIP events around every sparse-conv launch ----
+    _lib.use_ctx(w0.ctx)
     bt = w0.batches[0]
     with torch.cuda.stream(w0.stream):
         ops.set_profiling(device, True)
@@ -634,7 +696,7 @@ def main():
         # the same per-stream workload (tools/evidence.sh), committed under profiles/ -- not measurable from inside
         # this process; quoted only when kernel name and workload label match this run
         pmc, pmc_file = None, None
-        for cand in ('r05_dominant_pmc.json', 'r04_dominant_pmc.json'):
+        for cand in ('r06_dominant_pmc.json', 'r05_dominant_pmc.json'):
             ppath = os.path.join(ROOT, 'profiles', cand)
             if os.path.exists(ppath):
                 pj = json.load(open(ppath))
@@ -649,6 +711,74 @@ def main():
         alg = dominant['achieved_tflops'] if dominant else achieved
         pairs_per_step = (args.total_pairs or world * n_local)
         ms_per_step = elapsed / args.steps * 1e3
+        # the dominant kernel in the TIMED stream configuration (all streams of the rank at once, HIP events on each
+        # stream): the duration roofline.frac is computed from; the one-stream figure next to it
+        tc = [g for k_, g, _ in timed_cfg_launches if dominant and k_ == dominant['name']]
+        us_timed = 1e3 * float(np.mean(tc)) if tc else (dominant['avg_launch_us'] if dominant else None)
+        gfl = dominant['gflop_per_launch'] if dominant else flop / 1e9 / n_launch
+        alg_timed = gfl / (us_timed * 1e-6) / 1e3 if us_timed else alg        # TFLOP/s
+        traffic = pmc.get('hbm_bytes_per_launch') if pmc else None
+        alg_bytes = dominant['algorithmic_bytes_per_launch'] if dominant else byts / n_launch
+        roofline = {
+            'bound': 'mfma', 'achieved': products * alg_timed, 'peak': peak, 'unit': 'TFLOP/s',
+            'frac': products * alg_timed / peak,
+            'traffic': traffic,
+            'kernel': dominant['name'] if dominant else 'sparse conv (all variants)',
+            # average duration of that kernel's launches in the timed configuration (S streams at once); the rocprofv3
+            # --kernel-trace average of the same command is profiles/r06_kernel_stats_s3_b6.csv (tools/evidence.sh checks
+            # that the two agree)
+            'avg_launch_us': us_timed,
+            'traffic_ratio': (traffic / alg_bytes) if traffic else None,           # PMC bytes / algorithmic bytes per launch
+            # the C <= 64 gather/scatter layers (north_star: >= 0.40 of the HBM roofline): compulsory bytes over their
+            # measured time as a fraction of 8 TB/s, and the same layers against the pipe their kernels issue on
+            'c_le_64_hbm_frac': c64['frac_of_hbm_peak_compulsory'] if c64 else None,
+            'c_le_64_frac_own_pipe': c64['frac_of_roofline_own_pipe'] if c64 else None,
+            'c_le_64_compulsory_gbps': c64['compulsory_gbps'] if c64 else None,
+            'exact_f32_pairs_per_s': None,    # filled below: the same workload with DGR_EXACT_F32=1 (v_mfma_f32_*_f32 on f32 operands)
+            'products_per_mac': products,
+            'pipe': 'dense f16 MFMA (v_mfma_f32_32x32x16_f16)' if split else 'f32 MFMA (v_mfma_f32_32x32x2_f32)',
+            'algorithmic_bytes_per_launch': alg_bytes,
+            'gflop_per_launch': gfl,
+            'launches_per_batch': dominant['launches_per_batch'] if dominant else n_launch,
+            'streams_when_measured': len(workers),
+            'frac_one_stream': products * alg / peak,
+            'avg_launch_us_one_stream': dominant['avg_launch_us'] if dominant else conv_ms * 1e3 / n_launch,
+            'mfma_busy_from_profiles': pmc.get('mfma_busy') if pmc else None,
+            'traffic_source': (f'profiles/{pmc_file} (commit {pmc.get("commit", "not stamped")}): separate rocprofv3 --pmc passes '
+                               'of the one-stream command, 2 x FETCH_SIZE (gfx950 correction, calibrated on a 2-GB read: '
+                               'profiles/r05_mall_probe_counters.txt) + WRITE_SIZE, per launch; L2 <-> fabric bytes: '
+                               'Infinity-Cache hits are counted') if pmc else None,
+            'algorithmic_tflops': alg_timed,
+            'limited_by': 'not the matrix pipe: the memory system -- one gathered KB, one product KB written and read back per '
+                          'pair (rule-major tiles of 64 pairs) against 0.1 KB of algorithmic bytes; DESIGN.md 4.2'
+                          if split else None,
+            'share_of_conv_flop': dominant['share_of_conv_flop'] if dominant else 1.0,
+            'share_of_conv_time': dominant['share_of_conv_time'] if dominant else 1.0,
+            'c_le_64_ms_per_batch': c64['ms_per_batch'] if c64 else None,
+            # SURVEY.md 8d's model prices these layers' FLOP at the f32 MFMA peak, which the f16-pipe kernels do not obey:
+            # kept for continuity with rounds 1-5, NOT a roofline fraction (round-5 verdict, What's weak 2)
+            'c_le_64_frac_vs_f32_model': c64['frac_of_roofline'] if c64 else None,
+        }
+        roofline_detail = {
+            # the same launches counted as plain f32 MACs against the f32 MFMA peak (what an exact-f32 kernel is priced
+            # against); NOT a roofline fraction of this kernel -- it can exceed 1
+            'f32_view': {'achieved': alg, 'peak': PEAK_FP32_MFMA_TFLOPS, 'ratio': alg / PEAK_FP32_MFMA_TFLOPS},
+            'all_conv_layers': {'achieved_algorithmic_tflops': achieved,
+                                'launches_per_batch': n_launch, 'avg_launch_us': conv_ms * 1e3 / n_launch,
+                                'gflop_per_batch': flop / 1e9, 'compulsory_gbytes_per_batch': byts / 1e9,
+                                'hbm_gbps_compulsory': byts / (conv_ms * 1e-3) / 1e9,
+                                'roofline_ms_f32_model': sum(roofline_time_s(s) for s in per_layer) * 1e3,
+                                'frac_of_roofline_f32_model': sum(roofline_time_s(s) for s in per_layer) * 1e3 / conv_ms,
+                                'frac_of_roofline_own_pipe': (sum(roofline_time_own_pipe_s(s_, k_) for s_, k_ in zip(per_layer, kinds)) * 1e3 / conv_ms
+                                                              if len(kinds) == len(per_layer) else None)},
+            'c_le_64_layers': c64,
+            'by_kernel': {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in g.items()}
+                          for k, g in groups.items()},
+            # per kernel variant in the timed stream configuration: launches seen, mean main-kernel / main + reduction us
+            'by_kernel_timed_config': {k: {'launches': len(v), 'main_kernel_us': round(1e3 * float(np.mean([a for a, _ in v])), 2),
+                                           'with_reduction_us': round(1e3 * float(np.mean([b for _, b in v])), 2)}
+                                       for k, v in _group_launches(timed_cfg_launches).items()},
+        }
         out = {
             'metric': 'pair registrations/sec (FCGF x2 + 1-NN + 6-D inlier net + gate + weighted Procrustes + SE(3) refinement'
                       + (' + ICP' if args.full_register else '') + (', safeguard RANSAC forced' if args.force_safeguard else '') + ')',
@@ -676,49 +806,10 @@ def main():
                        'refinement': not args.no_refine,
                        'use_icp': bool(args.full_register), 'forced_safeguard': bool(args.force_safeguard),
                        'parallelism': f'pair-sharded x{world}, no data-path collective'},
-            # roofline of the DOMINANT conv kernel variant against the pipe it issues on: achieved = products per MAC x
-            # the algorithmic FLOP of its launches / their durations (HIP events on the launch stream around the MFMA
-            # phase of every layer during a profiled re-run of the same steps by one stream)
-            'roofline': {'bound': 'mfma', 'achieved': products * alg, 'peak': peak, 'unit': 'TFLOP/s',
-                         'frac': products * alg / peak,
-                         'pipe': 'dense f16 MFMA (v_mfma_f32_32x32x16_f16)' if split else 'f32 MFMA (v_mfma_f32_32x32x2_f32)',
-                         'products_per_mac': products, 'algorithmic_tflops': alg,
-                         'limited_by': 'not the matrix pipe: the memory system -- one gathered and one product KB per pair (rule-major '
-                                       'tiles of 64 pairs) leave L2 at ~4.3 TB/s, against a measured 3.6-5.2 TB/s for random '
-                                       '256-byte rows; row order irrelevant (DESIGN.md 4.2)'
-                                       if split else None,
-                         'traffic': pmc.get('hbm_bytes_per_launch') if pmc else None,
-                         'traffic_source': (f'profiles/{pmc_file}: separate rocprofv3 --pmc passes of the one-stream command, '
-                                            '2 x FETCH_SIZE (gfx950 correction, calibrated on a 2-GB read: profiles/r05_mall_probe_counters.txt) '
-                                            '+ WRITE_SIZE, per launch; L2 <-> fabric bytes: Infinity-Cache hits are counted') if pmc else None,
-                         'mfma_busy_from_profiles': pmc.get('mfma_busy') if pmc else None,
-                         'kernel': dominant['name'] if dominant else 'sparse conv (all variants)',
-                         'launches_per_batch': dominant['launches_per_batch'] if dominant else n_launch,
-                         'avg_launch_us': dominant['avg_launch_us'] if dominant else conv_ms * 1e3 / n_launch,
-                         'gflop_per_launch': dominant['gflop_per_launch'] if dominant else flop / 1e9 / n_launch,
-                         'share_of_conv_flop': dominant['share_of_conv_flop'] if dominant else 1.0,
-                         'share_of_conv_time': dominant['share_of_conv_time'] if dominant else 1.0,
-                         'algorithmic_bytes_per_launch': dominant['algorithmic_bytes_per_launch'] if dominant else byts / n_launch,
-                         # the same launches counted as plain f32 MACs against the f32 MFMA peak (what an exact-f32
-                         # kernel is priced against); NOT a roofline fraction of this kernel -- it can exceed 1
-                         'f32_view': {'achieved': alg, 'peak': PEAK_FP32_MFMA_TFLOPS, 'ratio': alg / PEAK_FP32_MFMA_TFLOPS},
-                         'all_conv_layers': {'achieved_algorithmic_tflops': achieved,
-                                             'launches_per_batch': n_launch, 'avg_launch_us': conv_ms * 1e3 / n_launch,
-                                             'gflop_per_batch': flop / 1e9, 'compulsory_gbytes_per_batch': byts / 1e9,
-                                             'hbm_gbps_compulsory': byts / (conv_ms * 1e-3) / 1e9,
-                                             'roofline_ms_f32_model': sum(roofline_time_s(s) for s in per_layer) * 1e3,
-                                             'frac_of_roofline_f32_model': sum(roofline_time_s(s) for s in per_layer) * 1e3 / conv_ms,
-                                             'frac_of_roofline_own_pipe': (sum(roofline_time_own_pipe_s(s_, k_) for s_, k_ in zip(per_layer, kinds)) * 1e3 / conv_ms
-                                                                           if len(kinds) == len(per_layer) else None)},
-                         # the C <= 64 gather/scatter layers (north_star's 1-GPU target: >= 0.40 of their roofline), as
-                         # scalars next to the full record below
-                         'c_le_64_frac': c64['frac_of_roofline'] if c64 else None,
-                         'c_le_64_frac_own_pipe': c64['frac_of_roofline_own_pipe'] if c64 else None,
-                         'c_le_64_ms_per_batch': c64['ms_per_batch'] if c64 else None,
-                         'c_le_64_compulsory_gbps': c64['compulsory_gbps'] if c64 else None,
-                         'c_le_64_layers': c64,
-                         'by_kernel': {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in g.items()}
-                                       for k, g in groups.items()}},
+            # roofline of the DOMINANT conv kernel variant against the pipe it issues on (scalars first: the fields a reader
+            # needs to reproduce `frac` by hand; the per-kernel / per-layer records are in `roofline_detail`)
+            'roofline': roofline,
+            'roofline_detail': roofline_detail,
             'host_cpu_s_per_step_per_rank': cpu_s_per_step,
             'stage_ms_per_batch': {k: round(v, 3) for k, v in prof.items() if k != 'conv_launches'},
             'te_m_mean': float(np.mean(te)) if te else None, 're_deg_mean': float(np.mean(re)) if re else None,
@@ -730,20 +821,46 @@ def main():
         log('roofline accounting done')
         out['parity'] = out['cpu_baseline'] = None
         if not args.no_parity and world == 1:
-            lb = last_bt
-            s0, e0, s1, e1 = lb['off0'][0], lb['off0'][1], lb['off1'][0], lb['off1'][1]
-            c0 = lb['C0'][s0:e0].cpu().numpy().copy(); c0[:, 0] = 0
-            c1 = lb['C1'][s1:e1].cpu().numpy().copy(); c1[:, 0] = 0
-            pair0 = {'xyz0': lb['X0'][s0:e0].cpu().numpy(), 'coords0': c0, 'xyz1': lb['X1'][s1:e1].cpu().numpy(), 'coords1': c1,
-                     'idx1': hip_out['idx1'][s0:e0] - s1, 'F0': hip_out['F0'].reshape(-1, 32)[s0:e0],
-                     'F1': hip_out['F1'].reshape(-1, 32)[s1:e1], 'logit': hip_out['logit'][s0:e0],
-                     'forced': lb['forced'].cpu().numpy()[s0:e0], 'device': device}
-            out['parity'], out['cpu_baseline'] = oracle_parity_and_baseline(ck, args, pair0, not args.no_cpu_baseline)
-            log(f'parity: {out["parity"]}')
-            if out['parity']:
-                # the stated tolerance next to the verdict that also accepts the reference's own chaos band
-                out['config']['parity_within_1e-4'] = bool(out['parity'].get('within_1e-4'))
-                out['config']['parity_ok'] = bool(out['parity'].get('ok'))
+            # one pair per stream: pair (stream index mod B) of the stream's last timed batch; the CPU baseline is timed on
+            # the first of them
+            checks = []
+            for wi, (lb, ho) in enumerate(stream_outs):
+                qi = wi % len(lb['ids'])
+                s0, e0, s1, e1 = lb['off0'][qi], lb['off0'][qi + 1], lb['off1'][qi], lb['off1'][qi + 1]
+                c0 = lb['C0'][s0:e0].cpu().numpy().copy(); c0[:, 0] = 0
+                c1 = lb['C1'][s1:e1].cpu().numpy().copy(); c1[:, 0] = 0
+                pair0 = {'xyz0': lb['X0'][s0:e0].cpu().numpy(), 'coords0': c0, 'xyz1': lb['X1'][s1:e1].cpu().numpy(), 'coords1': c1,
+                         'idx1': ho['idx1'][s0:e0] - s1, 'F0': ho['F0'].reshape(-1, 32)[s0:e0],
+                         'F1': ho['F1'].reshape(-1, 32)[s1:e1], 'logit': ho['logit'][s0:e0],
+                         'forced': lb['forced'].cpu().numpy()[s0:e0], 'device': device, 'stream': wi, 'pair': qi}
+                par, base = oracle_parity_and_baseline(ck, args, pair0, (not args.no_cpu_baseline) and wi == 0)
+                checks.append(par)
+                if wi == 0:
+                    out['cpu_baseline'] = base
+                log(f'parity (stream {wi}, pair {qi}): {par}')
+            out['parity'] = dict(checks[0], per_stream=[{k: c.get(k) for k in ('stream', 'pair', 'voxels', 'dF', 'dlogit_rel', 'dR', 'dt',
+                                                                              'refinement_iterations', 'within_1e-4', 'ok')}
+                                                        for c in checks])
+            # the stated tolerance next to the verdict that also accepts the reference's own chaos (f64 arbiter)
+            out['config']['parity_within_1e-4'] = bool(all(c.get('within_1e-4') for c in checks))
+            out['config']['parity_ok'] = bool(all(c.get('ok') for c in checks))
+            out['config']['parity_pairs_checked'] = len(checks)
+        # ---- the same workload on the reference's literal arithmetic (DGR_EXACT_F32=1: v_mfma_f32_*_f32 on the f32 operands),
+        #      one short leg in a child process (the switch is read when the library first runs a layer); outside the timed region
+        if world == 1 and not args.no_exact_leg and not args.no_parity and not os.environ.get('DGR_EXACT_F32'):
+            try:
+                cmd = [sys.executable, os.path.abspath(__file__), '--steps', '8', '--warmup', '2', '--no-parity', '--no-exact-leg',
+                       '--pairs-per-step', str(B), '--streams', str(S), '--n-raw', str(args.n_raw), '--voxel', str(args.voxel),
+                       '--kind', args.kind, '--conv1-ks', str(args.conv1_ks)] + (['--no-refine'] if args.no_refine else [])
+                cp = subprocess.run(cmd, env=dict(os.environ, DGR_EXACT_F32='1'), capture_output=True, text=True, timeout=600)
+                line = [l for l in cp.stdout.splitlines() if l.startswith('{')][-1]
+                ex = json.loads(line)
+                out['roofline']['exact_f32_pairs_per_s'] = ex['value']
+                out['exact_f32_leg'] = {'value': ex['value'], 'unit': 'pairs/s', 'steps': ex['steps'], 'ms_per_step': ex['ms_per_step'],
+                                        'dtype': ex['dtype'], 'kernel': ex['roofline']['kernel'], 'frac_of_f32_mfma_peak': ex['roofline']['frac']}
+                log(f'exact-f32 leg: {ex["value"]:.1f} pairs/s')
+            except Exception as e:   # the leg is a report, not the product: say so and go on
+                out['exact_f32_leg'] = {'error': repr(e)[:300]}
         print(json.dumps(out))
     if pg_up:
         dist.barrier()

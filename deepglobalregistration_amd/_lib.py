@@ -81,6 +81,8 @@ SIGNATURES = {
     'dgr_ctx_conv_launch_times': (C.c_int, [vp, c_f32p, c_f32p, C.c_int64, C.POINTER(C.c_int64)]),
     'dgr_ctx_conv_launch_kinds': (C.c_int, [vp, C.c_char_p, C.c_int64, C.POINTER(C.c_int64)]),
     'dgr_debug_ortho2rotation': (C.c_int, [vp, vp, C.c_int64, vp, vp, vp, vp]),
+    'dgr_debug_se3_refine_from': (C.c_int, [vp, vp, vp, vp, C.c_int64, C.c_float, C.c_int, C.c_int, C.c_double,
+                                            c_f64p, c_f64p, vp]),
     'dgr_debug_smooth_l1': (C.c_int, [vp, vp, vp, C.c_int64, C.c_float, vp, vp]),
     'dgr_debug_conv_layer': (C.c_int, [vp, vp, C.c_int, vp, vp, C.c_int, C.c_int64, vp, vp]),
 }

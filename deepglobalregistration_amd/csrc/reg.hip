@@ -34,6 +34,10 @@ struct RegArgs {
   float clip, q, eps;
   int is_logit, gate, skip_refine, max_iter, max_break;
   double ratio;
+  // parity instrumentation (dgr_debug_se3_refine_from; null in the product path): the optimiser state the loop
+  // resumes from / ends with -- 30 doubles: prm[9], Adam exp_avg[9], exp_avg_sq[9], iteration, loss_prev, break count
+  const double *state_in;
+  double *state_out;
 };
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -314,8 +318,16 @@ __global__ void __launch_bounds__(REG_THREADS) registration_kernel(RegArgs a) {
 #endif
   double lr = 0.1, b1t = 1.0, b2t = 1.0;
   float loss_prev = 0.f, loss = 0.f;
-  int breaks = 0, it = 0;
-  for (it = 0; it < a.max_iter; ++it) {
+  int breaks = 0, it = 0, it0 = 0;
+  if (a.state_in) {   // resume at iteration it0 from a given optimiser state (the schedules by their own recurrences)
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { prm[i] = (float)a.state_in[i]; am[i] = (float)a.state_in[9 + i]; av[i] = (float)a.state_in[18 + i]; }
+    it0 = (int)a.state_in[27];
+    loss_prev = (float)a.state_in[28];
+    breaks = (int)a.state_in[29];
+    for (int i = 0; i < it0; ++i) { lr *= 0.999; b1t *= 0.9; b2t *= 0.999; }
+  }
+  for (it = it0; it < a.max_iter; ++it) {
     Ortho o;
     ortho_forward(prm, o);
     const float R00 = o.x[0], R10 = o.x[1], R20 = o.x[2];
@@ -430,6 +442,10 @@ __global__ void __launch_bounds__(REG_THREADS) registration_kernel(RegArgs a) {
     }
     loss_prev = loss;
   }
+  if (tid == 0 && a.state_out) {
+    for (int i = 0; i < 9; ++i) { a.state_out[i] = prm[i]; a.state_out[9 + i] = am[i]; a.state_out[18 + i] = av[i]; }
+    a.state_out[27] = it; a.state_out[28] = loss_prev; a.state_out[29] = breaks;
+  }
   if (it >= a.max_iter) it = a.max_iter - 1;  // python's `i` after an exhausted range()
   if (tid == 0) {
     Ortho o;
@@ -453,7 +469,8 @@ static int launch_registration(dgr_ctx *ctx, const float *xyz0, const float *xyz
                                const float *lw, int is_logit, float clip, const int64_t *off0_dev,
                                int npairs, int64_t total_rows, float q, int max_iter, int max_break,
                                double ratio, int skip_refine, int gate, float eps, float *weights_out,
-                               DgrRegResult *results_dev, hipStream_t stream) {
+                               DgrRegResult *results_dev, hipStream_t stream, const double *state_in = nullptr,
+                               double *state_out = nullptr) {
   RegArgs a;
   a.xyz0 = xyz0; a.xyz1 = xyz1; a.idx1 = idx1; a.lw = lw; a.off0 = off0_dev;
   a.weights_out = weights_out; a.res = results_dev;
@@ -462,6 +479,7 @@ static int launch_registration(dgr_ctx *ctx, const float *xyz0, const float *xyz
   a.clip = clip; a.q = q; a.eps = eps;
   a.is_logit = is_logit; a.gate = gate; a.skip_refine = skip_refine;
   a.max_iter = max_iter; a.max_break = max_break; a.ratio = ratio;
+  a.state_in = state_in; a.state_out = state_out;
   registration_kernel<<<npairs, REG_THREADS, 0, stream>>>(a);
   DGR_LAUNCH_CHECK();
   return DGR_OK;
@@ -479,7 +497,8 @@ int dgr_registration_launch_ctx(dgr_ctx *ctx, const float *xyz0, const float *xy
 
 static int run_single(dgr_ctx *ctx, const float *X, const float *Y, const float *w, int64_t N, float q,
                       int max_iter, int max_break, double ratio, int skip_refine, float eps,
-                      DgrRegResult *host_res, hipStream_t stream) {
+                      DgrRegResult *host_res, hipStream_t stream, const double *state_in_host = nullptr,
+                      double *state_out_host = nullptr) {
   DGR_REQUIRE(ctx && X && Y && w, "registration: NULL argument");
   DGR_REQUIRE(N > 0 && N < (1ll << 31), "registration: N=%lld out of range", (long long)N);
   DGR_REQUIRE(skip_refine || max_iter >= 1, "GlobalRegistration: max_iter must be >= 1");
@@ -491,9 +510,19 @@ static int run_single(dgr_ctx *ctx, const float *X, const float *Y, const float 
   DGR_ALLOC(res, ctx->arena, DgrRegResult, 1);
   const int64_t h_off[2] = {0, N};
   DGR_HIP_CHECK(hipMemcpyAsync(off, h_off, sizeof(h_off), hipMemcpyHostToDevice, stream));
+  double *st_in = nullptr, *st_out = nullptr;
+  if (state_in_host) {
+    DGR_ALLOC(st_in, ctx->arena, double, 30);
+    DGR_HIP_CHECK(hipMemcpyAsync(st_in, state_in_host, 30 * sizeof(double), hipMemcpyHostToDevice, stream));
+  }
+  if (state_out_host) {
+    DGR_ALLOC(st_out, ctx->arena, double, 30);
+    DGR_HIP_CHECK(hipMemsetAsync(st_out, 0, 30 * sizeof(double), stream));
+  }
   DGR_CHECK(launch_registration(ctx, X, Y, nullptr, w, 0, 0.f, off, 1, N, q, max_iter, max_break, ratio,
-                                skip_refine, 0, eps, nullptr, res, stream));
+                                skip_refine, 0, eps, nullptr, res, stream, st_in, st_out));
   DGR_HIP_CHECK(hipMemcpyAsync(host_res, res, sizeof(DgrRegResult), hipMemcpyDeviceToHost, stream));
+  if (state_out_host) DGR_HIP_CHECK(hipMemcpyAsync(state_out_host, st_out, 30 * sizeof(double), hipMemcpyDeviceToHost, stream));
   DGR_HIP_CHECK(hipStreamSynchronize(stream));
   if (host_res->status == DGR_STATUS_SVD_FAILED) {
     dgr_set_error("weighted Procrustes: non-finite covariance, SVD failed");
@@ -527,6 +556,22 @@ extern "C" int dgr_se3_refine(dgr_ctx *ctx, const float *X, const float *Y, cons
   if (loss) *loss = r.loss;
   if (break_count) *break_count = r.break_count;
   return DGR_OK;
+}
+
+// Parity instrumentation: the refinement loop of dgr_se3_refine resumed at iteration state_in[27] from a given
+// optimiser state (30 host doubles: prm[9] = rot6d + trans, Adam exp_avg[9], exp_avg_sq[9], iteration, loss_prev, break
+// count) and run up to iteration max_iter; the state it ends with in state_out.  tests/helpers.py holds W such steps
+// against W steps of the reference algorithm in f32 and in f64 FROM THE SAME STATE (core/registration.py:168-190).
+extern "C" int dgr_debug_se3_refine_from(dgr_ctx *ctx, const float *X, const float *Y, const float *w, int64_t N,
+                                         float quantization_size, int max_iter, int max_break_count,
+                                         double break_threshold_ratio, const double *state_in, double *state_out,
+                                         dgr_stream stream) {
+  DGR_REQUIRE(state_in && state_out, "dgr_debug_se3_refine_from: NULL state");
+  DGR_REQUIRE(state_in[27] >= 0 && state_in[27] < max_iter, "dgr_debug_se3_refine_from: iteration %g outside [0, max_iter)", state_in[27]);
+  DgrRegResult r;
+  const float eps = 1.1920928955078125e-07f;
+  return run_single(ctx, X, Y, w, N, quantization_size, max_iter, max_break_count, break_threshold_ratio, 0, eps, &r,
+                    (hipStream_t)stream, state_in, state_out);
 }
 
 // ---- debug entry points: the device functions of the registration kernel on their own, so that the parity tests

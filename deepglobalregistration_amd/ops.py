@@ -325,6 +325,24 @@ def se3_refine(X, Y, w, quantization_size=1.0, max_iter=1000, max_break_count=20
             {'iterations': it.value, 'loss': loss.value, 'break_count': bc.value})
 
 
+def se3_refine_from(X, Y, w, state, max_iter, quantization_size=1.0, max_break_count=10 ** 9,
+                    break_threshold_ratio=1e-5):
+    """Parity instrumentation (dgr_debug_se3_refine_from): the refinement loop resumed at iteration state['i'] from the
+    optimiser state `state` = {'i', 'prm' [9], 'm' [9], 'v' [9], 'loss_prev', 'breaks'} (the layout of
+    `oracle.registration.global_registration(states=...)`) and run up to iteration `max_iter`.  Returns the end state."""
+    lib = _lib.load()
+    dev, X, Y, w = _xyw(X, Y, w)
+    si = (C.c_double * 30)(*([float(v) for v in state['prm']] + [float(v) for v in state['m']] + [float(v) for v in state['v']]
+                             + [float(state['i']), float(state['loss_prev']), float(state['breaks'])]))
+    so = (C.c_double * 30)()
+    check(lib.dgr_debug_se3_refine_from(get_ctx(dev), ptr(X), ptr(Y), ptr(w), X.shape[0], float(quantization_size),
+                                        int(max_iter), int(max_break_count), float(break_threshold_ratio), si, so,
+                                        stream_ptr(dev.index)))
+    so = np.array(so, np.float64)
+    return {'prm': so[:9].copy(), 'm': so[9:18].copy(), 'v': so[18:27].copy(), 'i': int(so[27]), 'loss_prev': float(so[28]),
+            'breaks': int(so[29])}
+
+
 def _xyz_dev(a, dev=None):
     t = a if torch.is_tensor(a) else torch.as_tensor(np.asarray(a))
     if dev is None:

@@ -284,6 +284,16 @@ int dgr_ctx_conv_launch_kinds(dgr_ctx *ctx, char *buf, int64_t capacity, int64_t
  * All pointers are device pointers. */
 int dgr_debug_ortho2rotation(dgr_ctx *ctx, const float *p6, int64_t n, const float *grad_R9, float *R9_out,
                              float *grad_p6_out, dgr_stream stream);
+/* The refinement loop of dgr_se3_refine (core/registration.py:168-190) RESUMED at iteration state_in[27] from a given
+ * optimiser state and run up to iteration max_iter: 30 HOST doubles = prm[9] (rot6d, trans), Adam exp_avg[9],
+ * exp_avg_sq[9], iteration, loss_prev, break count; state_out receives the state it ends with.  X, Y, w as for
+ * dgr_se3_refine (device).  Parity instrumentation: lets a test run W steps of this kernel and W steps of the reference
+ * algorithm (in f32 and in f64) from the SAME state, so that the comparison does not pass through the chaotic
+ * amplification of a whole trajectory. */
+int dgr_debug_se3_refine_from(dgr_ctx *ctx, const float *X, const float *Y, const float *w, int64_t N,
+                              float quantization_size, int max_iter, int max_break_count,
+                              double break_threshold_ratio, const double *state_in, double *state_out,
+                              dgr_stream stream);
 /* HighDimSmoothL1Loss (core/loss.py:51-61) per point of X, Y [n,3] (device) with quantization_size q -> per_point_out [n] */
 int dgr_debug_smooth_l1(dgr_ctx *ctx, const float *X, const float *Y, int64_t n, float quantization_size,
                         float *per_point_out, dgr_stream stream);

@@ -79,8 +79,16 @@ def assert_refine_parity(X, Y, w, R, t, stats, tol=1e-4, window=40, **kw):
         oreg.global_registration(X, Y, w, trace=trace, **kw2)
         tail = trace[max(0, min(so['iterations'], stats['iterations']) - window):]
         band = max(max(np.abs(Ri - Ro).max(), np.abs(ti - to).max()) for Ri, ti in tail)
+    arb = ''
+    if band is not None:
+        # the f64 arbiter, free-running as well (informational: the three sides stop at three iteration counts, and what
+        # separates them is the terminal oscillation the band measures)
+        import torch
+        R8, t8, s8 = oreg.global_registration(X, Y, w, dtype=torch.float64, **kw)
+        e = [max(np.abs(Ra - R8).max(), np.abs(np.asarray(ta).reshape(3) - t8.reshape(3)).max()) for Ra, ta in ((R, t), (Ro, to))]
+        arb = f'  f64 arbiter stops at {s8["iterations"]}: |hip - f64| {e[0]:.1e}  |f32 ref - f64| {e[1]:.1e}'
     _report(f'free-running       {_case():70s} n={len(X):6d} iterations hip {stats["iterations"]:4d} oracle {so["iterations"]:4d}  '
-            f'dR {dR:.1e} dt {dt:.1e}  ' + (f'oracle tail band {band:.1e}' if band is not None else 'inside 1e-4'))
+            f'dR {dR:.1e} dt {dt:.1e}  ' + (f'oracle tail band {band:.1e}' if band is not None else 'inside 1e-4') + arb)
     if band is not None:
         assert dR <= max(tol, band) and dt <= max(tol, band), (dR, dt, band, so, stats)
     return Ro, to, so
@@ -98,20 +106,51 @@ def oracle_pair_counts(maps, conv1_ks):
 
 
 
+def _hip_refine_from(Xn, Yn, wn, state, max_iter, kw):
+    import torch
+    from deepglobalregistration_amd import ops
+    return ops.se3_refine_from(torch.from_numpy(Xn).cuda(), torch.from_numpy(Yn).cuda(), torch.from_numpy(wn).cuda(), state,
+                               max_iter, kw.get('quantization_size', 1.0), 10 ** 9, kw.get('break_threshold_ratio', 1e-5))
+
+
+def assert_window_accuracy(X, Y, w, factor=2.0, **kw):
+    """LOCAL accuracy of the HIP refinement against the f64 arbiter (`oracle.parity.window_accuracy`): from the f32
+    reference's own optimiser state before step i, four steps by the f32 reference, by the reference algorithm in float64
+    and by the HIP kernel (`dgr_debug_se3_refine_from`).  Required: over the windows (the stationary start i = 0 listed but
+    left out, see `window_accuracy`) the HIP kernel is not farther from the f64 steps than the f32 reference is:
+    rms(e_hip) <= factor * rms(e_f32) + 1e-7.  Returns (rms_f32, rms_hip, rows)."""
+    from oracle import parity
+    rows = parity.window_accuracy(X, Y, w, lambda a, b, c, st, mi: _hip_refine_from(a, b, c, st, mi, kw), **kw)
+    a = np.array([r for r in rows if r[0] > 0], np.float64).reshape(-1, 3)
+    rms32, rmsh = float(np.sqrt((a[:, 1] ** 2).mean())), float(np.sqrt((a[:, 2] ** 2).mean()))
+    worst = max(rows[1:], key=lambda r: r[2] / max(r[1], 1e-9)) if len(rows) > 1 else rows[0]
+    _report(f'4-step windows     {_case():70s} n={len(np.asarray(X)):6d} {len(a):2d} windows from the reference\'s own states: '
+            f'rms |f32 ref - f64| {rms32:.1e}  rms |hip - f64| {rmsh:.1e}  (start 0: {rows[0][1]:.1e} / {rows[0][2]:.1e}; '
+            f'worst window i={worst[0]}: {worst[1]:.1e} / {worst[2]:.1e})')
+    assert rmsh <= factor * rms32 + 1e-7, (rms32, rmsh, rows)
+    return rms32, rmsh, rows
+
+
 def assert_iteration_matched(X, Y, w, tol=1e-4, **kw):
     """Iteration-matched refinement parity on the given inputs (the measurement is `oracle.parity.iteration_matched`):
     the oracle runs freely (k iterations), then BOTH sides run exactly k iterations (max_iter = k, max_break_count =
     10^9; the stopping logic is out of the picture).
-    Required: |dR| <= tol, |dt| <= tol max(1, |t|), equal final losses (2e-3) -- unless the reference algorithm itself
-    is not defined to that level on this input: Adam at lr = 0.1 * 0.999^i amplifies the f32 rounding of the loss /
-    gradient sums (and HighDimSmoothL1Loss jumps at s = 1), so the oracle run on a fixed ROW PERMUTATION of the same
-    input, or on the input changed by a few ULPs, with the same k moves by some band b; then the bound is
-    max(tol, 3 b).  The refinement starts at the weighted-Procrustes estimate, a stationary point of the loss whenever
-    all inlier residuals are below q: every gradient component is rounding noise and Adam's first step is lr * sign(g)
-    = +-0.1 per parameter whatever |g| is (measured: after ONE iteration the reference differs from itself by 0.27 when
-    its input changes by one ulp, tools/diag_refine.py; after 150 iterations most members of the perturbation family are
-    within 1e-4 of each other and one -- the sign pattern the HIP kernel also starts with -- is still 2e-3 away).
-    Returns (deviation, band)."""
+
+    Required: |dR| <= tol, |dt| <= tol max(1, |t|) against the f32 reference, equal final losses (2e-3).  Where that does
+    not hold, an F64 ARBITER decides which side is off (round-5 verdict, item 4): the reference ALGORITHM evaluated in
+    float64 on the same inputs for the same k iterations (`oracle.registration.global_registration(dtype=float64)`).
+      (a) err_hip = |HIP - f64| <= max(tol, 1.5 err_f32), err_f32 = |f32 reference - f64|: HIP is not farther from exact
+          arithmetic than the reference is -- accepted; or
+      (b) the trajectory is chaotic on this input -- Adam starts at the weighted-Procrustes estimate, where the gradient
+          is rounding noise and the first step is +-lr per parameter whatever its size, so a re-ordering of the f32 sums
+          picks another sign pattern and some patterns are still 1e-3 away after 150 iterations (tools/diag_refine.py) --
+          then BOTH of the following are required: err_hip <= max(tol, 1.5 err_family), err_family = the largest
+          |f32 reference on a perturbed input - f64| over a row permutation and +-1..8 ulp input scalings (the reference
+          itself lands that far from exact arithmetic when only its rounding changes), AND the LOCAL accuracy test
+          passes on this input (`assert_window_accuracy`: four HIP steps from any state of the reference's trajectory
+          are not farther from four f64 steps than four f32-reference steps are) -- i.e. the kernel's arithmetic is as
+          good as the reference's and the distance is the reference's own sensitivity, not a kernel error.
+    Returns (deviation from the f32 reference, err_hip_f64, err_f32_f64, err_family_f64 | None)."""
     import torch
     from deepglobalregistration_amd import ops
     from oracle import parity
@@ -120,18 +159,28 @@ def assert_iteration_matched(X, Y, w, tol=1e-4, **kw):
         R, t, st = ops.se3_refine(torch.from_numpy(Xn).cuda(), torch.from_numpy(Yn).cuda(), torch.from_numpy(wn).cuda(),
                                   kw.get('quantization_size', 1.0), max_iter, max_break, kw.get('break_threshold_ratio', 1e-5))
         return R, t, st
-    r = parity.iteration_matched(X, Y, w, refine, tol=tol, **kw)
-    d, band = max(r['dR'], r['dt']), r['band'] or 0.0
-    _report(f'iteration-matched  {_case():70s} n={len(np.asarray(X)):6d} iterations {r["iterations"]:4d} (both sides)          '
-            f'dR {r["dR"]:.1e} dt {r["dt"]:.1e}  '
-            + (f'reference vs itself (row permutation / 1-ulp inputs) {band:.1e}' if r['band'] is not None else 'inside 1e-4')
-            + f'  loss hip {r["loss"]:.6e} oracle {r["loss_oracle"]:.6e}')
+    Xn, Yn = np.asarray(X, np.float32), np.asarray(Y, np.float32)
+    wn = np.asarray(w, np.float32).reshape(-1, 1)
+    r = parity.iteration_matched(Xn, Yn, wn, refine, tol=10.0, **kw)     # (tol = 10: no band runs; the arbiter below)
+    d = max(r['dR'], r['dt'])
+    arb = parity.f64_arbiter(Xn, Yn, wn, r['iterations'], r['R_impl'], r['t_impl'], r['R_oracle'], r['t_oracle'], r['t_scale'],
+                             family=False, **kw)
+    eh, e32, efam = arb['err_impl_f64'], arb['err_f32_f64'], None
+    verdict = 'inside 1e-4 of the f32 reference' if d <= tol else 'hip not farther from f64 than the f32 reference (x1.5)'
+    if d > tol and eh > max(tol, 1.5 * e32):
+        efam = parity.f64_arbiter(Xn, Yn, wn, r['iterations'], r['R_impl'], r['t_impl'], r['R_oracle'], r['t_oracle'],
+                                  r['t_scale'], family=True, **kw)['err_family_f64']
+        verdict = f'chaotic input: f32 reference on perturbed inputs vs f64 {efam:.1e}'
+    _report(f'iteration-matched  {_case():70s} n={len(Xn):6d} iterations {r["iterations"]:4d} (both sides)          '
+            f'dR {r["dR"]:.1e} dt {r["dt"]:.1e}  |hip - f64| {eh:.1e}  |f32 ref - f64| {e32:.1e}  {verdict}'
+            f'  loss hip {r["loss"]:.6e} oracle {r["loss_oracle"]:.6e}')
     assert r['iterations_impl'] == r['iterations_oracle'], r
-    if d > tol:
-        assert d <= max(tol, 3 * band), (d, band, r['iterations'])
-    else:
+    if d <= tol:
         assert abs(r['loss'] - r['loss_oracle']) <= 2e-3 * abs(r['loss_oracle']) + 1e-9, r
-    return d, band
+    elif efam is not None:
+        assert eh <= max(tol, 1.5 * efam), (eh, e32, efam, r['iterations'])
+        assert_window_accuracy(Xn, Yn, wn, **kw)
+    return d, eh, e32, efam
 
 
 def harness_dgr(config, device):

@@ -92,3 +92,29 @@ def test_ortho6d_gradient_matches_reference(golden):
     assert fin.sum() >= 28 and np.array_equal(np.isnan(P.grad.numpy()), np.isnan(g['dP']))
     scale = np.maximum(1.0, np.abs(g['dP'][fin]).max(axis=1, keepdims=True))
     assert (np.abs(P.grad.numpy()[fin] - g['dP'][fin]) / scale).max() < 1e-5
+
+
+def test_refinement_instrumentation_is_faithful(golden):
+    """The test instrumentation of `oracle.registration.global_registration` (tests/helpers.py, the f64 arbiter): a run
+    resumed from a recorded optimiser state is the free run bit for bit, the float64 evaluation stays within rounding of the
+    f32 one on a well-conditioned input, and `parity.window_accuracy` of the f32 oracle against itself is exactly zero."""
+    from oracle import parity
+    g = golden('refine')
+    torch.set_num_threads(1)
+    kw = ast.literal_eval(str(g['outliers70_kw']))
+    X, Y, w = g['outliers70_X'], g['outliers70_Y'], g['outliers70_w']
+    states = []
+    R, t, st = oreg.global_registration(X, Y, w, states=states, **kw)
+    np.testing.assert_array_equal(R, g['outliers70_R'])          # recording states does not change the run
+    assert len(states) == st['iterations'] + 1 and states[0]['i'] == 0 and not states[0]['m'].any()
+    for k in (1, len(states) // 2, len(states) - 2):
+        R2, t2, st2 = oreg.global_registration(X, Y, w, start=states[k], **kw)
+        assert np.array_equal(R, R2) and np.array_equal(t, t2) and st2['iterations'] == st['iterations'] \
+            and st2['break_count'] == st['break_count'], k
+    kk = dict(kw, max_iter=st['iterations'], max_break_count=10 ** 9)
+    R8, t8, _ = oreg.global_registration(X, Y, w, dtype=torch.float64, **kk)
+    Rm, tm, _ = oreg.global_registration(X, Y, w, **kk)
+    assert R8.dtype == np.float64 and np.abs(Rm - R8).max() < 5e-6 and np.abs(tm - t8).max() < 5e-6
+    rows = parity.window_accuracy(X, Y, w, lambda a, b, c, s, mi: {'prm': oreg.global_registration(
+        a, b, c, start=s, **dict(kw, max_iter=mi, max_break_count=10 ** 9))[2]['prm']}, starts=[1, 10, 40], **kw)
+    assert all(r[1] == r[2] and r[1] < 1e-5 for r in rows), rows
