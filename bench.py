@@ -280,12 +280,16 @@ def launch_check(args, rank, world, backend):
     out = ddist.gather_results(T, np.zeros(len(mine), np.int32), np.zeros((len(mine), 4), np.float32), dst=0,
                                device=torch.device('cpu'))
     tt = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    cnt = torch.zeros(world, dtype=torch.int64)
+    cnt[rank] = len(mine)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(cnt)
     if rank == 0:
         ids = sorted(int(v) for v in out[0][:, 0, 3])
         print(json.dumps({'launch_check': True, 'n_gpus': world, 'requested_gpus': args.gpus, 'backend': backend,
                           'pairs': P, 'all_pairs_covered_once': ids == list(range(P)), 'max_over_ranks': float(tt.item()),
+                          'pairs_per_rank': [int(v) for v in cnt.tolist()],
                           'weights_broadcast_keys': len(ck['state_dict'])}))
     if world > 1:
         dist.barrier()

@@ -124,10 +124,23 @@ extern "C" int dgr_ctx_create(int device, dgr_ctx **out) {
   return DGR_OK;
 }
 
+int dgr_ctx_wait(dgr_ctx *ctx, hipStream_t stream) {
+  static const bool spin = getenv("DGR_SPIN_SYNC") != nullptr;
+  if (spin) {
+    DGR_HIP_CHECK(hipStreamSynchronize(stream));
+    return DGR_OK;
+  }
+  if (!ctx->wait_ev) DGR_HIP_CHECK(hipEventCreateWithFlags(&ctx->wait_ev, hipEventBlockingSync | hipEventDisableTiming));
+  DGR_HIP_CHECK(hipEventRecord(ctx->wait_ev, stream));
+  DGR_HIP_CHECK(hipEventSynchronize(ctx->wait_ev));
+  return DGR_OK;
+}
+
 extern "C" void dgr_ctx_destroy(dgr_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
+  if (ctx->wait_ev) (void)hipEventDestroy(ctx->wait_ev);
   ctx->arena.release();
   ctx->events.release();
   delete ctx;

@@ -531,7 +531,12 @@ static int knn_prefiltered(dgr_ctx *ctx, const float *F0, const float *F1, KnnBa
     q_begin = std::min(q_begin, d.q0);
     q_end = std::max(q_end, d.q0 + d.n0);
   }
-  const int64_t nq = q_end - q_begin;   // query rows covered (the pairs of a batch are consecutive row ranges)
+  // Query rows SPANNED by the pairs of B in the concatenated F0 (not the sum of their rows): the per-query scratch below is
+  // addressed by the row number itself.  Pairs too small for the prefilter (n1 < KNN_MIN_REFS, handled by the brute-force
+  // kernel) that sit between large ones are covered as well -- 4 x (3 + KNN_SLOTS) bytes per such row, their counts stay
+  // zero and the per-row kernels return at once for them; DGR_ALLOC fails with DGR_ENOMEM if the span does not fit the
+  // arena (the span is at most the batch's N0, which the arena is sized for).
+  const int64_t nq = q_end - q_begin;
   bf16x8 *Qp, *Rp;
   float *na, *nb;
   uint32_t *mt, *nb_max;
@@ -548,7 +553,8 @@ static int knn_prefiltered(dgr_ctx *ctx, const float *F0, const float *F1, KnnBa
   int32_t *fallback = cand_cnt + nq + KNN_MAXP, *qcount = cand_cnt + nq + 2 * KNN_MAXP;
   DGR_HIP_CHECK(hipMemsetAsync(cand_cnt, 0, (size_t)(nq + 4 * KNN_MAXP) * sizeof(int32_t), stream));
   DGR_HIP_CHECK(hipMemsetAsync(mt, 0xff, (size_t)nq * sizeof(uint32_t), stream));
-  // per-query arrays are addressed by the row of the concatenated F0: shift them so that row q_begin is element 0
+  // per-query arrays are addressed by the row of the concatenated F0: shift them so that row q_begin is element 0 (device
+  // addresses: the shifted pointers are only ever dereferenced at rows in [q_begin, q_end))
   mt -= q_begin; qlist -= q_begin; cand_cnt -= q_begin; cand -= q_begin * KNN_SLOTS;
   {
     const int rows_max = std::max(qb_max, rt_max) * 32;

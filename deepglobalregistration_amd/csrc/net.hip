@@ -76,7 +76,11 @@ struct DgrWeights {
   std::vector<DgrLayer> layers;  // 23 convs in forward order
   int64_t param_bytes = 0;
   int device = 0;
+  // Runs on whichever host thread drops the last reference (e.g. Python's GC inside a worker thread): the thread's current
+  // device is restored afterwards; the synchronisation stalls every stream of THIS device once, when the last sharer goes.
   ~DgrWeights() {
+    int cur = -1;
+    (void)hipGetDevice(&cur);
     (void)hipSetDevice(device);
     (void)hipDeviceSynchronize();
     for (auto &l : layers) {
@@ -89,6 +93,7 @@ struct DgrWeights {
       if (l.w16d) (void)hipFree(l.w16d);
       if (l.shift) (void)hipFree(l.shift);
     }
+    if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
   }
 };
 
@@ -755,7 +760,7 @@ int dgr_ctx_collect_profile(dgr_ctx *ctx) {
 static int check_flag(dgr_ctx *ctx, const int32_t *flag_dev, hipStream_t stream) {
   int32_t flag = 0;
   DGR_HIP_CHECK(hipMemcpyAsync(&flag, flag_dev, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-  DGR_HIP_CHECK(hipStreamSynchronize(stream));
+  DGR_CHECK(dgr_ctx_wait(ctx, stream));
   if (flag == 1) {
     dgr_set_error("duplicate coordinates in the sparse tensor input");
     return DGR_EINVAL;
@@ -783,10 +788,13 @@ void dgr_net_invalidate_runs(dgr_net *net) { net->run_generation = ~0ull; }
 int dgr_net_out_channels(const dgr_net *net) { return net->cout; }
 int dgr_net_in_channels(const dgr_net *net) { return net->cin; }
 int dgr_net_dim(const dgr_net *net) { return net->D; }
+const dgr_ctx *dgr_net_ctx(const dgr_net *net) { return net->ctx; }
 
 extern "C" int dgr_resunet_forward(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, const float *feats,
                                    int64_t N, float *out, dgr_stream stream_) {
   DGR_REQUIRE(ctx && net && coords && feats && out, "dgr_resunet_forward: NULL argument");
+  DGR_REQUIRE(net->ctx == ctx, "dgr_resunet_forward: the net object belongs to another context (one dgr_net per context: "
+                               "dgr_net_share gives a second context its own over the same weights)");
   DGR_REQUIRE(N > 0, "dgr_resunet_forward: empty sparse tensor (N=%lld)", (long long)N);
   hipStream_t stream = (hipStream_t)stream_;
   DGR_HIP_CHECK(hipSetDevice(ctx->device));

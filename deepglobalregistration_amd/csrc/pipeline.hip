@@ -8,7 +8,7 @@
 
 int dgr_registration_launch_ctx(dgr_ctx *ctx, const float *xyz0, const float *xyz1, const int64_t *idx1,
                                 const float *lw, int is_logit, float clip, const int64_t *off0_dev,
-                                int npairs, int64_t total_rows, float q, int max_iter, int max_break,
+                                const int64_t *off0_host, int npairs, int64_t total_rows, float q, int max_iter, int max_break,
                                 double ratio, int skip_refine, int gate, float eps, float *weights_out,
                                 DgrRegResult *results_dev, hipStream_t stream);
 int dgr_ctx_new_flag(dgr_ctx *ctx, hipStream_t stream);
@@ -17,6 +17,7 @@ int dgr_net_out_channels(const dgr_net *net);
 void dgr_net_invalidate_runs(dgr_net *net);
 int dgr_net_in_channels(const dgr_net *net);
 int dgr_net_dim(const dgr_net *net);
+const dgr_ctx *dgr_net_ctx(const dgr_net *net);
 
 // ---- 6-D coordinates (:261-262) and inlier features (:185-208) ----------------------------------
 __global__ void inlier_inputs_kernel(const int32_t *__restrict__ coords0, const float *__restrict__ xyz0,
@@ -173,8 +174,11 @@ extern "C" int dgr_register_batch(dgr_ctx *ctx, dgr_net *fcgf, dgr_net *inlier, 
               dgr_net_in_channels(inlier));
   for (int p = 0; p < npairs; ++p)
     DGR_REQUIRE(off0[p + 1] > off0[p] && off1[p + 1] > off1[p], "pair %d is empty", p);
+  DGR_REQUIRE(dgr_net_ctx(fcgf) == ctx && dgr_net_ctx(inlier) == ctx,
+              "dgr_register_batch: a net object belongs to another context (one dgr_net per context: dgr_net_share)");
   hipStream_t stream = (hipStream_t)stream_;
   DGR_HIP_CHECK(hipSetDevice(ctx->device));
+  ctx->last_T64.clear();   // (a call that fails midway leaves nothing of an earlier batch behind for dgr_register_batch_f64)
   DGR_CHECK(ctx->arena.reset());
   dgr_ctx_begin_profile(ctx);
   DGR_CHECK(dgr_ctx_new_flag(ctx, stream));
@@ -238,15 +242,20 @@ extern "C" int dgr_register_batch(dgr_ctx *ctx, dgr_net *fcgf, dgr_net *inlier, 
   DGR_CHECK(tm.rec(4, 0));
   const float eps = 1.1920928955078125e-07f;
   DGR_CHECK(dgr_registration_launch_ctx(ctx, xyz0, xyz1, idx1, forced_logit ? forced_logit : logit, 1,
-                                        prm->clip_weight_thresh, off0_dev, npairs, n0, 2.f * prm->voxel_size,
+                                        prm->clip_weight_thresh, off0_dev, off0, npairs, n0, 2.f * prm->voxel_size,
                                         prm->max_iter, prm->max_break_count, prm->break_threshold_ratio,
                                         prm->skip_refinement, 1, eps, weights, res_dev, stream));
   DGR_CHECK(tm.rec(4, 1));
 
   std::vector<DgrRegResult> res(npairs);
   DGR_HIP_CHECK(hipMemcpyAsync(res.data(), res_dev, (size_t)npairs * sizeof(DgrRegResult), hipMemcpyDeviceToHost, stream));
-  DGR_HIP_CHECK(hipStreamSynchronize(stream));
+  DGR_CHECK(dgr_ctx_wait(ctx, stream));   // the batch's one wait: the host thread sleeps (ctx.hip)
   DGR_CHECK(dgr_ctx_check_flag(ctx, stream));
+  for (int p = 0; p < npairs; ++p)
+    if (res[p].status == DGR_STATUS_EXCHANGE_TIMEOUT) {
+      dgr_set_error("registration of pair %d: the workgroups sharing the pair lost each other (exchange timed out)", p);
+      return DGR_EINTERNAL;
+    }
   for (int p = 0; p < npairs; ++p) {
     float *T = T_out + p * 16;
     const DgrRegResult &r = res[p];

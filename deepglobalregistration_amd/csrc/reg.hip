@@ -12,6 +12,16 @@
 // them with an analytic gradient (13 block-reduced sums accumulated in f64), and the 9-parameter
 // Adam update + the discrete stopping logic run redundantly in every thread.  Per-point
 // arithmetic is f32 like the reference; the 3x3 SVD is f64 (one-sided Jacobi) like its LAPACK call.
+//
+// Round 5: a CLUSTER of 1 .. 8 workgroups per pair (a function of the pair's row count alone, so that a pair's result
+// does not depend on its batch).  The iteration is instruction-issue bound on the point pass (one wave per SIMD, ~145
+// instructions per row): more waves on the same SIMDs do not help (measured in round 2), more SIMDs do.  Workgroup j of
+// a cluster keeps its own share of the rows (256-row chunks j, j + CL, ...), and the cluster exchanges its 13 (pass 1:
+// 17) f64 partial sums once per iteration through memory: every workgroup publishes its totals as 8-byte granules
+// {32 data bits, 32-bit sequence tag} with system-scope stores (no fence needed: data and tag travel in one word;
+// MI355X_MICROARCH.md "handoff-1to1"), polls the granules of all members, and adds them up in member order -- the same
+// bits in every workgroup, so all of them take the same Adam step and the same stopping decision.  Deterministic
+// (fixed order), independent of scheduling.  A cluster of one skips the exchange and is the round-4 kernel bit for bit.
 #include "dgr_internal.h"
 #include "svd3.h"
 
@@ -23,7 +33,22 @@
 constexpr int REG_THREADS = DGR_REG_THREADS;
 constexpr int REG_WAVES = REG_THREADS / 64;
 
+constexpr int REG_CLMAX = 8;      // workgroups per pair at most
+constexpr int REG_XG = 64;        // granules of a member's slot per exchange buffer: 34 used (17 doubles), padded to 512 bytes
+                                  // so that the members' slots -- polled by every member -- do not share cache lines
+constexpr int REG_SPIN_LIMIT = 4000000;   // polls of one granule before the kernel gives up (seconds; see reg_poll2)
+// workgroups that share a pair: by its row count only (batch-invariant results)
+#ifndef DGR_REG_CLUSTER_MAX   // (build-time A/B: -DDGR_REG_CLUSTER_MAX=1 is the one-workgroup kernel of round 4)
+#define DGR_REG_CLUSTER_MAX REG_CLMAX
+#endif
+__host__ __device__ inline int reg_cluster_size(int n) {
+  const int cl = n >= 16384 ? 8 : n >= 8192 ? 4 : n >= 4096 ? 2 : 1;
+  return cl < DGR_REG_CLUSTER_MAX ? cl : DGR_REG_CLUSTER_MAX;
+}
+
 struct RegArgs {
+  unsigned long long *xbuf;   // [npairs][2][REG_CLMAX][REG_XG] exchange granules, zeroed before the launch
+  int pair_base;              // first pair of this launch (a batch is launched in slices, launch_registration)
   const float *xyz0, *xyz1;
   const int64_t *idx1;  // may be null: xyz1 is already gathered (row aligned with xyz0)
   const float *lw;      // logits (is_logit) or weights
@@ -74,7 +99,7 @@ __device__ __forceinline__ void block_sum(const double (&v)[NV], double *lds /* 
 // the 8 it receives, then 4, 2, 1; after four steps every lane owns one value summed over 16 lanes,
 // two more steps finish the wave.  Wave results go to a double-buffered LDS slab (`buf` alternates
 // per call, which removes the write-after-read barrier); every thread then sums the waves itself.
-template <int NV>
+template <int NV, bool FINISH = true>
 __device__ __forceinline__ void block_sum_butterfly(const double (&vin)[NV], double *slab /* [2][REG_WAVES][16] */,
                                                     int buf, double (&out)[NV]) {
   static_assert(NV <= 16, "at most 16 values");
@@ -96,12 +121,63 @@ __device__ __forceinline__ void block_sum_butterfly(const double (&vin)[NV], dou
   double *mine = slab + (buf * REG_WAVES + wave) * 16;
   if ((lane & 3) == 0) mine[(b5 ? 8 : 0) + (b4 ? 4 : 0) + (b3 ? 2 : 0) + (b2 ? 1 : 0)] = d;
   __syncthreads();
+  if (!FINISH) return;   // cluster path: the caller sums the waves per value (thread i < NV) and exchanges
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     double s = 0.0;
 #pragma unroll
     for (int w = 0; w < REG_WAVES; ++w) s += slab[(buf * REG_WAVES + w) * 16 + i];
     out[i] = s;
+  }
+}
+
+// both words of a published double: the two granules are requested together, until both carry the tag
+__device__ __forceinline__ double reg_poll2(const unsigned long long *p, uint32_t tag, int &fail) {
+  unsigned long long v0, v1;
+  int spins = 0;
+  for (;;) {
+    v0 = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    v1 = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if ((uint32_t)(v0 >> 32) == tag && (uint32_t)(v1 >> 32) == tag) break;
+    // the members of a cluster are consecutive workgroups of one launch and become resident together; the limit only
+    // turns a broken assumption into an error code instead of a hang
+    if (++spins > REG_SPIN_LIMIT) { fail = 1; break; }
+    __builtin_amdgcn_s_sleep(2);
+  }
+  return __longlong_as_double((long long)((v1 << 32) | (v0 & 0xffffffffull)));
+}
+
+// Cluster-wide sum of the NV workgroup totals tot[0 .. NV) (LDS, written before the last barrier): every thread of
+// every member returns with the same out[] = sum over members 0 .. CL-1 in that order.  `seq` counts the exchanges of
+// this launch from 1 (tag; buffer = seq & 1: a member is at most one exchange ahead of the slowest one).  xl: LDS
+// [REG_CLMAX][17].  One barrier; the caller's next barrier separates these reads of xl from the next exchange's writes.
+template <int NV>
+__device__ __forceinline__ void cluster_sum(const double *tot, int CL, int j, unsigned long long *xb, uint32_t seq,
+                                            double *xl, int *fail_s, double (&out)[NV]) {
+  static_assert(2 * NV <= REG_XG && NV <= 17, "granules per member");
+  const int tid = threadIdx.x;
+  unsigned long long *buf = xb + (seq & 1u) * (REG_CLMAX * REG_XG);
+  if (tid < NV) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(tot[tid]);
+    const unsigned long long tg = (unsigned long long)seq << 32;
+    __hip_atomic_store(buf + j * REG_XG + 2 * tid, (bits & 0xffffffffull) | tg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(buf + j * REG_XG + 2 * tid + 1, (bits >> 32) | tg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (tid < CL * NV) {
+    const int jj = tid / NV, i = tid - jj * NV;
+    int fail = 0;
+    // (this member's own totals come back the same way: `tot` is another wave's LDS write, with no barrier in between)
+    xl[jj * 17 + i] = reg_poll2(buf + jj * REG_XG + 2 * i, seq, fail);
+    if (fail) *fail_s = 1;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    double sacc = xl[i];
+#pragma unroll
+    for (int jj = 1; jj < REG_CLMAX; ++jj)
+      if (jj < CL) sacc += xl[jj * 17 + i];
+    out[i] = sacc;
   }
 }
 
@@ -198,19 +274,30 @@ __global__ void __launch_bounds__(REG_THREADS) registration_kernel(RegArgs a) {
   __shared__ int wave_cnt[REG_WAVES];
   __shared__ float init_Rt[12];
   __shared__ int status_s;
-  const int p = blockIdx.x;
+  __shared__ double xl[REG_CLMAX * 17];   // the members' totals of one exchange
+  __shared__ double wg_tot[17];           // this workgroup's totals, as published
+  __shared__ int fail_s;
+  const int p = a.pair_base + blockIdx.x / REG_CLMAX, cj = blockIdx.x % REG_CLMAX;   // pair, member of its cluster
   const int64_t r0 = a.off0[p];
   const int n = (int)(a.off0[p + 1] - r0);
+  const int CL = reg_cluster_size(n);
+  if (cj >= CL) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float4 *cA = a.cA + r0, *cB = a.cB + r0;
+  // this member's compacted rows: its own region (capacity = its chunks x 256 rows)
+  const int chunks = (n + REG_THREADS - 1) / REG_THREADS;
+  const int64_t creg = r0 + (int64_t)p * REG_CLMAX * REG_THREADS + (int64_t)cj * ((chunks + CL - 1) / CL) * REG_THREADS;
+  float4 *cA = a.cA + creg, *cB = a.cB + creg;
   DgrRegResult *res = a.res + p;
+  unsigned long long *xb = a.xbuf + (int64_t)p * (2 * REG_CLMAX * REG_XG);
+  uint32_t seq = 0;
+  if (tid == 0) fail_s = 0;
 
   // ---- pass 1: weights (gate), compaction of w > 0 rows, Procrustes sums ---------------------
   double acc[17];
 #pragma unroll
   for (int i = 0; i < 17; ++i) acc[i] = 0.0;
   int m = 0;  // compacted count so far (uniform)
-  for (int base = 0; base < n; base += REG_THREADS) {
+  for (int base = cj * REG_THREADS; base < n; base += CL * REG_THREADS) {   // chunks cj, cj + CL, ...
     const int i = base + tid;
     float w = 0.f, x[3] = {0, 0, 0}, y[3] = {0, 0, 0};
     if (i < n) {
@@ -255,6 +342,13 @@ __global__ void __launch_bounds__(REG_THREADS) registration_kernel(RegArgs a) {
   }
   double S[17];
   block_sum<17>(acc, red, S);
+  if (CL > 1) {   // the pair's sums: every member's totals, added in member order (the same bits everywhere)
+    cluster_sum<17>(red + REG_WAVES * 17, CL, cj, xb, ++seq, xl, &fail_s, S);
+    if (fail_s) {
+      if (tid == 0 && cj == 0) { res->status = DGR_STATUS_EXCHANGE_TIMEOUT; res->iterations = 0; }
+      return;
+    }
+  }
 
   // ---- gate + weighted Procrustes (thread 0) ----------------------------------------------------
   if (tid == 0) {
@@ -290,13 +384,17 @@ __global__ void __launch_bounds__(REG_THREADS) registration_kernel(RegArgs a) {
           t[i] = (float)my[i] - (R[i * 3] * (float)mx[0] + R[i * 3 + 1] * (float)mx[1] + R[i * 3 + 2] * (float)mx[2]);
       }
     }
-    for (int i = 0; i < 9; ++i) { init_Rt[i] = R[i]; res->R[i] = R[i]; }
-    for (int i = 0; i < 3; ++i) { init_Rt[9 + i] = t[i]; res->t[i] = t[i]; }
-    res->wsum = (float)wsum;
-    res->status = status;
-    res->iterations = 0;
-    res->break_count = 0;
-    res->loss = 0.f;
+    for (int i = 0; i < 9; ++i) init_Rt[i] = R[i];
+    for (int i = 0; i < 3; ++i) init_Rt[9 + i] = t[i];
+    if (cj == 0) {   // (every member computes the same start from the same sums; one writes the record)
+      for (int i = 0; i < 9; ++i) res->R[i] = R[i];
+      for (int i = 0; i < 3; ++i) res->t[i] = t[i];
+      res->wsum = (float)wsum;
+      res->status = status;
+      res->iterations = 0;
+      res->break_count = 0;
+      res->loss = 0.f;
+    }
     status_s = status;
   }
   __syncthreads();
@@ -405,7 +503,24 @@ __global__ void __launch_bounds__(REG_THREADS) registration_kernel(RegArgs a) {
     for (int i = 0; i < 13; ++i) gd[i] = (double)g[i];
     block_sum_butterfly<13>(gd, slab, it & 1, Gs);
 #else
-    block_sum_butterfly<13>(g, slab, it & 1, Gs);
+    if (CL == 1) {
+      block_sum_butterfly<13>(g, slab, it & 1, Gs);
+    } else {
+      // the waves' sums per value (the same order as above), published, and the members' totals added in member order
+      block_sum_butterfly<13, false>(g, slab, it & 1, Gs);
+      if (tid < 13) {
+        double sw = 0.0;
+#pragma unroll
+        for (int w = 0; w < REG_WAVES; ++w) sw += slab[((it & 1) * REG_WAVES + w) * 16 + tid];
+        wg_tot[tid] = sw;
+      }
+      // (tid < 13 is one wave: its own LDS writes are visible to its own reads in cluster_sum without a barrier)
+      cluster_sum<13>(wg_tot, CL, cj, xb, ++seq, xl, &fail_s, Gs);
+      if (fail_s) {
+        if (tid == 0 && cj == 0) res->status = DGR_STATUS_EXCHANGE_TIMEOUT;
+        return;
+      }
+    }
 #endif
 #ifdef DGR_REG_TIMING
     const long long tc2 = clock64();
@@ -442,12 +557,12 @@ __global__ void __launch_bounds__(REG_THREADS) registration_kernel(RegArgs a) {
     }
     loss_prev = loss;
   }
-  if (tid == 0 && a.state_out) {
+  if (tid == 0 && cj == 0 && a.state_out) {
     for (int i = 0; i < 9; ++i) { a.state_out[i] = prm[i]; a.state_out[9 + i] = am[i]; a.state_out[18 + i] = av[i]; }
     a.state_out[27] = it; a.state_out[28] = loss_prev; a.state_out[29] = breaks;
   }
   if (it >= a.max_iter) it = a.max_iter - 1;  // python's `i` after an exhausted range()
-  if (tid == 0) {
+  if (tid == 0 && cj == 0) {
     Ortho o;
     ortho_forward(prm, o);
     res->R[0] = o.x[0]; res->R[1] = o.y[0]; res->R[2] = o.z[0];
@@ -464,9 +579,16 @@ __global__ void __launch_bounds__(REG_THREADS) registration_kernel(RegArgs a) {
   }
 }
 
-// needs 2 x float4 x total_rows of scratch; allocated by the callers below from the ctx arena
+// needs 2 x float4 x total_rows of scratch; allocated here from the ctx arena.
+// off0_host (nullable): the pairs' row offsets on the host, for slicing the batch.  The members of a cluster SPIN while
+// they wait for each other, and a member lands on the XCD its workgroup index selects -- exactly one member of an
+// 8-cluster per XCD.  Two such launches on different streams could fill each other's slots with spinners (an XCD holds
+// 64 workgroups of this kernel) if a launch carried dozens of clusters; a launch therefore carries at most
+// REG_MAX_SPINNERS members of multi-member clusters (8 pairs of 27 k rows: at most 8 of an XCD's 64 slots), the rest
+// of the batch follows in the next launch on the same stream.  Without the host offsets every pair counts as 8 members.
+constexpr int REG_MAX_SPINNERS = 64;
 static int launch_registration(dgr_ctx *ctx, const float *xyz0, const float *xyz1, const int64_t *idx1,
-                               const float *lw, int is_logit, float clip, const int64_t *off0_dev,
+                               const float *lw, int is_logit, float clip, const int64_t *off0_dev, const int64_t *off0_host,
                                int npairs, int64_t total_rows, float q, int max_iter, int max_break,
                                double ratio, int skip_refine, int gate, float eps, float *weights_out,
                                DgrRegResult *results_dev, hipStream_t stream, const double *state_in = nullptr,
@@ -474,23 +596,40 @@ static int launch_registration(dgr_ctx *ctx, const float *xyz0, const float *xyz
   RegArgs a;
   a.xyz0 = xyz0; a.xyz1 = xyz1; a.idx1 = idx1; a.lw = lw; a.off0 = off0_dev;
   a.weights_out = weights_out; a.res = results_dev;
-  DGR_ALLOC(a.cA, ctx->arena, float4, total_rows);
-  DGR_ALLOC(a.cB, ctx->arena, float4, total_rows);
+  // per-member compaction regions: a pair's rows + one chunk of slack per member
+  const int64_t crows = total_rows + (int64_t)npairs * REG_CLMAX * REG_THREADS;
+  DGR_ALLOC(a.cA, ctx->arena, float4, crows);
+  DGR_ALLOC(a.cB, ctx->arena, float4, crows);
+  DGR_ALLOC(a.xbuf, ctx->arena, unsigned long long, (int64_t)npairs * 2 * REG_CLMAX * REG_XG);
+  DGR_HIP_CHECK(hipMemsetAsync(a.xbuf, 0, (size_t)npairs * 2 * REG_CLMAX * REG_XG * sizeof(unsigned long long), stream));
   a.clip = clip; a.q = q; a.eps = eps;
   a.is_logit = is_logit; a.gate = gate; a.skip_refine = skip_refine;
   a.max_iter = max_iter; a.max_break = max_break; a.ratio = ratio;
   a.state_in = state_in; a.state_out = state_out;
-  registration_kernel<<<npairs, REG_THREADS, 0, stream>>>(a);
-  DGR_LAUNCH_CHECK();
+  for (int p0 = 0; p0 < npairs;) {
+    int p1 = p0, spinners = 0;
+    while (p1 < npairs && p1 - p0 < 4096) {
+      const int cl = off0_host ? reg_cluster_size((int)(off0_host[p1 + 1] - off0_host[p1])) : REG_CLMAX;
+      const int add = cl > 1 ? cl : 0;
+      if (p1 > p0 && spinners + add > REG_MAX_SPINNERS) break;
+      spinners += add;
+      ++p1;
+    }
+    a.pair_base = p0;
+    // REG_CLMAX consecutive workgroups per pair; those beyond the pair's cluster size exit at once
+    registration_kernel<<<(p1 - p0) * REG_CLMAX, REG_THREADS, 0, stream>>>(a);
+    DGR_LAUNCH_CHECK();
+    p0 = p1;
+  }
   return DGR_OK;
 }
 
 int dgr_registration_launch_ctx(dgr_ctx *ctx, const float *xyz0, const float *xyz1, const int64_t *idx1,
                                 const float *lw, int is_logit, float clip, const int64_t *off0_dev,
-                                int npairs, int64_t total_rows, float q, int max_iter, int max_break,
+                                const int64_t *off0_host, int npairs, int64_t total_rows, float q, int max_iter, int max_break,
                                 double ratio, int skip_refine, int gate, float eps, float *weights_out,
                                 DgrRegResult *results_dev, hipStream_t stream) {
-  return launch_registration(ctx, xyz0, xyz1, idx1, lw, is_logit, clip, off0_dev, npairs, total_rows, q,
+  return launch_registration(ctx, xyz0, xyz1, idx1, lw, is_logit, clip, off0_dev, off0_host, npairs, total_rows, q,
                              max_iter, max_break, ratio, skip_refine, gate, eps, weights_out, results_dev,
                              stream);
 }
@@ -519,11 +658,15 @@ static int run_single(dgr_ctx *ctx, const float *X, const float *Y, const float 
     DGR_ALLOC(st_out, ctx->arena, double, 30);
     DGR_HIP_CHECK(hipMemsetAsync(st_out, 0, 30 * sizeof(double), stream));
   }
-  DGR_CHECK(launch_registration(ctx, X, Y, nullptr, w, 0, 0.f, off, 1, N, q, max_iter, max_break, ratio,
+  DGR_CHECK(launch_registration(ctx, X, Y, nullptr, w, 0, 0.f, off, h_off, 1, N, q, max_iter, max_break, ratio,
                                 skip_refine, 0, eps, nullptr, res, stream, st_in, st_out));
   DGR_HIP_CHECK(hipMemcpyAsync(host_res, res, sizeof(DgrRegResult), hipMemcpyDeviceToHost, stream));
   if (state_out_host) DGR_HIP_CHECK(hipMemcpyAsync(state_out_host, st_out, 30 * sizeof(double), hipMemcpyDeviceToHost, stream));
   DGR_HIP_CHECK(hipStreamSynchronize(stream));
+  if (host_res->status == DGR_STATUS_EXCHANGE_TIMEOUT) {
+    dgr_set_error("registration: the workgroups sharing a pair lost each other (exchange timed out)");
+    return DGR_EINTERNAL;
+  }
   if (host_res->status == DGR_STATUS_SVD_FAILED) {
     dgr_set_error("weighted Procrustes: non-finite covariance, SVD failed");
     return DGR_ESVD;

@@ -66,6 +66,11 @@ class ResUNet2:
         if (type(other), other.D, other.in_channels, other.out_channels, other.conv1_kernel_size) != \
                 (type(self), self.D, self.in_channels, self.out_channels, self.conv1_kernel_size):
             raise ValueError('share_weights: the other model is a different network')
+        if other._net is None:
+            # the source's library handle belongs to the context of the thread that CREATED it: resolving it lazily from the
+            # sharer's thread would bind the loader's net to the wrong context (and two sharers could race on `other._net`)
+            raise RuntimeError('share_weights: the other model has no device-resident weights yet -- run it once, or call '
+                               'its _handle(), on the thread that owns it before sharing')
         self.normalize_feature = other.normalize_feature
         self._state = None
         self._share = other
@@ -77,7 +82,7 @@ class ResUNet2:
             share = getattr(self, '_share', None)
             if share is not None:
                 self._net = ops.NetHandle(None, self.D, self.in_channels, self.out_channels, self.conv1_kernel_size,
-                                          self.normalize_feature, self.device, share_from=share._handle())
+                                          self.normalize_feature, self.device, share_from=share._net)
                 return self._net
             if self._state is None:
                 raise RuntimeError('load_state_dict() must be called before the first forward')

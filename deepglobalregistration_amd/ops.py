@@ -63,9 +63,11 @@ class NetHandle:
         lib = _lib.load()
         self.device = torch.device(device)
         self.D, self.cin, self.cout = D, in_channels, out_channels
+        self.conv1_ks, self.normalize = int(conv1_kernel_size), bool(normalize_feature)
         if share_from is not None:
             # a net object for the calling thread's context over the weights `share_from` already holds (dgr_net_share)
-            if (share_from.D, share_from.cin, share_from.cout) != (D, in_channels, out_channels):
+            if (share_from.D, share_from.cin, share_from.cout, share_from.conv1_ks, share_from.normalize) != \
+                    (D, in_channels, out_channels, self.conv1_ks, self.normalize):
                 raise ValueError('share_from is a different network')
             h = vp()
             with torch.cuda.device(self.device):
@@ -396,7 +398,8 @@ def register_batch(fcgf, inlier, coords0, xyz0, off0, coords1, xyz1, off1, voxel
                    forced_logit=None, override_idx1=None, safeguard=False, use_icp=False, ransac_hypotheses=4000000,
                    ransac_seed=0):
     """Fused pipeline over a batch of voxelised pairs (dgr_register_batch).  Returns
-    T [npairs,4,4] (float32; float64 when the safeguard / ICP stages ran), status [npairs] int32, stats [npairs,4] float32.
+    T [npairs,4,4] float64 (what the reference's register() returns; fetched through dgr_register_batch_f64: the learned
+    f32 estimate widens exactly, the safeguard / ICP stages compute in float64), status [npairs] int32, stats [npairs,4] float32.
     `status` is a CODE plus FLAG bits:
     `status & _lib.STATUS_MASK` is 0 ok / 1 low confidence / 2 SVD failed / 3 safeguard (T from the RANSAC), and
     `_lib.STATUS_FLAG_ICP_SKIPPED` (0x100) is OR-ed on when `use_icp` was asked for but the final ICP could not run on the
@@ -431,14 +434,15 @@ def register_batch(fcgf, inlier, coords0, xyz0, off0, coords1, xyz1, off1, voxel
                                  ptr(coords1), ptr(xyz1), o1, npairs, C.byref(prm), ptr(ov), ptr(fl),
                                  T.ctypes.data_as(_lib.c_f32p), status.ctypes.data_as(_lib.c_i32p),
                                  stats.ctypes.data_as(_lib.c_f32p), stream_ptr(dev.index)))
-    if safeguard or use_icp:
-        # the RANSAC / ICP stages compute in float64 like Open3D: fetch their results at full width (the reference's
-        # register() returns np.float64); without them the f32 estimate widens exactly either way
-        T64 = np.empty((npairs, 16), np.float64)
-        n = C.c_int64(0)
-        check(lib.dgr_register_batch_f64(get_ctx(dev), T64.ctypes.data_as(_lib.c_f64p), npairs, C.byref(n)))
-        return T64.reshape(npairs, 4, 4), status, stats
-    return T.reshape(npairs, 4, 4), status, stats
+    # always at full width, whatever the flags (the RANSAC / ICP stages compute in float64 like Open3D; without them the
+    # f32 estimate widens exactly): one return dtype.  The library clears its float64 copy when a call starts, so a call
+    # that failed midway cannot leave an earlier batch's transforms to be read here.
+    T64 = np.empty((npairs, 16), np.float64)
+    n = C.c_int64(0)
+    check(lib.dgr_register_batch_f64(get_ctx(dev), T64.ctypes.data_as(_lib.c_f64p), npairs, C.byref(n)))
+    if n.value != npairs:
+        raise RuntimeError(f'dgr_register_batch_f64 holds {n.value} pairs, expected {npairs}')
+    return T64.reshape(npairs, 4, 4), status, stats
 
 
 _BATCH_OUT = {'idx1': (0, torch.int64), 'logit': (1, torch.float32), 'weights': (2, torch.float32),

@@ -49,7 +49,10 @@ enum { DGR_STATUS_OK = 0, DGR_STATUS_LOW_CONFIDENCE = 1, DGR_STATUS_SVD_FAILED =
        DGR_STATUS_SAFEGUARD = 3 /* gate failed, T from the safeguard RANSAC (dgr_params.safeguard) */,
        /* flag, OR-ed onto one of the codes above (status & DGR_STATUS_MASK): dgr_params.use_icp, but the final ICP could
           not run on this pair (no finite target point); T is the estimate the code names, before ICP */
-       DGR_STATUS_FLAG_ICP_SKIPPED = 0x100, DGR_STATUS_MASK = 0xff };
+       DGR_STATUS_FLAG_ICP_SKIPPED = 0x100, DGR_STATUS_MASK = 0xff,
+       /* internal: the workgroups that share a pair's refinement lost each other (never returned to the caller as a
+        * status: the call fails with DGR_EINTERNAL) */
+       DGR_STATUS_EXCHANGE_TIMEOUT = 0x7f };
 
 const char *dgr_last_error(void);
 const char *dgr_version(void);

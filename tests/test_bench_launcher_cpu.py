@@ -30,6 +30,18 @@ def test_gpus_2_starts_two_ranks_and_covers_512_pairs():
     assert out['weights_broadcast_keys'] > 100
 
 
+def test_gpus_8_starts_eight_ranks_weak_and_strong():
+    """The node the driver scales to: 8 ranks (gloo on this container's 8 cores).  Weak mode: 8 x S x B pairs, every pair
+    registered once; strong mode: BASELINE configs[3], 512 pairs dealt 64 per rank by cost."""
+    out = _run('--gpus', '8')
+    assert out['n_gpus'] == 8 and out['requested_gpus'] == 8
+    assert out['pairs'] == 8 * 3 * 6 and out['all_pairs_covered_once']     # the defaults: 3 streams x batches of 6 per rank
+    assert out['max_over_ranks'] == 8.0 and out['weights_broadcast_keys'] > 100
+    out = _run('--gpus', '8', '--total-pairs', '512')
+    assert out['n_gpus'] == 8 and out['pairs'] == 512 and out['all_pairs_covered_once']
+    assert out['pairs_per_rank'] == [64] * 8
+
+
 def test_gpus_1_runs_in_process():
     out = _run('--gpus', '1')
     assert out['n_gpus'] == 1 and out['all_pairs_covered_once']

@@ -73,3 +73,26 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
                     '-Wl,-rpath,/opt/rocm/lib'], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
     assert 'dgr_hip' in out
+
+
+def test_registration_kernel_has_no_packed_f32_arithmetic(tmp_path):
+    """reg.hip is built without the SLP vectoriser (csrc/Makefile: FLAGS_reg): builds of the registration kernel with packed
+    f32 arithmetic were not reproducible next to a second process on the GPU (tools/r06_runs/run2.sh,
+    run3.sh).  Guard: the object the library links contains the kernel WITHOUT v_pk_{fma,mul,add}_f32."""
+    import shutil
+    import subprocess
+    objdump = '/opt/rocm/lib/llvm/bin/llvm-objdump'
+    obj = os.path.join(ROOT, 'deepglobalregistration_amd', 'csrc', 'build', 'reg.o')
+    if not (os.path.exists(objdump) and os.path.exists(obj) and shutil.which('hipcc')):
+        pytest.skip('no build tree / ROCm tools')
+    mk = open(os.path.join(ROOT, 'deepglobalregistration_amd', 'csrc', 'Makefile')).read()
+    assert re.search(r'^FLAGS_reg\s*:=.*-fno-slp-vectorize', mk, flags=re.M)
+    # the device code object is bundled inside the host object: extract (next to a copy of the object), then disassemble
+    shutil.copy(obj, tmp_path / 'reg.o')
+    subprocess.run([objdump, '--offloading', 'reg.o'], check=True, capture_output=True, cwd=tmp_path)
+    co = [f for f in os.listdir(tmp_path) if 'gfx950' in f]
+    assert len(co) == 1, os.listdir(tmp_path)
+    asm = subprocess.run([objdump, '-d', co[0]], check=True, capture_output=True, text=True, cwd=tmp_path).stdout
+    assert 'registration_kernel' in asm
+    packed = re.findall(r'\bv_pk_(?:fma|mul|add)_f32\b', asm)
+    assert not packed, f'{len(packed)} packed-f32 instructions in reg.o'

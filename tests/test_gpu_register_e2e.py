@@ -168,7 +168,7 @@ def test_register_equals_the_reference_run():
                              break_threshold_ratio=1e-4, quantization_size=2 * float(g['voxel']))
 
 
-def test_register_with_icp_equals_the_reference_run():
+def test_register_with_icp_reproduces_the_recorded_run():
     """`register()` as shipped (`use_icp = True`, the reference's default) against the reference's own run through its
     ICP call site (:317-322; tests/golden/register_e2e_o3d.npz case `icp`)."""
     from test_oracle_register_golden import golden_case, golden_o3d
@@ -185,7 +185,7 @@ def test_register_with_icp_equals_the_reference_run():
     assert dT < 1e-4, dT
 
 
-def test_register_safeguard_equals_the_reference_run():
+def test_register_safeguard_reproduces_the_recorded_run():
     """Gate fails -> safeguard RANSAC -> ICP against the reference's own run through both Open3D call sites (:50-64,
     302-322; case `safeguard` of register_e2e_o3d.npz): same matches, same winning hypothesis and consensus, T to 1e-6."""
     from test_oracle_register_golden import golden_case, golden_o3d
