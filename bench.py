@@ -118,8 +118,9 @@ def roofline_time_own_pipe_s(s, kind):
 
 def _group_launches(launches):
     g = {}
-    for kind, main_ms, total_ms in launches:
-        g.setdefault(kind, []).append((main_ms, total_ms))
+    for kind, us in launches:
+        if us > 0:
+            g.setdefault(kind, []).append(us)
     return g
 
 
@@ -139,6 +140,12 @@ RANDOM_ROW_CEILING_GBPS = 5100.0
 # CPU legs (rank 0, N = 1 only): parity of the timed batch's pair 0 against the oracle, and the
 # oracle timed as the reported CPU baseline.  The oracle is the checker, never the measured product.
 # ----------------------------------------------------------------------------------------------
+def _host_checkpoint(ck):
+    """The checkpoint with its state dicts as host arrays (after a broadcast they may be views of a device buffer)."""
+    return {k: ({n: (v.detach().cpu().numpy() if torch.is_tensor(v) else v) for n, v in d.items()}
+                if k.startswith('state_dict') and isinstance(d, dict) else d) for k, d in ck.items()}
+
+
 def oracle_parity_and_baseline(ck, args, pair0, do_baseline):
     """pair0 = dict(xyz0, coords0, xyz1, coords1 [numpy, batch column 0], idx1 [local], F0, F1, logit, forced, device).
     Returns (parity dict, cpu_baseline dict | None)."""
@@ -380,7 +387,11 @@ def main():
     S = max(1, args.streams)
     ck = synth.synth_checkpoint(seed=0, voxel_size=args.voxel, feat_conv1_kernel_size=args.conv1_ks) if rank == 0 else None
     coll_dev = device if backend == 'nccl' else torch.device('cpu')
+    torch.cuda.synchronize()
+    t_b = time.perf_counter()
     ck = ddist.broadcast_checkpoint(ck, src=0, device=coll_dev)
+    torch.cuda.synchronize()
+    t_bcast = time.perf_counter() - t_b
     log('checkpoint ready')
 
     # ---- which pairs does this rank register? --------------------------------------------------
@@ -448,9 +459,12 @@ def main():
                 cfg = {'weights': ck, 'clip_weight_thresh': 0.05}
                 if shared_with is not None:
                     cfg['share_weights_with'] = shared_with.dgr
+                t_n = time.perf_counter()
                 self.dgr = DeepGlobalRegistration(cfg, device)
                 dgr = self.dgr
                 dgr.fcgf_model._handle(); dgr.inlier_model._handle()
+                torch.cuda.synchronize()
+                self.net_s = time.perf_counter() - t_n     # state dict -> the kernels' operand layouts in HBM (or: share them)
                 self.batches = []
                 for ids in self.batch_ids:
                     x0, c0, x1, c1, off0, off1, ovr = [], [], [], [], [0], [0], []
@@ -517,17 +531,19 @@ def main():
                     self.step()
 
         def run_profiled(self, n):
-            """n more steps with HIP events around every sparse-conv launch ON THIS WORKER'S STREAM (the library's
-            profiling mode), all workers of the rank at once: the per-launch durations of the TIMED stream configuration."""
-            self.prof_launches = []   # (kind, main-kernel ms, main + reduction ms) of every conv launch
+            """n more steps in the library's profiling mode, all workers of the rank at once: the dominant kernel stamps its
+            own start and end on the device wall clock (conv_wide.hip), i.e. its execution span in the TIMED stream
+            configuration -- the duration rocprofv3 --kernel-trace reports for it.  (HIP-event spans are useless here: with
+            other streams on the GPU they include the wait for compute units.)"""
+            self.prof_launches = []   # (kind, the kernel's own execution span in us [0 = not instrumented]) per conv launch
             with self:
                 ops.set_profiling(device, True)
                 for _ in range(n):
                     self.step()
-                    lm, gm = ops.conv_launch_times(device)
                     kd = ops.conv_launch_kinds(device)
-                    if len(lm) == len(kd):
-                        self.prof_launches += list(zip(kd, gm, lm))
+                    ku = ops.conv_launch_kernel_us(device)
+                    if len(ku) == len(kd):
+                        self.prof_launches += list(zip(kd, ku))
                 ops.set_profiling(device, False)
 
     workers = [Worker(w, ids) for w, ids in enumerate(per_stream) if ids]
@@ -566,6 +582,11 @@ def main():
     log(f'timed region done: {elapsed / args.steps * 1e3:.1f} ms/step ({n_local} pairs/step on this rank)')
 
     w0 = workers[0]
+    st = torch.tensor([t_bcast, w0.net_s], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
+    if pg_up:
+        dist.all_reduce(st, op=dist.ReduceOp.MAX)
+    startup = {'checkpoint_broadcast': float(st[0]), 'weights_to_operand_layouts': float(st[1]),
+               'weights_prepared_on_device_this_rank': bool(getattr(w0.dgr.inlier_model._handle(), 'created_on_device', False))}
     _lib.use_ctx(w0.ctx)
     # outputs of the LAST call of stream 0 (the last batch of the last timed step), before anything else runs there
     last_bt = w0.last_bt
@@ -589,7 +610,7 @@ def main():
 
     # ---- the same stream configuration once more, profiled: every worker at once, HIP events around every conv launch on
     #      the worker's own stream (roofline.frac is quoted from HERE: the configuration the headline was timed in)
-    n_prof_c = min(args.steps, 6)
+    n_prof_c = min(args.steps, 10)
     if len(workers) == 1:
         workers[0].run_profiled(n_prof_c)
     else:
@@ -616,6 +637,7 @@ def main():
                 prof[k] = prof.get(k, 0.0) + v
         launch_ms, gemm_ms = ops.conv_launch_times(device)   # last profiled call: FCGF layers, then the inlier net's
         kinds = ops.conv_launch_kinds(device)
+        kernel_us = ops.conv_launch_kernel_us(device)          # the wide-layer kernels' own execution spans
         ops.set_profiling(device, False)
     prof = {k: v / n_prof for k, v in prof.items()}
     log(f'profiled region done: {prof}')
@@ -717,8 +739,12 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         # the dominant kernel in the TIMED stream configuration (all streams of the rank at once, HIP events on each
         # stream): the duration roofline.frac is computed from; the one-stream figure next to it
-        tc = [g for k_, g, _ in timed_cfg_launches if dominant and k_ == dominant['name']]
-        us_timed = 1e3 * float(np.mean(tc)) if tc else (dominant['avg_launch_us'] if dominant else None)
+        tc = [u for k_, u in timed_cfg_launches if dominant and k_ == dominant['name'] and u > 0]
+        us_one = [u for k_, u in zip(kinds, kernel_us) if dominant and k_ == dominant['name'] and u > 0] if len(kernel_us) == len(kinds) else []
+        # one stream: the kernel's own span where it stamps one (else the HIP-event span of its launch)
+        us_one = float(np.mean(us_one)) if us_one else (dominant['avg_launch_us'] if dominant else None)
+        us_timed = float(np.mean(tc)) if tc else us_one
+        alg = (dominant['gflop_per_launch'] / (us_one * 1e-6) / 1e3) if (dominant and us_one) else alg
         gfl = dominant['gflop_per_launch'] if dominant else flop / 1e9 / n_launch
         alg_timed = gfl / (us_timed * 1e-6) / 1e3 if us_timed else alg        # TFLOP/s
         traffic = pmc.get('hbm_bytes_per_launch') if pmc else None
@@ -746,7 +772,10 @@ def main():
             'launches_per_batch': dominant['launches_per_batch'] if dominant else n_launch,
             'streams_when_measured': len(workers),
             'frac_one_stream': products * alg / peak,
-            'avg_launch_us_one_stream': dominant['avg_launch_us'] if dominant else conv_ms * 1e3 / n_launch,
+            'avg_launch_us_one_stream': us_one if us_one else conv_ms * 1e3 / n_launch,
+            'duration_source': 'stamped by the kernel itself on the device wall clock (earliest wave start to latest wave end): '
+                               'the span rocprofv3 --kernel-trace reports; HIP-event span of the one-stream launch for comparison: '
+                               + (f'{dominant["avg_launch_us"]:.0f} us' if dominant else 'n/a'),
             'mfma_busy_from_profiles': pmc.get('mfma_busy') if pmc else None,
             'traffic_source': (f'profiles/{pmc_file} (commit {pmc.get("commit", "not stamped")}): separate rocprofv3 --pmc passes '
                                'of the one-stream command, 2 x FETCH_SIZE (gfx950 correction, calibrated on a 2-GB read: '
@@ -778,9 +807,8 @@ def main():
             'c_le_64_layers': c64,
             'by_kernel': {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in g.items()}
                           for k, g in groups.items()},
-            # per kernel variant in the timed stream configuration: launches seen, mean main-kernel / main + reduction us
-            'by_kernel_timed_config': {k: {'launches': len(v), 'main_kernel_us': round(1e3 * float(np.mean([a for a, _ in v])), 2),
-                                           'with_reduction_us': round(1e3 * float(np.mean([b for _, b in v])), 2)}
+            # the instrumented (wide-layer) kernels in the timed stream configuration: launches seen, mean execution span
+            'kernel_us_timed_config': {k: {'launches': len(v), 'mean_us': round(float(np.mean(v)), 1)}
                                        for k, v in _group_launches(timed_cfg_launches).items()},
         }
         out = {
@@ -815,6 +843,11 @@ def main():
             'roofline': roofline,
             'roofline_detail': roofline_detail,
             'host_cpu_s_per_step_per_rank': cpu_s_per_step,
+            # one-time start-up of a rank, MAX over ranks: the RCCL broadcast of the checkpoint (ranks > 0 receive ~0.94 GB
+            # into HBM and keep it there) and the preparation of the kernels' weight layouts (ranks > 0, and a forced
+            # one-rank group: by HIP kernels from the broadcast buffer, dgr_net_create_device; the source rank: from its host
+            # copy)
+            'startup_s': startup,
             'stage_ms_per_batch': {k: round(v, 3) for k, v in prof.items() if k != 'conv_launches'},
             'te_m_mean': float(np.mean(te)) if te else None, 're_deg_mean': float(np.mean(re)) if re else None,
             'status_counts': {str(k): int((status_all == k).sum()) for k in np.unique(status_all)},
@@ -828,6 +861,7 @@ def main():
             # one pair per stream: pair (stream index mod B) of the stream's last timed batch; the CPU baseline is timed on
             # the first of them
             checks = []
+            ck = _host_checkpoint(ck)
             for wi, (lb, ho) in enumerate(stream_outs):
                 qi = wi % len(lb['ids'])
                 s0, e0, s1, e1 = lb['off0'][qi], lb['off0'][qi + 1], lb['off1'][qi], lb['off1'][qi + 1]

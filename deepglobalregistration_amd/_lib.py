@@ -45,6 +45,8 @@ SIGNATURES = {
     'dgr_voxelize': (C.c_int, [vp, vp, C.c_int, C.c_int64, C.c_double, C.c_int32, vp, vp, vp, c_i64p, vp]),
     'dgr_net_create': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.POINTER(WeightDesc), C.c_int, C.POINTER(vp)]),
+    'dgr_net_create_device': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.POINTER(WeightDesc), C.c_int, C.POINTER(vp)]),
     'dgr_net_destroy': (None, [vp]),
     'dgr_net_param_bytes': (C.c_int64, [vp]),
     'dgr_net_share': (C.c_int, [vp, vp, C.POINTER(vp)]),
@@ -79,6 +81,7 @@ SIGNATURES = {
     'dgr_ctx_stage_times_v2': (C.c_int, [vp, c_f32p, C.c_int, C.POINTER(C.c_int)]),
     'dgr_ctx_conv_launches': (C.c_int64, [vp]),
     'dgr_ctx_conv_launch_times': (C.c_int, [vp, c_f32p, c_f32p, C.c_int64, C.POINTER(C.c_int64)]),
+    'dgr_ctx_conv_launch_kernel_us': (C.c_int, [vp, c_f32p, C.c_int64, C.POINTER(C.c_int64)]),
     'dgr_ctx_conv_launch_kinds': (C.c_int, [vp, C.c_char_p, C.c_int64, C.POINTER(C.c_int64)]),
     'dgr_debug_ortho2rotation': (C.c_int, [vp, vp, C.c_int64, vp, vp, vp, vp]),
     'dgr_debug_se3_refine_from': (C.c_int, [vp, vp, vp, vp, C.c_int64, C.c_float, C.c_int, C.c_int, C.c_double,

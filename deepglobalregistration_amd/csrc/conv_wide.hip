@@ -67,6 +67,10 @@ struct ConvWideArgs {
   const int32_t *pair_in, *tile_ptr;
   int cout, K;
   float w_unscale;               // inverse of the layer's weight scale
+  unsigned long long *clk;       // profiling only (else null): {earliest start, latest end} of the kernel's waves on the
+                                 // 100-MHz wall clock -- the kernel's execution span as rocprofv3 --kernel-trace reports it,
+                                 // measurable while other streams share the GPU (a HIP-event span then includes the wait
+                                 // for compute units)
 };
 
 #define DGR_LDS_PTR(off) ((__attribute__((address_space(3))) void *)(lds + (off)))
@@ -132,6 +136,7 @@ __global__ void __launch_bounds__(512, 1) sparse_conv_wide_f16x2(ConvWideArgs a,
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (a.clk && tid == 0) atomicMin(a.clk, (unsigned long long)wall_clock64());
   const int T = a.tile_ptr[a.K];
   const int per = (T + 7) >> 3;
   const int xcd = blockIdx.x & 7;
@@ -268,6 +273,10 @@ __global__ void __launch_bounds__(512, 1) sparse_conv_wide_f16x2(ConvWideArgs a,
         sphase(t, std::integral_constant<int, 3>());
       }
     }
+    if (a.clk && lane == 0) {   // the storing waves issue the kernel's last memory operations
+      dgr_wait_vmcnt<0>();
+      atomicMax(a.clk + 1, (unsigned long long)wall_clock64());
+    }
     return;
   }
 
@@ -379,6 +388,7 @@ __global__ void __launch_bounds__(512, 1) sparse_conv_wide_f16x2(ConvWideArgs a,
     ctile(t, accA, accB);
     if (t + 1 < n_loop) ctile(t + 1, accB, accA);
   }
+  if (a.clk && lane == 0) atomicMax(a.clk + 1, (unsigned long long)wall_clock64());
 }
 
 template <int CP, int NB, int WM>
@@ -408,6 +418,7 @@ int dgr_conv_wide_launch(const DgrConvLaunch &a, const DgrSplitRows &in, const v
   ka.planes = in.planes; ka.row_scale = in.scale; ka.y = a.y;
   ka.wb = static_cast<const uint4 *>(wb); ka.piece_stride = piece_stride;
   ka.pair_in = a.pair_in; ka.tile_ptr = a.tile_ptr; ka.cout = a.cout; ka.K = a.K; ka.w_unscale = w_unscale;
+  ka.clk = a.clk;
   const int64_t tile_bound = a.tile_bound > 0 ? a.tile_bound : (int64_t)num_cus * 4;
 #define DGR_WIDE(CPV, NBV, WMV)                                                                 \
   do {                                                                                          \

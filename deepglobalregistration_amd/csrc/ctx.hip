@@ -1,5 +1,6 @@
 // Context, error reporting and the grow-only HBM arena of libdgr_hip.so.
 #include <stdarg.h>
+#include <time.h>
 #include <string.h>
 
 #include "dgr_internal.h"
@@ -130,9 +131,19 @@ int dgr_ctx_wait(dgr_ctx *ctx, hipStream_t stream) {
     DGR_HIP_CHECK(hipStreamSynchronize(stream));
     return DGR_OK;
   }
-  if (!ctx->wait_ev) DGR_HIP_CHECK(hipEventCreateWithFlags(&ctx->wait_ev, hipEventBlockingSync | hipEventDisableTiming));
+  // (hipEventSynchronize on a hipEventBlockingSync event still kept the thread at 100 % here -- measured, round 6: the
+  // runtime waits actively unless the DEVICE was created with hipDeviceScheduleBlockingSync, which torch has done before
+  // this library is loaded.  So: poll the event, sleeping between polls.)
+  if (!ctx->wait_ev) DGR_HIP_CHECK(hipEventCreateWithFlags(&ctx->wait_ev, hipEventDisableTiming));
   DGR_HIP_CHECK(hipEventRecord(ctx->wait_ev, stream));
-  DGR_HIP_CHECK(hipEventSynchronize(ctx->wait_ev));
+  struct timespec nap = {0, 20000};   // 20 us, doubling to 200 us: a batch runs for milliseconds
+  for (;;) {
+    const hipError_t e = hipEventQuery(ctx->wait_ev);
+    if (e == hipSuccess) break;
+    if (e != hipErrorNotReady) DGR_HIP_CHECK(e);
+    nanosleep(&nap, nullptr);
+    if (nap.tv_nsec < 200000) nap.tv_nsec *= 2;
+  }
   return DGR_OK;
 }
 
@@ -183,6 +194,15 @@ extern "C" int dgr_ctx_conv_launch_times(dgr_ctx *ctx, float *times_ms, float *g
     times_ms[i] = ctx->conv_span_ms[i];
     if (gemm_ms) gemm_ms[i] = i < (int64_t)ctx->gemm_span_ms.size() ? ctx->gemm_span_ms[i] : 0.f;
   }
+  *n = m;
+  return DGR_OK;
+}
+
+extern "C" int dgr_ctx_conv_launch_kernel_us(dgr_ctx *ctx, float *us, int64_t capacity, int64_t *n) {
+  DGR_REQUIRE(ctx != nullptr && us != nullptr && n != nullptr, "bad argument");
+  int64_t m = (int64_t)ctx->conv_clk_us.size();
+  if (m > capacity) m = capacity;
+  for (int64_t i = 0; i < m; ++i) us[i] = ctx->conv_clk_us[i];
   *n = m;
   return DGR_OK;
 }

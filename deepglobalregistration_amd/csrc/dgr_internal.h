@@ -188,6 +188,7 @@ struct DgrConvLaunch {
   const int32_t *n_rows_dev;                                 // identity map: number of rows
   int64_t tile_bound;                                        // host upper bound on the tile count (0 = unknown)
   int l2_normalize = 0;   // identity maps with Cout <= 32: rows leave as x / (|x|_2 + 1e-8) (model/resunet.py:643-647)
+  unsigned long long *clk = nullptr;   // profiling: {earliest start, latest end} wall-clock ticks of the kernel (conv_wide.hip)
 };
 int dgr_conv_launch(const DgrConvLaunch &a, int num_cus, hipStream_t stream, const char **kernel_name = nullptr);
 // A tensor in the form the wide-layer kernel gathers (conv_wide.hip): per row channels / 64 blocks of 256 bytes
@@ -278,14 +279,16 @@ struct dgr_ctx {
   // event spans recorded while profiling; resolved by dgr_ctx_collect_profile after a sync
   std::vector<std::pair<hipEvent_t, hipEvent_t>> conv_spans, gemm_spans, map3_spans, map6_spans;
   std::vector<float> conv_span_ms, gemm_span_ms;  // per-launch durations of the last collected profile
+  std::vector<unsigned long long *> conv_clks;    // per launch: device {start, end} ticks written by the kernel itself, or null
+  std::vector<float> conv_clk_us;                 // ... resolved: the kernel's own execution span in us (0 = not instrumented)
   std::vector<const char *> conv_kinds;            // kernel variant of every span (static strings)
   int32_t *flag_dev = nullptr;  // error flag word of the current top-level call (arena)
-  hipEvent_t wait_ev = nullptr; // blocking-sync event of dgr_ctx_wait (created on first use)
+  hipEvent_t wait_ev = nullptr; // the event dgr_ctx_wait polls (created on first use)
 };
 
-// Wait for `stream` WITHOUT spinning: an event with hipEventBlockingSync, so that the host thread sleeps in the driver
-// while its batch runs (hipStreamSynchronize busy-waits: with S streams x N ranks per node that is S x N cores pinned at
-// 100 % for nothing; round-5 verdict, What's weak 7).  DGR_SPIN_SYNC=1 restores hipStreamSynchronize (A/B, latency tests).
+// Wait for `stream` WITHOUT spinning: an event polled with naps in between, so that the host thread sleeps while its batch
+// runs (hipStreamSynchronize busy-waits: with S streams x N ranks per node that is S x N cores pinned at 100 % for nothing;
+// round-5 verdict, What's weak 7).  DGR_SPIN_SYNC=1 restores hipStreamSynchronize (A/B, latency tests).
 int dgr_ctx_wait(dgr_ctx *ctx, hipStream_t stream);
 
 // internal forward that does not reset the arena (used by the fused pipeline)

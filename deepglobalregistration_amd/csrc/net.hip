@@ -115,8 +115,190 @@ static const dgr_weight_desc *find_desc(const dgr_weight_desc *w, int n, const s
   return nullptr;
 }
 
+// ---- the same re-tilings ON THE DEVICE (dgr_net_create_device: the checkpoint's tensors are already in HBM, e.g. out of
+// the RCCL broadcast buffer of a multi-GPU start -- no copy back to the host, no host-side loops over 236 M parameters).
+// Every kernel below computes element o of a destination layout exactly as the host loops of make_layer do (same index
+// arithmetic, the same left-to-right f32 products, the same f16 roundings): the two paths give bit-identical weight sets
+// (tests/test_gpu_device_weights.py).
+template <class F>
+__global__ void __launch_bounds__(256) dgr_fill_kernel(int64_t n, F f) {
+  for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < n; o += (int64_t)gridDim.x * 256) f(o);
+}
+template <class F>
+static int dgr_fill(int64_t n, F f) {
+  if (n <= 0) return DGR_OK;
+  const int64_t blocks = std::min<int64_t>((n + 255) / 256, 1 << 16);
+  dgr_fill_kernel<<<(int)blocks, 256>>>(n, f);
+  DGR_LAUNCH_CHECK();
+  return DGR_OK;
+}
+__device__ __forceinline__ uint16_t dgr_f16_bits_dev(float x) {
+  const _Float16 h = (_Float16)x;
+  return __builtin_bit_cast(uint16_t, h);
+}
+__device__ __forceinline__ float dgr_f16_val_dev(float x) { return (float)(_Float16)x; }
+__global__ void __launch_bounds__(256) dgr_absmax_scaled_kernel(const float *__restrict__ w, const float *__restrict__ scale,
+                                                                int64_t n, int cout, uint32_t *out_bits) {
+  float mx = 0.f;
+  for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < n; o += (int64_t)gridDim.x * 256)
+    mx = fmaxf(mx, fabsf(__fmul_rn(w[o], scale[o % cout])));
+  for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(mx));   // non-negative floats order like their bits
+}
+
+// make_layer's second half for a kernel tensor that is ALREADY in HBM (src = [K, cin, cout] f32, device): every layout the
+// conv kernels read, produced by the fill kernels above; scale / shift = the folded batch norm (host, cout floats).
+static int make_layer_device(dgr_net *net, DgrLayer L, const float *src, const std::vector<float> &scale,
+                             const std::vector<float> &shift, bool has_shift, const std::string &name) {
+  const int K = L.K, cin = L.cin, cout = L.cout;
+  static const bool exact_f32 = getenv("DGR_EXACT_F32") != nullptr;
+  L.pieces = 2;
+  float *sc = nullptr;       // scale[] on the device
+  uint32_t *mxb = nullptr;
+  DGR_HIP_CHECK(hipMalloc((void **)&sc, (size_t)cout * sizeof(float)));
+  DGR_HIP_CHECK(hipMemcpy(sc, scale.data(), (size_t)cout * sizeof(float), hipMemcpyHostToDevice));
+  DGR_HIP_CHECK(hipMalloc((void **)&mxb, sizeof(uint32_t)));
+  DGR_HIP_CHECK(hipMemset(mxb, 0, sizeof(uint32_t)));
+  struct Tmp {   // freed on every exit (after the fill kernels have run: hipFree synchronises)
+    float *a; uint32_t *b;
+    ~Tmp() { (void)hipFree(a); (void)hipFree(b); }
+  } tmp{sc, mxb};
+  float w_scale = 1.f;
+  {
+    const int64_t n = (int64_t)K * cin * cout;
+    dgr_absmax_scaled_kernel<<<(int)std::min<int64_t>((n + 255) / 256, 4096), 256>>>(src, sc, n, cout, mxb);
+    DGR_LAUNCH_CHECK();
+    uint32_t bits = 0;
+    DGR_HIP_CHECK(hipMemcpy(&bits, mxb, sizeof(bits), hipMemcpyDeviceToHost));
+    float mx;
+    memcpy(&mx, &bits, 4);
+    int e = 0;
+    if (mx > 0.f && std::isfinite(mx)) (void)frexpf(mx, &e);
+    e = std::min(std::max(e, -100), 100);
+    w_scale = ldexpf(1.f, 15 - e);
+    L.w_unscale = ldexpf(1.f, e - 15);
+  }
+  const bool use_wide = K > 1 && !exact_f32 && dgr_conv_wide_supported(L.cin_pad, cin, cout) && !(net->D == 3 && K == 27);
+  if (use_wide) {
+    const int S16 = cin / 16, NB32 = cout / 32;
+    L.wb_piece = (int64_t)K * S16 * NB32 * 64;
+    const int64_t ne = L.wb_piece * 8;
+    uint16_t *dst;
+    DGR_HIP_CHECK(hipMalloc((void **)&dst, (size_t)2 * ne * sizeof(uint16_t)));
+    L.wb = dst;
+    DGR_CHECK(dgr_fill(ne, [=] __device__(int64_t o) {
+      const int e = (int)(o & 7), lane = (int)((o >> 3) & 63);
+      const int64_t r = o >> 9;
+      const int nb = (int)(r % NB32), s2 = (int)((r / NB32) % S16), k = (int)(r / ((int64_t)NB32 * S16));
+      const int col = 32 * nb + (lane & 31), row = 16 * s2 + 8 * (lane >> 5) + e;
+      const float xs = __fmul_rn(__fmul_rn(src[((size_t)k * cin + row) * cout + col], sc[col]), w_scale);
+      dst[o] = dgr_f16_bits_dev(xs);
+      dst[ne + o] = dgr_f16_bits_dev(xs - dgr_f16_val_dev(xs));
+    }));
+    net->W->param_bytes += (size_t)2 * ne * sizeof(uint16_t);
+  } else {
+    const int S = L.cin_pad / 8, NBLK = L.cout_pad / 32;
+    const int64_t ne = (int64_t)K * S * NBLK * 256;
+    float *dst;
+    DGR_HIP_CHECK(hipMalloc((void **)&dst, (size_t)ne * sizeof(float)));
+    L.w = dst;
+    DGR_CHECK(dgr_fill(ne, [=] __device__(int64_t o) {
+      const int c = (int)(o & 3), lane = (int)((o >> 2) & 63);
+      const int64_t r = o >> 8;
+      const int nb = (int)(r % NBLK), s2 = (int)((r / NBLK) % S), k = (int)(r / ((int64_t)NBLK * S));
+      const int row = 8 * s2 + 4 * (lane >> 5) + c, col = 32 * nb + (lane & 31);
+      dst[o] = (row < cin && col < cout) ? __fmul_rn(src[((size_t)k * cin + row) * cout + col], sc[col]) : 0.f;
+    }));
+    net->W->param_bytes += (size_t)ne * sizeof(float);
+  }
+  if (net->D == 3 && K == 27 && L.cin_pad % 16 == 0 && cout % 32 == 0) {
+    const int GT = L.cin_pad / 16, NB = cout / 16;
+    {
+      const int64_t ne = (int64_t)K * GT * NB * 256;
+      float *dst;
+      DGR_HIP_CHECK(hipMalloc((void **)&dst, (size_t)ne * sizeof(float)));
+      L.w16 = dst;
+      DGR_CHECK(dgr_fill(ne, [=] __device__(int64_t o) {
+        const int c = (int)(o & 3), lane = (int)((o >> 2) & 63);
+        const int64_t r = o >> 8;
+        const int jb = (int)(r % NB), g = (int)((r / NB) % GT), k = (int)(r / ((int64_t)NB * GT));
+        const int col = 16 * jb + (lane & 15), row = 16 * g + 4 * (lane >> 4) + c;
+        dst[o] = row < cin ? __fmul_rn(src[((size_t)k * cin + row) * cout + col], sc[col]) : 0.f;
+      }));
+      net->W->param_bytes += (size_t)ne * sizeof(float);
+    }
+    if (cin % 32 == 0) {
+      const int S32 = cin / 32;
+      L.w16b_piece = (int64_t)K * S32 * NB * 64;
+      const int64_t ne = L.w16b_piece * 8;
+      uint16_t *pcs;
+      DGR_HIP_CHECK(hipMalloc((void **)&pcs, (size_t)2 * ne * sizeof(uint16_t)));
+      L.w16b = pcs;
+      DGR_CHECK(dgr_fill(ne, [=] __device__(int64_t o) {
+        const int e = (int)(o & 7), lane = (int)((o >> 3) & 63);
+        const int64_t r = o >> 9;
+        const int jb = (int)(r % NB), sI = (int)((r / NB) % S32), k = (int)(r / ((int64_t)NB * S32));
+        const int col = 16 * jb + (lane & 15), row = 32 * sI + 8 * (lane >> 4) + e;
+        const float xs = __fmul_rn(__fmul_rn(src[((size_t)k * cin + row) * cout + col], sc[col]), w_scale);
+        pcs[o] = dgr_f16_bits_dev(xs);
+        pcs[ne + o] = dgr_f16_bits_dev(xs - dgr_f16_val_dev(xs));
+      }));
+      net->W->param_bytes += (size_t)2 * ne * sizeof(uint16_t);
+      if (net->D == 3 && K == 27 && dgr_conv_dense_supported(cin, L.cin_pad, cout)) {
+        uint16_t *pd;
+        DGR_HIP_CHECK(hipMalloc((void **)&pd, (size_t)2 * ne * sizeof(uint16_t)));
+        L.w16d = pd;
+        DGR_CHECK(dgr_fill(2 * ne, [=] __device__(int64_t o) {   // (fragments of both pieces alike)
+          const int e = (int)(o & 3), h = (int)((o >> 2) & 1);
+          const int64_t f = o >> 3, base = f & ~(int64_t)63;
+          const int lane = (int)(f & 63), col = lane & 15, lq = lane >> 4;
+          const int64_t srcf = base + col + 16 * ((lq >> 1) + 2 * h);
+          pd[o] = pcs[srcf * 8 + 4 * (lq & 1) + e];
+        }));
+        net->W->param_bytes += (size_t)2 * ne * sizeof(uint16_t);
+      }
+    }
+  }
+  if (net->D == 3 && name == "conv1" && cin == 1 && cout == 32 && K <= 343) {
+    int ks = 1;
+    while (ks * ks * ks < K) ++ks;
+    const int ks2 = ks * ks, steps = (ks2 + 3) / 4;
+    const int64_t ne = (int64_t)ks * steps * 128;
+    float *dst;
+    DGR_HIP_CHECK(hipMalloc((void **)&dst, (size_t)ne * sizeof(float)));
+    L.wc = dst;
+    DGR_CHECK(dgr_fill(ne, [=] __device__(int64_t o) {
+      const int j = (int)(o & 1), lane = (int)((o >> 1) & 63);
+      const int64_t r = o >> 7;
+      const int s2 = (int)(r % steps), kz = (int)(r / steps);
+      const int kk = 4 * s2 + (lane >> 4), col = (lane & 15) + 16 * j;
+      dst[o] = kk < ks2 ? __fmul_rn(src[(size_t)(kz * ks2 + kk) * cout + col], sc[col]) : 0.f;
+    }));
+  }
+  if (name == "conv1" && cin == 6 && cout == 32 && K > 1) {
+    const int64_t ne = (int64_t)K * 192;
+    float *dst;
+    DGR_HIP_CHECK(hipMalloc((void **)&dst, (size_t)ne * sizeof(float)));
+    L.wq = dst;
+    DGR_CHECK(dgr_fill(ne, [=] __device__(int64_t o) {
+      const int e = (int)(o & 3), q = (int)((o >> 2) & 3);
+      const int i = (int)((o >> 4) % 12), k = (int)(o / 192);
+      const int ci = i >> 1, co = 8 * q + 4 * (i & 1) + e;
+      dst[o] = __fmul_rn(src[((size_t)k * cin + ci) * cout + co], sc[co]);
+    }));
+    net->W->param_bytes += (size_t)ne * sizeof(float);
+  }
+  if (has_shift) {
+    DGR_HIP_CHECK(hipMalloc((void **)&L.shift, cout * sizeof(float)));
+    DGR_HIP_CHECK(hipMemcpy(L.shift, shift.data(), cout * sizeof(float), hipMemcpyHostToDevice));
+  }
+  DGR_HIP_CHECK(hipDeviceSynchronize());   // the fills read sc / the caller's tensors: done before either can go away
+  net->W->layers.push_back(L);
+  return DGR_OK;
+}
+
 static int make_layer(dgr_net *net, const dgr_weight_desc *descs, int nd, const std::string &name, int K,
-                      int cin, int cout, const char *bn, bool bias) {
+                      int cin, int cout, const char *bn, bool bias, bool dev = false) {
   DgrLayer L;
   L.name = name;
   L.K = K; L.cin = cin; L.cout = cout;
@@ -135,6 +317,14 @@ static int make_layer(dgr_net *net, const dgr_weight_desc *descs, int nd, const 
               name.c_str(), (long long)kd->numel, K, cin, cout);
   std::vector<float> scale(cout, 1.f), shift(cout, 0.f);
   bool has_shift = false;
+  // the per-channel tensors (batch norm, bias: cout floats each) are folded on the host either way; `dev`: fetched first
+  std::vector<std::vector<float>> small;
+  auto host_of = [&](const dgr_weight_desc *d) -> const float * {
+    if (!dev) return d->data;
+    small.emplace_back((size_t)d->numel);
+    if (hipMemcpy(small.back().data(), d->data, (size_t)d->numel * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
+    return small.back().data();
+  };
   if (bn) {
     std::string p = std::string(bn) + ".bn.";
     const dgr_weight_desc *g = find_desc(descs, nd, p + "weight"), *b = find_desc(descs, nd, p + "bias"),
@@ -143,19 +333,24 @@ static int make_layer(dgr_net *net, const dgr_weight_desc *descs, int nd, const 
     DGR_REQUIRE(g && b && m && v, "state_dict is missing batch-norm tensors '%s*'", p.c_str());
     DGR_REQUIRE(g->numel == cout && b->numel == cout && m->numel == cout && v->numel == cout,
                 "batch-norm '%s' has the wrong width", p.c_str());
+    const float *gd = host_of(g), *bd2 = host_of(b), *md = host_of(m), *vd = host_of(v);
+    DGR_REQUIRE(gd && bd2 && md && vd, "batch-norm '%s': device tensors could not be read", p.c_str());
     for (int c = 0; c < cout; ++c) {
-      float s = g->data[c] / sqrtf(v->data[c] + BN_EPS);
+      float s = gd[c] / sqrtf(vd[c] + BN_EPS);
       scale[c] = s;
-      shift[c] = b->data[c] - m->data[c] * s;
+      shift[c] = bd2[c] - md[c] * s;
     }
     has_shift = true;
   }
   if (bias) {
     const dgr_weight_desc *bd = find_desc(descs, nd, name + ".bias");
     DGR_REQUIRE(bd && bd->numel == cout, "state_dict is missing '%s.bias' [1,%d]", name.c_str(), cout);
-    for (int c = 0; c < cout; ++c) shift[c] += bd->data[c];
+    const float *bh = host_of(bd);
+    DGR_REQUIRE(bh, "'%s.bias': device tensor could not be read", name.c_str());
+    for (int c = 0; c < cout; ++c) shift[c] += bh[c];
     has_shift = true;
   }
+  if (dev) return make_layer_device(net, L, kd->data, scale, shift, has_shift, name);
   // DGR_EXACT_F32=1: every conv on v_mfma_f32_*_f32 with the f32 operands themselves (the reference's arithmetic,
   // conv.hip / conv_os.hip) -- the mode the split-operand kernels are measured against.  Default: two f16 pieces per
   // operand under power-of-two scales, three products per MAC (conv_wide.hip, conv_os.hip).
@@ -323,9 +518,8 @@ static int make_layer(dgr_net *net, const dgr_weight_desc *descs, int nd, const 
   return DGR_OK;
 }
 
-extern "C" int dgr_net_create(dgr_ctx *ctx, int D, int in_channels, int out_channels,
-                              int conv1_kernel_size, int normalize_feature,
-                              const dgr_weight_desc *weights, int n_weights, dgr_net **out) {
+static int net_create(dgr_ctx *ctx, int D, int in_channels, int out_channels, int conv1_kernel_size, int normalize_feature,
+                      const dgr_weight_desc *weights, int n_weights, dgr_net **out, bool dev) {
   DGR_REQUIRE(ctx && weights && out, "dgr_net_create: NULL argument");
   DGR_REQUIRE(D == 3 || D == 6, "dgr_net_create: D=%d (ResUNetBN2C is used with D=3 and D=6)", D);
   DGR_REQUIRE(in_channels >= 1 && in_channels <= 256 && out_channels >= 1 && out_channels <= 64,
@@ -342,7 +536,7 @@ extern "C" int dgr_net_create(dgr_ctx *ctx, int D, int in_channels, int out_chan
   for (int d = 0; d < D; ++d) { k3 *= 3; k1 *= conv1_kernel_size; }
   int rc = DGR_OK;
   auto L = [&](const std::string &name, int K, int ci, int co, const char *bn, bool bias = false) {
-    if (rc == DGR_OK) rc = make_layer(net, weights, n_weights, name, K, ci, co, bn, bias);
+    if (rc == DGR_OK) rc = make_layer(net, weights, n_weights, name, K, ci, co, bn, bias, dev);
   };
   auto block = [&](const std::string &b, int c) {
     L(b + ".conv1", k3, c, c, (b + ".norm1").c_str());
@@ -363,6 +557,18 @@ extern "C" int dgr_net_create(dgr_ctx *ctx, int D, int in_channels, int out_chan
   }
   *out = net;
   return DGR_OK;
+}
+
+extern "C" int dgr_net_create(dgr_ctx *ctx, int D, int in_channels, int out_channels,
+                              int conv1_kernel_size, int normalize_feature,
+                              const dgr_weight_desc *weights, int n_weights, dgr_net **out) {
+  return net_create(ctx, D, in_channels, out_channels, conv1_kernel_size, normalize_feature, weights, n_weights, out, false);
+}
+
+extern "C" int dgr_net_create_device(dgr_ctx *ctx, int D, int in_channels, int out_channels,
+                                     int conv1_kernel_size, int normalize_feature,
+                                     const dgr_weight_desc *weights, int n_weights, dgr_net **out) {
+  return net_create(ctx, D, in_channels, out_channels, conv1_kernel_size, normalize_feature, weights, n_weights, out, true);
 }
 
 extern "C" void dgr_net_destroy(dgr_net *net) {
@@ -507,12 +713,19 @@ struct Fwd {
     const bool small_cin = km && !swapped && !res && L.cin <= 8 && L.cout == 32 && L.cin_pad == 8;
     // (Cin = 6 / 1 -- the inlier net's two input widths -- run the thread-per-voxel variant, conv.hip)
     const char *kname = (L.cin == 6 && L.wq) ? "conv_cin6_quad_kernel" : L.cin == 1 ? "conv_small_cin_row_kernel" : "conv_small_cin_kernel";
+    unsigned long long *clk = nullptr;
     const bool wide = L.wb && km;
     if (small_cin)
       DGR_CHECK(dgr_conv_small_cin(in.ptr, in.ld, in.relu, L.cin, L.w, L.wq, L.shift, *km, cout_map.n_dev, cout_map.n_cap,
                                    out.ptr, out.ld, stream));
     else if (wide) {
       DGR_REQUIRE(in.split.planes, "layer %s: the wide-layer kernel needs its input as split rows", L.name.c_str());
+      if (prof) {   // the kernel stamps its own start / end (dgr_ctx_conv_launch_kernel_us)
+        DGR_ALLOC(a.clk, ctx->arena, unsigned long long, 2);
+        DGR_HIP_CHECK(hipMemsetAsync(a.clk, 0xff, sizeof(unsigned long long), stream));       // start: atomicMin
+        DGR_HIP_CHECK(hipMemsetAsync(a.clk + 1, 0, sizeof(unsigned long long), stream));      // end: atomicMax
+        clk = a.clk;
+      }
       DGR_CHECK(dgr_conv_wide_launch(a, in.split, L.wb, L.wb_piece, L.w_unscale, ctx->num_cus, stream, &kname));
     } else
       DGR_CHECK(dgr_conv_launch(a, ctx->num_cus, stream, &kname));
@@ -528,8 +741,11 @@ struct Fwd {
       ctx->conv_spans.push_back({e0, e1});
       ctx->gemm_spans.push_back({e0, em});
       ctx->conv_kinds.push_back(kname);
+      ctx->conv_clks.resize(ctx->conv_spans.size(), nullptr);
+      ctx->conv_clks.back() = clk;
     }
     LayerRun &r = net->runs[li];
+    a.clk = nullptr;   // (the recorded launch is re-run by dgr_net_rerun_layer after the arena moved on)
     r.launch = a;
     r.split_in = wide ? in.split : DgrSplitRows();
     r.split_out = out.split;
@@ -723,6 +939,7 @@ void dgr_ctx_begin_profile(dgr_ctx *ctx) {
   ctx->conv_spans.clear();
   ctx->gemm_spans.clear();
   ctx->conv_kinds.clear();
+  ctx->conv_clks.clear();
   ctx->map3_spans.clear();
   ctx->map6_spans.clear();
   ctx->conv_launches = 0;
@@ -754,6 +971,13 @@ int dgr_ctx_collect_profile(dgr_ctx *ctx) {
     DGR_HIP_CHECK(hipEventElapsedTime(&t, sp.first, sp.second));
     ctx->gemm_span_ms.push_back(t);
   }
+  ctx->conv_clk_us.assign(ctx->conv_spans.size(), 0.f);
+  for (size_t i = 0; i < ctx->conv_clks.size() && i < ctx->conv_clk_us.size(); ++i)
+    if (ctx->conv_clks[i]) {
+      unsigned long long c[2] = {0, 0};
+      DGR_HIP_CHECK(hipMemcpy(c, ctx->conv_clks[i], sizeof(c), hipMemcpyDeviceToHost));
+      if (c[1] > c[0]) ctx->conv_clk_us[i] = (float)((double)(c[1] - c[0]) * 0.01);   // 100-MHz ticks
+    }
   return DGR_OK;
 }
 

@@ -41,6 +41,8 @@ def _flatten_state(sd):
 
 
 def _unflatten_state(metas, flat):
+    """`flat`: a numpy array or a torch tensor (the broadcast buffer itself, on whatever device it lives): the entries of
+    the returned dict are VIEWS of it."""
     out, pos = {}, 0
     for k, shape in metas:
         n = int(np.prod(shape)) if len(shape) else 1
@@ -77,7 +79,14 @@ def broadcast_checkpoint(ckpt, src=0, device=None):
         else:
             buf = torch.empty(n, dtype=torch.float32, device=device)
         dist.broadcast(buf, src=src)
-        out[name] = ckpt[name] if rank == src and not roundtrip else _unflatten_state(metas, buf.cpu().numpy())
+        if rank == src and not roundtrip:
+            out[name] = ckpt[name]
+        elif buf.is_cuda:
+            # RCCL: the weights stay where the broadcast put them -- views of the flat device buffer, which the networks'
+            # loader hands to dgr_net_create_device (no D2H copy, no host-side weight preparation on the receiving ranks)
+            out[name] = _unflatten_state(metas, buf)
+        else:
+            out[name] = _unflatten_state(metas, buf.numpy())
         del buf
     return out
 

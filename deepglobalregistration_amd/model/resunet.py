@@ -35,10 +35,17 @@ class ResUNet2:
 
     # --- torch.nn.Module-like surface used by core/deep_global_registration.py:114-131 -------
     def load_state_dict(self, state_dict, strict=True):
-        self._state = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v))
-                       for k, v in state_dict.items()}
-        self._state = me_conventions.convert_state_dict(self._state, self.D, self.me_conventions['kernel_order'],
-                                                        self.me_conventions['transposed_mirrored'])
+        default_conv = (self.me_conventions['kernel_order'] == me_conventions.DEFAULT['kernel_order']
+                        and not self.me_conventions['transposed_mirrored'])
+        if default_conv and state_dict and all(torch.is_tensor(v) and v.is_cuda for v in state_dict.values()):
+            # already in HBM and in the library's convention (e.g. out of dist.broadcast_checkpoint): it stays on the device,
+            # the library prepares its operand layouts there (dgr_net_create_device)
+            self._state = dict(state_dict)
+        else:
+            self._state = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v))
+                           for k, v in state_dict.items()}
+            self._state = me_conventions.convert_state_dict(self._state, self.D, self.me_conventions['kernel_order'],
+                                                            self.me_conventions['transposed_mirrored'])
         self._net = None
         self._share = None
         return self

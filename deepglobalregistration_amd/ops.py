@@ -75,19 +75,32 @@ class NetHandle:
             self.handle = h
             return
         keep, descs = [], []
-        for name, t in state_dict.items():
-            if name.endswith('num_batches_tracked'):
-                continue
-            a = t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
-            a = np.ascontiguousarray(a, dtype=np.float32)
-            keep.append(a)
-            descs.append(_lib.WeightDesc(name.encode(), a.ctypes.data, a.size))
+        items = [(n, t) for n, t in state_dict.items() if not n.endswith('num_batches_tracked')]
+        # a state dict that is ALREADY on this device (torch CUDA tensors: e.g. views of the broadcast buffer of a
+        # multi-GPU start, dist.broadcast_checkpoint) stays there: dgr_net_create_device folds / splits / tiles it with
+        # HIP kernels; anything else goes through the host path
+        on_device = bool(items) and all(torch.is_tensor(t) and t.is_cuda and t.device.index == (self.device.index or 0)
+                                        for _, t in items)
+        self.created_on_device = on_device
+        for name, t in items:
+            if on_device:
+                a = t.detach().to(torch.float32).contiguous()
+                keep.append(a)
+                descs.append(_lib.WeightDesc(name.encode(), a.data_ptr(), a.numel()))
+            else:
+                a = t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
+                a = np.ascontiguousarray(a, dtype=np.float32)
+                keep.append(a)
+                descs.append(_lib.WeightDesc(name.encode(), a.ctypes.data, a.size))
         arr = (_lib.WeightDesc * len(descs))(*descs)
         h = vp()
         with torch.cuda.device(self.device):
-            check(lib.dgr_net_create(get_ctx(self.device), D, in_channels, out_channels,
-                                     conv1_kernel_size, int(bool(normalize_feature)), arr, len(descs),
-                                     C.byref(h)))
+            if on_device:
+                torch.cuda.current_stream(self.device).synchronize()   # the tensors' producers (a broadcast) have finished
+            create = lib.dgr_net_create_device if on_device else lib.dgr_net_create
+            check(create(get_ctx(self.device), D, in_channels, out_channels,
+                         conv1_kernel_size, int(bool(normalize_feature)), arr, len(descs),
+                         C.byref(h)))
         self.handle = h
 
     def __del__(self):
@@ -485,6 +498,16 @@ def conv_launch_times(device):
     n = C.c_int64(0)
     check(_lib.load().dgr_ctx_conv_launch_times(get_ctx(device), t, g, cap, C.byref(n)))
     return [float(t[i]) for i in range(n.value)], [float(g[i]) for i in range(n.value)]
+
+
+def conv_launch_kernel_us(device):
+    """Per launch of `conv_launch_times`: the kernel's own execution span in us (stamped by the kernel on the device wall
+    clock: the duration rocprofv3 --kernel-trace reports, valid under concurrent streams); 0 = kernel not instrumented."""
+    cap = 4096
+    t = (C.c_float * cap)()
+    n = C.c_int64(0)
+    check(_lib.load().dgr_ctx_conv_launch_kernel_us(get_ctx(device), t, cap, C.byref(n)))
+    return [float(t[i]) for i in range(n.value)]
 
 
 def conv_launch_kinds(device):

@@ -87,13 +87,22 @@ int dgr_voxelize(dgr_ctx *ctx, const void *xyz, int is_f64, int64_t M, double vo
  * Python host, tools/check_me_conventions.py tells the readings apart on a real pair. */
 typedef struct {
   const char *name;
-  const float *data; /* host */
+  const float *data; /* host (dgr_net_create) / device (dgr_net_create_device) */
   int64_t numel;
 } dgr_weight_desc;
 
 int dgr_net_create(dgr_ctx *ctx, int D, int in_channels, int out_channels, int conv1_kernel_size,
                    int normalize_feature, const dgr_weight_desc *weights, int n_weights,
                    dgr_net **out);
+/* The same with every `data` a DEVICE pointer on the context's device ("host or device pointers"): the state
+ * dict is already in HBM -- e.g. views of the flat RCCL broadcast buffer of a multi-GPU start (deepglobalregistration_amd/
+ * dist.py) -- and batch-norm folding, the power-of-two weight scale, the f16 split and every MFMA operand layout are
+ * produced by HIP kernels from there: nothing but the per-channel batch-norm vectors (cout floats each) travels to the host.
+ * Bit-identical weight sets to dgr_net_create on the same values (tests/test_gpu_device_weights.py).  The library copies:
+ * the caller may free its tensors when the call returns. */
+int dgr_net_create_device(dgr_ctx *ctx, int D, int in_channels, int out_channels, int conv1_kernel_size,
+                          int normalize_feature, const dgr_weight_desc *weights, int n_weights,
+                          dgr_net **out);
 void dgr_net_destroy(dgr_net *net);
 int64_t dgr_net_param_bytes(const dgr_net *net);
 /* A second net object bound to `ctx` (another context of the SAME device: one context per HIP stream / host thread)
@@ -276,6 +285,11 @@ int64_t dgr_ctx_conv_launches(dgr_ctx *ctx);
  * 0..22, then the inlier net's): times_ms = MFMA phase + reduce phase, gemm_ms (nullable) = MFMA phase alone
  * (the sparse_conv_mfma kernel); *n = number written (<= capacity) */
 int dgr_ctx_conv_launch_times(dgr_ctx *ctx, float *times_ms, float *gemm_ms, int64_t capacity, int64_t *n);
+/* the same launches timed BY THE KERNEL ITSELF: execution span in microseconds (latest wave end - earliest wave start on
+ * the device's 100-MHz wall clock) -- what rocprofv3 --kernel-trace reports as the kernel's duration, valid also while other
+ * streams share the GPU (the HIP-event spans above then include the wait for compute units).  0 for launches whose kernel
+ * is not instrumented (only the wide-layer kernel, the dominant one, is). */
+int dgr_ctx_conv_launch_kernel_us(dgr_ctx *ctx, float *us, int64_t capacity, int64_t *n);
 /* kernel variant that ran each of those launches (the kernel's name as rocprofv3 --kernel-trace prints it),
  * newline-separated and NUL-terminated in buf; *n = number of names written */
 int dgr_ctx_conv_launch_kinds(dgr_ctx *ctx, char *buf, int64_t capacity, int64_t *n);

@@ -67,6 +67,9 @@ def test_rccl_collectives_on_a_one_rank_group_match_the_plain_run(tmp_path, plai
     forced, r2, err = _bench(str(tmp_path), 1, tag='pg', DGR_BENCH_BACKEND=None, DGR_BENCH_FORCE_PG='1')
     assert 'nccl process group up' in err, err[-2000:]
     assert forced['n_gpus'] == 1 and forced['config']['pairs_per_step'] == 6
+    # ... and the networks were built ON THE DEVICE from the broadcast buffer (dgr_net_create_device), bit-identical to
+    # the plain run's host-prepared weights (the equalities below)
+    assert forced['startup_s']['weights_prepared_on_device_this_rank'] and not plain['startup_s']['weights_prepared_on_device_this_rank']
     o1, o2 = np.argsort(r1['ids']), np.argsort(r2['ids'])
     assert sorted(r2['ids'].tolist()) == list(range(6))
     np.testing.assert_array_equal(r1['status'][o1], r2['status'][o2])

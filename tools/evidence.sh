@@ -7,8 +7,13 @@
 R=$PWD; O=$R/gpurun_out/final; mkdir -p $O; rm -rf $O/*
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py"
-RND=r05
+RND=r06
 W="BASELINE configs[1], 6 pairs per batch"
+# the commit these files belong to: written into tools/COMMIT by the caller before gpurun snapshots the tree (the box has
+# no .git): `git rev-parse --short HEAD > tools/COMMIT; git diff --quiet || echo "+dirty" >> tools/COMMIT`
+COMMIT=$(tr -d '\n' < $R/tools/COMMIT 2>/dev/null || echo unknown)
+export DGR_EVIDENCE_COMMIT=$COMMIT
+echo "evidence bundle of commit $COMMIT" > $O/COMMIT.txt
 # one stream, the default batch of 6 pairs: names the dominant kernel
 timeout 300 $B --streams 1 --no-parity > $O/bench_c1_s1_b6.json 2> $O/bench_c1_s1_b6.err
 if [ "$1" != nopmc ]; then
@@ -28,6 +33,10 @@ if [ "$1" != nopmc ]; then
   python $R/tools/pmc_dominant.py "conv1_grid_mfma" "$W" $DBS > $O/conv1_pmc.json
   python $R/tools/pmc_dominant.py "knn_mfma_kernel<true>" "$W" $DBS > $O/knn_pmc.json
   python $R/tools/pmc_dominant.py "registration_kernel" "$W" $DBS > $O/registration_pmc.json
+  python - <<P
+import json
+d = json.load(open('$O/dominant_pmc.json')); d['commit'] = '$COMMIT'; json.dump(d, open('$O/dominant_pmc.json', 'w'), indent=1)
+P
   rm -rf $O/pmc
   cp $O/dominant_pmc.json $R/profiles/${RND}_dominant_pmc.json    # the lines below quote it (roofline.traffic)
 fi
@@ -55,11 +64,44 @@ timeout 300 rocprofv3 --kernel-trace -d $O/kt1 -o kt -- $B --streams 1 --pairs-p
 python $R/tools/rocpd_summary.py $O/kt1/kt_results.db $O/kernel_stats_s1_b4.csv --trace sparse_conv $O/conv_trace_s1_b4.csv
 timeout 300 rocprofv3 --kernel-trace -d $O/kt6 -o kt -- $B --streams 1 --no-parity --steps 5 > $O/kt6.log 2>&1
 python $R/tools/rocpd_summary.py $O/kt6/kt_results.db $O/kernel_stats_s1_b6.csv
+grep '^{' $O/kt6.log | tail -1 > $O/bench_c1_s1_b6_under_rocprof.json
 timeout 300 rocprofv3 --kernel-trace -d $O/kt3 -o kt -- $B --no-parity --steps 5 > $O/kt3.log 2>&1
 python $R/tools/rocpd_summary.py $O/kt3/kt_results.db $O/kernel_stats_s3_b6.csv
+# the line printed INSIDE that profiled run against the profiler's own table: roofline.avg_launch_us (stamped by the kernel)
+# and the rocprofv3 average of the same kernel in the same process must agree (round-5 verdict, task 1b)
+python - <<P | tee $O/line_vs_rocprof.txt
+import csv, json
+line = [l for l in open('$O/kt3.log') if l.startswith('{')][-1]
+d = json.loads(line); k = d['roofline']['kernel']; us = d['roofline']['avg_launch_us']
+rows = [r for r in csv.DictReader(open('$O/kernel_stats_s3_b6.csv')) if k in r['Name']]
+avg = float(rows[0]['AverageNs']) / 1e3
+print(f'commit $COMMIT: {k}: bench line (3 streams, under rocprofv3) {us:.1f} us, rocprofv3 --kernel-trace average {avg:.1f} us over {rows[0]["Calls"]} calls: '
+      f'{abs(us - avg) / avg * 100:.1f} % apart ({"OK" if abs(us - avg) <= 0.03 * avg else "MORE THAN 3 %"})')
+P
 rm -rf $O/kt1 $O/kt3 $O/kt6
 # the whole GPU suite with the parity tables (split operands vs f64; refinement vs the oracle, iteration-matched and free-running)
 if [ "$1" != quick ]; then   # PYTEST_ARGS: a subset (default: the whole suite)
   (cd $R && DGR_PARITY_REPORT=$O/parity timeout 1800 python -m pytest ${PYTEST_ARGS:-tests} -m gpu -q 2>&1 | tail -15 > $O/pytest_gpu.log)
 fi
+# stamp the commit into every JSON / text artefact of the bundle
+python - <<P
+import glob, json
+for f in glob.glob('$O/*.json'):
+    txt = open(f).read().strip()
+    if not txt:
+        continue
+    try:
+        d, multi = json.loads(txt), True
+    except Exception:
+        try:
+            d, multi = json.loads(txt.splitlines()[-1]), False
+        except Exception:
+            continue
+    if isinstance(d, dict):
+        d['commit'] = '$COMMIT'
+        json.dump(d, open(f, 'w'), indent=1 if '\n' in txt and multi else None)
+for f in glob.glob('$O/*.csv') + glob.glob('$O/parity/*.txt'):
+    s = open(f).read()
+    open(f, 'w').write(s + ('' if s.endswith('\n') else '\n') + '# commit $COMMIT\n')
+P
 ls -la $O; cat $O/pytest_gpu.log; tail -c 600 $O/bench_c1_default.json
