@@ -526,9 +526,11 @@ def main():
             self.last_bt = todo[-1]
 
         def run(self, n):
+            c0 = time.thread_time()
             with self:
                 for _ in range(n):
                     self.step()
+            self.thread_cpu_s = time.thread_time() - c0   # CPU seconds of THIS driver thread alone (enqueue + wait)
 
         def run_profiled(self, n):
             """n more steps in the library's profiling mode, all workers of the rank at once: the dominant kernel stamps its
@@ -843,6 +845,9 @@ def main():
             'roofline': roofline,
             'roofline_detail': roofline_detail,
             'host_cpu_s_per_step_per_rank': cpu_s_per_step,
+            # ... of which the stream-driving threads themselves (enqueueing a batch's launches, then sleeping until it is
+            # done: dgr_ctx_wait); the rest is the HIP runtime's own threads
+            'host_cpu_s_per_step_driver_threads': sum(getattr(w, 'thread_cpu_s', 0.0) for w in workers) / args.steps,
             # one-time start-up of a rank, MAX over ranks: the RCCL broadcast of the checkpoint (ranks > 0 receive ~0.94 GB
             # into HBM and keep it there) and the preparation of the kernels' weight layouts (ranks > 0, and a forced
             # one-rank group: by HIP kernels from the broadcast buffer, dgr_net_create_device; the source rank: from its host

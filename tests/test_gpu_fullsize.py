@@ -22,7 +22,7 @@ def world():
     from deepglobalregistration_amd.core.deep_global_registration import DeepGlobalRegistration
     ck = synth.synth_checkpoint(seed=0, voxel_size=VOXEL, feat_conv1_kernel_size=KS)
     dgr = DeepGlobalRegistration({'weights': ck, 'clip_weight_thresh': 0.05}, torch.device('cuda'))
-    pairs = [synth.synth_pair(s, n_raw=NRAW) for s in range(4)]
+    pairs = [synth.synth_pair(s, n_raw=NRAW) for s in range(6)]
     vox = []
     for p, (a, b, _) in enumerate(pairs):
         xa, ca, _ = dgr.preprocess(a, batch_index=p)
@@ -120,3 +120,23 @@ def test_fullsize_batch_of_four_matches_oracle_and_single(world):
     assert np.array_equal(r['idx1'][:n0], single['idx1'])
     assert rel_err(r['logit'][:n0], single['logit']) < 1e-6
     print(f'full size B=4: pair 2 |dF|={dF:.2e} rel|dlogit|={dl:.2e}')
+
+
+def test_fullsize_batch_of_six_matches_oracle_and_single(world):
+    """B = 6 (bench.py's default batch since round 5): the LAST pair of the batch vs the oracle, pair 0 of the batch vs the
+    same pair registered alone."""
+    r = _run(world, [0, 1, 2, 3, 4, 5])
+    off0, off1 = r['off0'], r['off1']
+    s0, e0, s1, e1 = off0[5], off0[6], off1[5], off1[6]
+    li = r['idx1'][s0:e0] - s1
+    assert li.min() >= 0 and li.max() < e1 - s1
+    oF0, oF1, ologit, _, _ = _oracle_pair(world, 5, li)
+    dF = max(np.abs(r['F0'][s0:e0] - oF0).max(), np.abs(r['F1'][s1:e1] - oF1).max())
+    dl = rel_err(r['logit'][s0:e0], ologit)
+    assert dF < TOL and dl < TOL, (dF, dl)
+    single = world['cache'].get(0) or _run(world, [0])
+    n0, n1 = single['off0'][1], single['off1'][1]
+    assert np.abs(r['F0'][:n0] - single['F0']).max() < 1e-6 and np.abs(r['F1'][:n1] - single['F1']).max() < 1e-6
+    assert np.array_equal(r['idx1'][:n0], single['idx1'])
+    assert rel_err(r['logit'][:n0], single['logit']) < 1e-6
+    print(f'full size B=6: pair 5 |dF|={dF:.2e} rel|dlogit|={dl:.2e}')
