@@ -295,17 +295,26 @@ __global__ void __launch_bounds__(KM_THREADS)
   const int n_out = *n_out_dev;
   const int64_t o = (int64_t)rb * KM_THREADS + threadIdx.x;
   int row_pairs = 0;
-  for (int w = 0; w < KW; ++w) {
-    const uint32_t word = (o < n_out) ? mask_out[o * KW + w] : 0u;
-    if (o < n_out) wpre[o * KW + w] = (unsigned short)row_pairs;
-    row_pairs += __popc(word);
-    unsigned long long mine = 0;
+  // the row's whole mask first (KW <= 24 words, all loads in flight together: the loop below alternates ballots and
+  // stores, which kept the loads one memory round trip apart -- 23 dependent trips per wave)
+  constexpr int KW_MAX = (KM_KMAX + 31) / 32;
+  uint32_t words[KW_MAX];
 #pragma unroll
-    for (int b = 0; b < 32; ++b) {
-      const unsigned long long m = __ballot((word >> b) & 1u);
-      if (lane == b) mine = m;
+  for (int w = 0; w < KW_MAX; ++w) words[w] = (w < KW && o < n_out) ? mask_out[o * KW + w] : 0u;
+#pragma unroll
+  for (int w = 0; w < KW_MAX; ++w) {
+    if (w < KW) {   // (uniform)
+      const uint32_t word = words[w];
+      if (o < n_out) wpre[o * KW + w] = (unsigned short)row_pairs;
+      row_pairs += __popc(word);
+      unsigned long long mine = 0;
+#pragma unroll
+      for (int b = 0; b < 32; ++b) {
+        const unsigned long long m = __ballot((word >> b) & 1u);
+        if (lane == b) mine = m;
+      }
+      if (lane < 32 && 32 * w + lane < KM_KMAX) bal[wave][32 * w + lane] = mine;
     }
-    if (lane < 32 && 32 * w + lane < KM_KMAX) bal[wave][32 * w + lane] = mine;
   }
   if (o < n_out) row_cnt[o] = row_pairs;   // (rows beyond the count: cleared together with the bit matrix)
   __syncthreads();

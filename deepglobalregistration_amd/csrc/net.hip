@@ -983,8 +983,9 @@ int dgr_ctx_collect_profile(dgr_ctx *ctx) {
 
 static int check_flag(dgr_ctx *ctx, const int32_t *flag_dev, hipStream_t stream) {
   int32_t flag = 0;
+  DGR_CHECK(dgr_ctx_wait(ctx, stream));   // (before the pageable copy, which would otherwise busy-wait for the stream)
   DGR_HIP_CHECK(hipMemcpyAsync(&flag, flag_dev, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-  DGR_CHECK(dgr_ctx_wait(ctx, stream));
+  DGR_HIP_CHECK(hipStreamSynchronize(stream));
   if (flag == 1) {
     dgr_set_error("duplicate coordinates in the sparse tensor input");
     return DGR_EINVAL;
