@@ -348,48 +348,21 @@ struct PlaceArgs {
   int32_t *in_pos;
   const unsigned short *wpre_out, *wpre_in;
 };
-// the READS of one pair's placement (all independent of each other: issued together), then its WRITES -- split so that a
-// lane can have two records' reads in flight before either's scattered stores (kmap_place_hits)
-struct PlacePos {
-  int64_t slot, pos, in_slot;
-};
-__device__ __forceinline__ PlacePos place_lookup(const PlaceArgs &p, int k, int64_t o, int64_t in) {
-  PlacePos r;
-  const int op = p.out_ptr[o];
-  const unsigned short wp = p.wpre_out[o * p.KW + (k >> 5)];
-  const uint32_t mw = p.mask_out[o * p.KW + (k >> 5)];
+__device__ __forceinline__ void place_pair(const PlaceArgs &p, int k, int64_t o, int64_t in) {
+  const int64_t slot = (int64_t)p.out_ptr[o] + mask_rank_pre(p.mask_out + o * p.KW, p.wpre_out + o * p.KW, k);
   const int64_t g = o >> 6;
   const int4 c = p.cell[g * p.K + k];   // ONE 16-byte read: column ballot + pairs of the block's earlier groups
-  const int bs = p.base[(int64_t)k * p.RB + (g >> 2)];
-  int ip = 0;
-  unsigned short iwp = 0;
-  uint32_t imw = 0;
-  if (p.mask_in) {
-    ip = p.in_ptr[in];
-    iwp = p.wpre_in[in * p.KW + (k >> 5)];
-    imw = p.mask_in[in * p.KW + (k >> 5)];
-  }
-  const uint32_t below = (1u << (k & 31)) - 1u;
-  r.slot = (int64_t)op + wp + __popc(mw & below);
   const unsigned long long cm = ((unsigned long long)(uint32_t)c.y << 32) | (uint32_t)c.x;
-  r.pos = (int64_t)bs + c.z + __popcll(cm & ((1ull << (o & 63)) - 1ull));
-  r.in_slot = (int64_t)ip + iwp + __popc(imw & below);
-  return r;
-}
-__device__ __forceinline__ void place_commit(const PlaceArgs &p, const PlacePos &r, int k, int64_t o, int64_t in) {
-  if (r.pos < p.pair_cap && r.slot < p.pair_cap) {
-    p.pair_in[r.pos] = (int32_t)in;
-    if (p.pair_out) p.pair_out[r.pos] = (int32_t)o;
-    if (p.pair_k) p.pair_k[r.pos] = (uint16_t)k;
-    p.out_pos[r.slot] = (int32_t)r.pos;
-    if (p.mask_in) p.in_pos[r.in_slot] = (int32_t)r.pos;
+  const int64_t pos = (int64_t)p.base[(int64_t)k * p.RB + (g >> 2)] + c.z + __popcll(cm & ((1ull << (o & 63)) - 1ull));
+  if (pos < p.pair_cap && slot < p.pair_cap) {
+    p.pair_in[pos] = (int32_t)in;
+    if (p.pair_out) p.pair_out[pos] = (int32_t)o;
+    if (p.pair_k) p.pair_k[pos] = (uint16_t)k;
+    p.out_pos[slot] = (int32_t)pos;
+    if (p.mask_in) p.in_pos[p.in_ptr[in] + mask_rank_pre(p.mask_in + in * p.KW, p.wpre_in + in * p.KW, k)] = (int32_t)pos;
   } else {
     *p.overflow = 2;
   }
-}
-__device__ __forceinline__ void place_pair(const PlaceArgs &p, int k, int64_t o, int64_t in) {
-  const PlacePos r = place_lookup(p, k, o, in);
-  place_commit(p, r, k, o, in);
 }
 
 // one wave per region of the hit list: one lane per record places the pair; a wave whose region overflowed during the
@@ -419,18 +392,9 @@ __global__ void __launch_bounds__(KM_THREADS)
       });
       continue;
     }
-    // two records per lane and trip: both records' look-ups are in flight before the first scattered store
-    const unsigned long long *recs = h.recs + (int64_t)r * h.region;
-    for (int e = lane; e < n; e += 128) {
-      const bool two = e + 64 < n;
-      const unsigned long long ra = recs[e], rb = two ? recs[e + 64] : ra;
-      const int ka = (int)(ra >> 54), kb = (int)(rb >> 54);
-      const int64_t oa = (int64_t)((ra >> 27) & 0x7ffffffull), ia = (int64_t)(ra & 0x7ffffffull);
-      const int64_t ob = (int64_t)((rb >> 27) & 0x7ffffffull), ib = (int64_t)(rb & 0x7ffffffull);
-      const PlacePos pa = place_lookup(p, ka, oa, ia);
-      const PlacePos pb = place_lookup(p, kb, ob, ib);
-      place_commit(p, pa, ka, oa, ia);
-      if (two) place_commit(p, pb, kb, ob, ib);
+    for (int e = lane; e < n; e += 64) {
+      const unsigned long long rec = h.recs[(int64_t)r * h.region + e];
+      place_pair(p, (int)(rec >> 54), (int64_t)((rec >> 27) & 0x7ffffffull), (int64_t)(rec & 0x7ffffffull));
     }
   }
 }

@@ -251,7 +251,8 @@ extern "C" int dgr_register_batch(dgr_ctx *ctx, dgr_net *fcgf, dgr_net *inlier, 
   // the batch's one wait, BEFORE the result copy: a device-to-host copy into pageable memory blocks inside the runtime
   // (busy-waiting) until the stream has drained -- issued first it would BE the wait, and the thread would spin through the
   // whole batch (measured, round 6: driver threads at 98 % of the wall time)
-  DGR_CHECK(dgr_ctx_wait(ctx, stream));
+  DGR_CHECK(dgr_ctx_wait(ctx, stream, (long)(ctx->batch_ns_per_row * (double)(n0 + n1))));
+  ctx->batch_ns_per_row = (double)ctx->last_wait_ns / (double)(n0 + n1);
   DGR_HIP_CHECK(hipMemcpyAsync(res.data(), res_dev, (size_t)npairs * sizeof(DgrRegResult), hipMemcpyDeviceToHost, stream));
   DGR_HIP_CHECK(hipStreamSynchronize(stream));
   DGR_CHECK(dgr_ctx_check_flag(ctx, stream));
