@@ -895,7 +895,7 @@ def main():
                 cmd = [sys.executable, os.path.abspath(__file__), '--steps', '8', '--warmup', '2', '--no-parity', '--no-exact-leg',
                        '--pairs-per-step', str(B), '--streams', str(S), '--n-raw', str(args.n_raw), '--voxel', str(args.voxel),
                        '--kind', args.kind, '--conv1-ks', str(args.conv1_ks)] + (['--no-refine'] if args.no_refine else [])
-                cp = subprocess.run(cmd, env=dict(os.environ, DGR_EXACT_F32='1'), capture_output=True, text=True, timeout=600)
+                cp = subprocess.run(cmd, env=dict(os.environ, DGR_EXACT_F32='1'), capture_output=True, text=True, timeout=300)
                 line = [l for l in cp.stdout.splitlines() if l.startswith('{')][-1]
                 ex = json.loads(line)
                 out['roofline']['exact_f32_pairs_per_s'] = ex['value']

@@ -79,6 +79,7 @@ print(f'commit $COMMIT: {k}: bench line (3 streams, under rocprofv3) {us:.1f} us
       f'{abs(us - avg) / avg * 100:.1f} % apart ({"OK" if abs(us - avg) <= 0.03 * avg else "MORE THAN 3 %"})')
 P
 rm -rf $O/kt1 $O/kt3 $O/kt6
+(cd $R && timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -3 $O/smoke.log)
 # the whole GPU suite with the parity tables (split operands vs f64; refinement vs the oracle, iteration-matched and free-running)
 if [ "$1" != quick ]; then   # PYTEST_ARGS: a subset (default: the whole suite)
   (cd $R && DGR_PARITY_REPORT=$O/parity timeout 1800 python -m pytest ${PYTEST_ARGS:-tests} -m gpu -q 2>&1 | tail -15 > $O/pytest_gpu.log)
