@@ -57,6 +57,31 @@ def test_two_ranks_cover_every_pair_once_and_match_one_rank(tmp_path, plain_run)
     assert two['host_cpu_s_per_step_per_rank'] > 0
 
 
+def test_eight_ranks_on_one_gpu_cover_every_pair_once_and_match_one_rank(tmp_path):
+    """The node size the driver scales to, as far as a 1-GPU box can go: EIGHT ranks (eight processes, eight library
+    contexts, eight copies of the weights) on device 0 over gloo, 16 pairs dealt by cost -- launcher, broadcast, dealing,
+    gather at world size 8 with real GPU work, next to seven other processes on the same GPU.  Every pair covered once and
+    bitwise the 1-rank results."""
+    common8 = [a if a != '6' else '16' for a in COMMON]          # --total-pairs 16: two per rank
+    def run(gpus, tag):
+        env = dict(os.environ, DGR_BENCH_BACKEND='gloo', DGR_BENCH_ONE_GPU='1')
+        for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'DGR_BENCH_FORCE_PG', 'DGR_DIST_FORCE_COLLECTIVES'):
+            env.pop(k, None)
+        out = os.path.join(str(tmp_path), f'res{tag}.npz')
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(gpus), '--dump-results', out, *common8],
+                           env=env, capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1]), np.load(out)
+    one, r1 = run(1, 'a')
+    eight, r8 = run(8, 'b')
+    assert eight['n_gpus'] == 8 and eight['config']['pairs_per_step'] == 16 and eight['scaling'] == 'strong'
+    assert sorted(r1['ids'].tolist()) == list(range(16)) and sorted(r8['ids'].tolist()) == list(range(16))
+    o1, o8 = np.argsort(r1['ids']), np.argsort(r8['ids'])
+    np.testing.assert_array_equal(r1['status'][o1], r8['status'][o8])
+    np.testing.assert_array_equal(r1['T'][o1], r8['T'][o8])
+    np.testing.assert_array_equal(r1['stats'][o1], r8['stats'][o8])
+
+
 def test_rccl_collectives_on_a_one_rank_group_match_the_plain_run(tmp_path, plain_run):
     """The RCCL half of the multi-GPU path on the hardware a 1-GPU box has: DGR_BENCH_FORCE_PG=1 makes the one-rank run
     call init_process_group('nccl', device_id=...), broadcast_object_list, the flat weight broadcast (the networks are
