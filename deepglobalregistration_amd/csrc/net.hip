@@ -521,6 +521,17 @@ static int make_layer(dgr_net *net, const dgr_weight_desc *descs, int nd, const 
 static int net_create(dgr_ctx *ctx, int D, int in_channels, int out_channels, int conv1_kernel_size, int normalize_feature,
                       const dgr_weight_desc *weights, int n_weights, dgr_net **out, bool dev) {
   DGR_REQUIRE(ctx && weights && out, "dgr_net_create: NULL argument");
+  if (dev) {
+    // every tensor must really live on this context's device: the fill kernels dereference the pointers
+    for (int i = 0; i < n_weights; ++i) {
+      hipPointerAttribute_t at;
+      const hipError_t e = hipPointerGetAttributes(&at, weights[i].data);
+      if (e != hipSuccess) (void)hipGetLastError();
+      DGR_REQUIRE(e == hipSuccess && at.type == hipMemoryTypeDevice && at.device == ctx->device,
+                  "dgr_net_create_device: '%s' is not a device pointer on device %d (use dgr_net_create for host tensors)",
+                  weights[i].name ? weights[i].name : "?", ctx->device);
+    }
+  }
   DGR_REQUIRE(D == 3 || D == 6, "dgr_net_create: D=%d (ResUNetBN2C is used with D=3 and D=6)", D);
   DGR_REQUIRE(in_channels >= 1 && in_channels <= 256 && out_channels >= 1 && out_channels <= 64,
               "dgr_net_create: unsupported channel counts in=%d out=%d", in_channels, out_channels);

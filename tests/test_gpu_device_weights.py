@@ -46,3 +46,21 @@ def test_inlier_weights_prepared_on_device_are_bit_identical():
     a, b = _forward_both(ck['state_dict_inlier'], 6, 6, 1, 3, False, coords6, feats6)
     assert np.isfinite(a).all() and np.abs(a).max() > 0
     assert np.array_equal(a, b), np.abs(a - b).max()
+
+
+def test_device_entry_point_refuses_host_pointers():
+    """`dgr_net_create_device` dereferences its tensors in kernels: a host pointer must be an error, not a GPU fault."""
+    import ctypes as C
+    from deepglobalregistration_amd import _lib, ops, synth
+    ck = synth.synth_checkpoint(seed=11, voxel_size=0.05, feat_conv1_kernel_size=3, with_inlier=False)
+    keep, descs = [], []
+    for name, t in ck['state_dict'].items():
+        if name.endswith('num_batches_tracked'):
+            continue
+        a = np.ascontiguousarray(np.asarray(t), dtype=np.float32)
+        keep.append(a)
+        descs.append(_lib.WeightDesc(name.encode(), a.ctypes.data, a.size))
+    arr = (_lib.WeightDesc * len(descs))(*descs)
+    h = C.c_void_p()
+    with pytest.raises(ValueError, match='not a device pointer'):
+        _lib.check(_lib.load().dgr_net_create_device(ops.get_ctx(torch.device('cuda:0')), 3, 1, 32, 3, 1, arr, len(descs), C.byref(h)))
