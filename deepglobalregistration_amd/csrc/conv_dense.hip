@@ -46,6 +46,15 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // (native vector: HIP's uint4 struct copies as memcpy and stays in scratch)
 
+#ifndef DGR_DENSE_RG
+#define DGR_DENSE_RG 2      // 16-row groups per wave with 64 input or output channels ...
+#endif
+#ifndef DGR_DENSE_RG32
+#define DGR_DENSE_RG32 2    // ... and at 32 -> 32
+#endif
+#ifndef DGR_DENSE_WD
+#define DGR_DENSE_WD 8      // weight ring: at most this many steps in flight
+#endif
 struct ConvDenseArgs {
   const float *in;
   float *out;
@@ -59,17 +68,26 @@ struct ConvDenseArgs {
   uint32_t *out_amax, *out_amax2;   // (nullable) the same for the rows written here: atomicMax per row
   float w_unscale;         // inverse of the layer's weight scale
   uint32_t in_bytes;       // size of the input tensor (row capacity x row stride): bound of the buffer loads
+  // Rows as READY-MADE OPERANDS (round 6).  in_ds: the input tensor written by its producer as "dense split rows" -- per
+  // row 4 CIN bytes = [h plane: CIN halves][m plane: CIN halves], the two f16 pieces of scale(row) * max(x, 0 if ReLU),
+  // every 32-channel group in THIS kernel's gather order (16-byte chunk c = channels 32 s + 4 c .. + 3 and 32 s + 16 + 4 c
+  // .. + 3): the offset loop then holds no conversion at all (it was 4/5 of the kernel's vector instructions, more issue
+  // cycles than its MFMAs).  out_ds: the rows written here in that form for the next dense-tile layer (the middle tensor
+  // of a residual block: `out` may then be null).  Same dgr_row_scale_of / dgr_split2 arithmetic on the same values as the
+  // consumer-side split: bit-identical results (tests/test_gpu_dense_conv.py).
+  const unsigned char *in_ds;
+  unsigned char *out_ds;
 };
 
-// CIN, COUT in {32, 64}; RG = 16-row groups per wave; WAVES per workgroup
-template <int CIN, int COUT, int RG, int WAVES>
+// CIN, COUT in {32, 64}; RG = 16-row groups per wave; WAVES per workgroup; PS: the input comes as dense split rows
+template <int CIN, int COUT, int RG, int WAVES, bool PS>
 __global__ void __launch_bounds__(64 * WAVES, 2) sparse_conv_dense_f16x2(ConvDenseArgs a) {
   constexpr int KV = 27;
   constexpr int S = CIN / 32, NCB = COUT / 16;
   constexpr int THREADS = 64 * WAVES;
   constexpr int MB = WAVES * RG * 16;            // output rows per workgroup
   constexpr int NST = S * NCB;                   // (32-channel step, 16-column block) steps per offset
-  constexpr int WD = NST >= 8 ? 8 : NST >= 4 ? 4 : 2;   // weight ring: the fragments of WD steps in flight per wave
+  constexpr int WD = NST >= 8 ? DGR_DENSE_WD : NST >= 4 ? 4 : 2;   // weight ring: the fragments of WD steps in flight per wave
   static_assert(NST % WD == 0, "the weight ring turns a whole number of times per offset (static register indexing)");
   __shared__ int nbr_s[KV][MB];
 
@@ -91,8 +109,12 @@ __global__ void __launch_bounds__(64 * WAVES, 2) sparse_conv_dense_f16x2(ConvDen
   // DESIGN.md section 8.)
   u32x4 rh[WD], rm[WD];
   const u32x4 *wph = a.wb + lane, *wpm = a.wb + a.piece_stride + lane;
+  // (consumption order of an offset's NST fragments: column block outer, 32-channel step inner -- one accumulator tile
+  // per row group alive at a time; in memory the fragments lie step-major)
   auto wreq = [&](int g, int i) {
-    const int gg = min(g, KV * NST - 1);
+    const int gc = min(g, KV * NST - 1);
+    const int k = gc / NST, jj = gc - k * NST;
+    const int gg = k * NST + (jj % S) * NCB + jj / S;
     rh[i] = wph[(int64_t)gg * 64];
     rm[i] = wpm[(int64_t)gg * 64];
   };
@@ -122,7 +144,8 @@ __global__ void __launch_bounds__(64 * WAVES, 2) sparse_conv_dense_f16x2(ConvDen
   __syncthreads();
 
   // gathered rows of the NEXT offset: requested here, consumed (split into pieces) at the top of the next iteration
-  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.in), 0, a.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      PS ? (void *)const_cast<unsigned char *>(a.in_ds) : (void *)const_cast<float *>(a.in), 0, a.in_bytes, 0x00020000);
   // the gathered rows of one offset (raw f32, requested DEPTH offsets ahead), their row scales and table entries
   struct RowSet { f32x4 raw[RG][S][2]; uint32_t mx[RG]; int nv[RG]; };
   // Request layout: lane L = 4 r + c reads 16 bytes of row r of the group so that every QUAD of lanes reads 64
@@ -139,12 +162,17 @@ __global__ void __launch_bounds__(64 * WAVES, 2) sparse_conv_dense_f16x2(ConvDen
       const int ne = max(n, 0);
       // buffer loads: a missing neighbour gets an offset past the tensor -- the bounds check returns zeros without a
       // memory access, and the request stays branch-free
-      const uint32_t off = n >= 0 ? (uint32_t)n * (uint32_t)(a.in_ld * 4) + 16u * (lane & 3) : a.in_bytes;
+      const uint32_t off = n >= 0 ? (uint32_t)n * (uint32_t)((PS ? CIN : a.in_ld) * 4) + 16u * (lane & 3) : a.in_bytes;
       const uint32_t mv = a.row_amax[ne];
 #pragma unroll
       for (int s = 0; s < S; ++s) {
-        g.raw[rg][s][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off + 128 * s, 0, 0));
-        g.raw[rg][s][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off + 128 * s + 64, 0, 0));
+        if constexpr (PS) {   // chunk (lane & 3) of the 32-channel group's h plane and of its m plane
+          g.raw[rg][s][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off + 64 * s, 0, 0));
+          g.raw[rg][s][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off + 2 * CIN + 64 * s, 0, 0));
+        } else {
+          g.raw[rg][s][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off + 128 * s, 0, 0));
+          g.raw[rg][s][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off + 128 * s + 64, 0, 0));
+        }
       }
       g.mx[rg] = mv;   // (turned into the scale, and selected against `nv`, when it is consumed: nothing here may wait for the request)
       g.nv[rg] = n;
@@ -176,6 +204,10 @@ __global__ void __launch_bounds__(64 * WAVES, 2) sparse_conv_dense_f16x2(ConvDen
 #pragma unroll
       for (int s = 0; s < S; ++s) {
         i32x4 hw, mw;   // four dwords = eight halves each: elements 0..3 from the first request, 4..7 from the second
+        if constexpr (PS) {
+          hw = __builtin_bit_cast(i32x4, g.raw[rg][s][0]);
+          mw = __builtin_bit_cast(i32x4, g.raw[rg][s][1]);
+        } else
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const i32x4 v = __builtin_bit_cast(i32x4, g.raw[rg][s][h]);
@@ -204,29 +236,40 @@ __global__ void __launch_bounds__(64 * WAVES, 2) sparse_conv_dense_f16x2(ConvDen
     //      step below: in the in-order memory counter every ring slot is older than the rows requested after it)
     gather(min(k + DEPTH, KV - 1), g);   // refills the set just consumed
     __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise sinks these requests below the MFMAs: no time in flight)
-    // ---- this offset's tile: tmp = W[k]^T x (zero for missing neighbours)
-    f32x4 tmp[RG][NCB];
+    // ---- this offset's tiles, one 16-column block after the other: tmp = W[k]^T x (zero for missing neighbours), folded
+    //      into the running total one block late -- nothing waits for the matrix pipe.  Per 32-channel step: its MFMAs,
+    //      then the two requests that refill the ring slot they read (the same fragment of the NEXT offset: a whole
+    //      offset in flight).  The scheduling barriers pin that order: left alone, the scheduler collects all sixteen
+    //      requests of an offset at the top of the loop, a few hundred cycles before the first MFMA that needs them.
+    f32x4 prev[RG];
 #pragma unroll
-    for (int rg = 0; rg < RG; ++rg)
+    for (int cb = 0; cb < NCB; ++cb) {
+      f32x4 tmp[RG];
 #pragma unroll
-      for (int cb = 0; cb < NCB; ++cb) tmp[rg][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int rg = 0; rg < RG; ++rg) tmp[rg] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < NST; ++j) {
-      const int s = j / NCB, cb = j % NCB;
-      const f16x8 wh = __builtin_bit_cast(f16x8, rh[j % WD]);
-      const f16x8 wm = __builtin_bit_cast(f16x8, rm[j % WD]);
+      for (int s = 0; s < S; ++s) {
+        const int j = cb * S + s;
+        const f16x8 wh = __builtin_bit_cast(f16x8, rh[j % WD]);
+        const f16x8 wm = __builtin_bit_cast(f16x8, rm[j % WD]);
 #pragma unroll
-      for (int rg = 0; rg < RG; ++rg) {
-        tmp[rg][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm, bh[rg][s], tmp[rg][cb], 0, 0, 0);
-        tmp[rg][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bm[rg][s], tmp[rg][cb], 0, 0, 0);
-        tmp[rg][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bh[rg][s], tmp[rg][cb], 0, 0, 0);
+        for (int rg = 0; rg < RG; ++rg) tmp[rg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm, bh[rg][s], tmp[rg], 0, 0, 0);
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg) tmp[rg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bm[rg][s], tmp[rg], 0, 0, 0);
+#pragma unroll
+        for (int rg = 0; rg < RG; ++rg) tmp[rg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bh[rg][s], tmp[rg], 0, 0, 0);
+        wreq(k * NST + j + WD, j % WD);   // the ring slot just consumed
+        if (s == 0 && cb > 0) {
+#pragma unroll
+          for (int rg = 0; rg < RG; ++rg) total[rg][cb - 1] += prev[rg] * fold[rg];
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      wreq(k * NST + j + WD, j % WD);   // the ring slot just consumed
+#pragma unroll
+      for (int rg = 0; rg < RG; ++rg) prev[rg] = tmp[rg];
     }
 #pragma unroll
-    for (int rg = 0; rg < RG; ++rg)
-#pragma unroll
-      for (int cb = 0; cb < NCB; ++cb) total[rg][cb] += tmp[rg][cb] * fold[rg];
+    for (int rg = 0; rg < RG; ++rg) total[rg][NCB - 1] += prev[rg] * fold[rg];
   };
   if (DEPTH == 1) {
 #pragma unroll 1
@@ -244,26 +287,53 @@ __global__ void __launch_bounds__(64 * WAVES, 2) sparse_conv_dense_f16x2(ConvDen
   //      ... and their largest |x| is left behind for the split-operand consumers of this tensor: a row's channels sit
   //      in the four lanes lr + 16 lq of this wave
   const float out_lo = a.out_relu ? 0.f : -__builtin_inff();
+  const int out_relu_lo = a.out_relu ? 0 : (int)0x80000000;
 #pragma unroll
   for (int rg = 0; rg < RG; ++rg) {
     const int64_t row = row0 + (wave * RG + rg) * 16 + lr;
     uint32_t mx = 0;
-    if (row < n_out) {
 #pragma unroll
-      for (int cb = 0; cb < NCB; ++cb) {
-        f32x4 v = total[rg][cb];
-        v.x = fmaxf(v.x, out_lo); v.y = fmaxf(v.y, out_lo); v.z = fmaxf(v.z, out_lo); v.w = fmaxf(v.w, out_lo);
-        *reinterpret_cast<f32x4 *>(a.out + row * a.out_ld + 16 * cb + 4 * lq) = v;
+    for (int cb = 0; cb < NCB; ++cb) {
+      f32x4 v = total[rg][cb];
+      v.x = fmaxf(v.x, out_lo); v.y = fmaxf(v.y, out_lo); v.z = fmaxf(v.z, out_lo); v.w = fmaxf(v.w, out_lo);
+      total[rg][cb] = v;
+      if (row < n_out) {
+        if (a.out) *reinterpret_cast<f32x4 *>(a.out + row * a.out_ld + 16 * cb + 4 * lq) = v;
         const i32x4 b = __builtin_bit_cast(i32x4, v);
         mx = max(mx, max(max((uint32_t)b.x & 0x7fffffffu, (uint32_t)b.y & 0x7fffffffu), max((uint32_t)b.z & 0x7fffffffu, (uint32_t)b.w & 0x7fffffffu)));
       }
     }
-    if (a.out_amax || a.out_amax2) {   // (kernel-uniform)
+    if (a.out_amax || a.out_amax2 || a.out_ds) {   // (kernel-uniform)
       mx = max(mx, (uint32_t)__shfl_xor((int)mx, 16, 64));
       mx = max(mx, (uint32_t)__shfl_xor((int)mx, 32, 64));
       if (lq == 0 && row < n_out) {
         if (a.out_amax) atomicMax(a.out_amax + row, mx);
         if (a.out_amax2) atomicMax(a.out_amax2 + row, mx);
+      }
+    }
+    if (a.out_ds && row < n_out) {
+      // the row once more as the next dense-tile layer's operands: exactly what that layer's own split makes of the f32
+      // row (the row's scale from the same maximum, the pending ReLU as the same integer max, dgr_split2's roundings);
+      // lane (lr, lq) holds chunk lq of every 32-channel group: channels 4 lq .. + 3 of column blocks 2 s and 2 s + 1
+      const float sx = dgr_row_scale_of(mx);
+      unsigned char *dst = a.out_ds + row * (int64_t)(4 * COUT) + 16 * lq;
+#pragma unroll
+      for (int s = 0; s < COUT / 32; ++s) {
+        u32x4 hw, mw;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const i32x4 v = __builtin_bit_cast(i32x4, total[rg][2 * s + h]);
+#pragma unroll
+          for (int u = 0; u < 4; u += 2) {
+            const f32x2 xs = f32x2{__builtin_bit_cast(float, max(v[u], out_relu_lo)), __builtin_bit_cast(float, max(v[u + 1], out_relu_lo))} * sx;
+            const f16x2 hh = __builtin_convertvector(xs, f16x2);
+            const f16x2 mm = __builtin_convertvector(xs - __builtin_convertvector(hh, f32x2), f16x2);
+            hw[2 * h + u / 2] = __builtin_bit_cast(uint32_t, hh);
+            mw[2 * h + u / 2] = __builtin_bit_cast(uint32_t, mm);
+          }
+        }
+        *reinterpret_cast<u32x4 *>(dst + 64 * s) = hw;
+        *reinterpret_cast<u32x4 *>(dst + 2 * COUT + 64 * s) = mw;
       }
     }
   }
@@ -276,10 +346,13 @@ bool dgr_conv_dense_supported(int cin, int cin_pad, int cout) {
 template <int CIN, int COUT>
 static int launch_dense(const ConvDenseArgs &ka, int64_t n_out_cap, hipStream_t stream) {
   // (8 waves per workgroup / 16 rows per wave measured 2.56 / 2.50 ms FCGF conv time against 2.51 with this shape)
-  constexpr int RG = 2, WAVES = 4, MB = WAVES * RG * 16;
+  constexpr int RG = (CIN == 32 && COUT == 32) ? DGR_DENSE_RG32 : DGR_DENSE_RG, WAVES = 4, MB = WAVES * RG * 16;
   int64_t blocks = dgr_ceil_div(n_out_cap, MB);
   blocks = (blocks + 7) / 8 * 8;
-  sparse_conv_dense_f16x2<CIN, COUT, RG, WAVES><<<(unsigned)blocks, 64 * WAVES, 0, stream>>>(ka);
+  if (ka.in_ds)
+    sparse_conv_dense_f16x2<CIN, COUT, RG, WAVES, true><<<(unsigned)blocks, 64 * WAVES, 0, stream>>>(ka);
+  else
+    sparse_conv_dense_f16x2<CIN, COUT, RG, WAVES, false><<<(unsigned)blocks, 64 * WAVES, 0, stream>>>(ka);
   DGR_LAUNCH_CHECK();
   return DGR_OK;
 }
@@ -298,11 +371,13 @@ int dgr_conv_dense_launch(const DgrConvOsLaunch &a, hipStream_t stream, const ch
   ka.res_ld = a.res_ld; ka.res_relu = a.res_relu;
   ka.row_amax = a.row_amax; ka.w_unscale = a.w_unscale;
   ka.out_amax = a.out_amax; ka.out_amax2 = a.out_amax2;
+  ka.in_ds = a.in_dsplit; ka.out_ds = a.out_dsplit;
+  DGR_REQUIRE(a.out || a.out_dsplit, "dense-tile conv: no output");
   DGR_REQUIRE(a.n_in_cap > 0 && a.n_in_cap * (int64_t)a.in_ld * 4 < (1ll << 31), "dense-tile conv: input tensor beyond 2 GB");
-  ka.in_bytes = (uint32_t)(a.n_in_cap * (int64_t)a.in_ld * 4);
+  ka.in_bytes = (uint32_t)(a.n_in_cap * (int64_t)(a.in_dsplit ? a.cin : a.in_ld) * 4);
 #define DGR_DENSE(CI, CO)                                                                   \
   if (a.cin == CI && a.cout == CO) {                                                        \
-    if (kernel_name) *kernel_name = "sparse_conv_dense_f16x2<" #CI ", " #CO ">";            \
+    if (kernel_name) *kernel_name = a.in_dsplit ? "sparse_conv_dense_f16x2<" #CI ", " #CO ", ps>" : "sparse_conv_dense_f16x2<" #CI ", " #CO ">"; \
     return launch_dense<CI, CO>(ka, a.n_out_cap, stream);                                   \
   }
   DGR_DENSE(32, 32) DGR_DENSE(32, 64) DGR_DENSE(64, 32) DGR_DENSE(64, 64)

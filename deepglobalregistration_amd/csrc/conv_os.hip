@@ -417,12 +417,14 @@ int dgr_conv_os_launch(const DgrConvOsLaunch &a, hipStream_t stream, const char 
     else if (mb == 32) { DGR_OS(CPV, 64, 32, CKV); }                        \
     else { DGR_OS(CPV, 64, 16, CKV); }                                      \
   } while (0)
-#define DGR_OS_CK 64      // input channels per pipeline phase
+  // input channels per pipeline phase: 64, or 128 where the caller asks for it (a.phase_channels; Cin >= 128: half the
+  // phases -- a barrier and a chain of dependent LDS / L2 round trips each -- per tile)
+  const bool ck128 = a.phase_channels == 128;
   switch (a.cin_pad) {
     case 32: DGR_OS_MB(32, 32);
-    case 64: DGR_OS_MB(64, DGR_OS_CK);
-    case 128: DGR_OS_MB(128, DGR_OS_CK);
-    case 256: DGR_OS_MB(256, DGR_OS_CK);
+    case 64: DGR_OS_MB(64, 64);
+    case 128: if (ck128) DGR_OS_MB(128, 128); else DGR_OS_MB(128, 64);
+    case 256: if (ck128) DGR_OS_MB(256, 128); else DGR_OS_MB(256, 64);
     default: break;
   }
 #undef DGR_OS_MB

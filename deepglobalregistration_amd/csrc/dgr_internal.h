@@ -238,11 +238,16 @@ struct DgrConvOsLaunch {
   int64_t n_in_cap = 0;                    // row capacity of the input tensor (32-bit gather offsets)
   const float *res; int res_ld, res_relu;
   int rows_per_block;   // 64 | 32 | 16 output rows per workgroup
+  int phase_channels = 64;   // list-based kernel: input channels per pipeline phase (64 | 128; 128 needs Cin >= 128)
   const DgrNbrTable *nbr;
   const int32_t *n_out_dev;
   int64_t n_out_cap;
   int cin, cin_pad, cout;
   bool dense = false;   // same-stride layer with C <= 64: the dense-tile kernel (conv_dense.hip) instead of the list-based one
+  // dense-tile kernel only: the input / the output (also) as "dense split rows" -- the rows as ready-made f16 operand
+  // pieces in that kernel's gather order (conv_dense.hip, ConvDenseArgs::in_ds); with out_dsplit, `out` may be null
+  const unsigned char *in_dsplit = nullptr;
+  unsigned char *out_dsplit = nullptr;
 };
 int dgr_conv_os_launch(const DgrConvOsLaunch &a, hipStream_t stream, const char **kernel_name = nullptr);
 bool dgr_conv_dense_supported(int cin, int cin_pad, int cout);

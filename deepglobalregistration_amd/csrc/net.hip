@@ -617,6 +617,11 @@ struct Tensor {
   // split-operand consumers (conv_os.hip / conv_dense.hip); amax2: the same array of the concatenation this tensor is a
   // column range of.  Zero-initialised, filled by atomicMax.
   uint32_t *amax = nullptr, *amax2 = nullptr;
+  // 3-D net: the rows as ready-made operand pieces of the dense-tile kernel (conv_dense.hip, "dense split rows": 4 x
+  // channels bytes per row), written by the tensor's producer; dsplit_only: nobody reads the f32 rows (a block's middle
+  // tensor) -- they are not written and `dsplit` is the tensor's own buffer
+  unsigned char *dsplit = nullptr;
+  bool dsplit_only = false;
 };
 
 struct Fwd {
@@ -677,7 +682,15 @@ struct Fwd {
       DgrConvOsLaunch o;
       o.in = in.ptr; o.in_ld = in.ld; o.in_relu = in.relu;
       o.out = out.ptr; o.out_ld = out.ld; o.out_relu = out.relu;
-      o.rows_per_block = lvl_out <= 1 ? 64 : lvl_out == 2 ? 32 : 16;
+      // rows per workgroup and input channels per pipeline phase of the list-based kernel, measured per layer shape on
+      // the benchmark's clouds (tools/r06_runs/run15-17.sh): the coarse levels have few rows and need small blocks to fill
+      // 256 CUs; with Cin >= 128 a phase of 128 channels halves the number of barrier-separated phases per tile, and at
+      // level 2 that pays for 64-row blocks (half the weight fragments through the vector-memory path); the one wide layer
+      // that writes level 0 (conv2_tr) is faster with 64
+      o.rows_per_block = lvl_out <= 1 ? 64 : lvl_out == 2 ? (L.cin_pad >= 128 ? 64 : 32) : 16;
+      o.phase_channels = (L.cin_pad >= 256 || (L.cin_pad == 128 && lvl_out >= 2)) ? 128 : 64;
+      if (const char *e = getenv(lvl_out == 2 ? "DGR_OS_MB2" : lvl_out == 3 ? "DGR_OS_MB3" : "DGR_OS_MB01")) o.rows_per_block = atoi(e);
+      if (const char *e = getenv("DGR_OS_CK")) o.phase_channels = atoi(e);
       o.w16 = L.w16; o.shift = L.shift;
       o.wb3 = L.w16b; o.piece_stride = L.w16b_piece;
       o.wbd = L.w16d;
@@ -703,6 +716,12 @@ struct Fwd {
       // (its buffer loads address the input with 32-bit byte offsets: tensors of 2 GB and more stay on the list kernel)
       o.dense = same_stride && o.row_amax && o.wbd && !os_lists && dgr_conv_dense_supported(L.cin, L.cin_pad, L.cout) &&
                 cin_map.n_cap * (int64_t)in.ld * 4 < (1ll << 31);
+      DGR_REQUIRE(o.dense || (!in.dsplit_only && !out.dsplit_only), "layer %s: dense split rows outside the dense-tile kernel", L.name.c_str());
+      if (o.dense) {
+        o.in_dsplit = in.dsplit;
+        o.out_dsplit = out.dsplit;
+        if (out.dsplit_only) o.out = nullptr;
+      }
       const char *kname = "sparse_conv_os";
       DGR_CHECK(dgr_conv_os_launch(o, stream, &kname));
       if (prof) {
@@ -872,6 +891,23 @@ int dgr_resunet_forward_impl(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, 
     for (Tensor *t : {&T8, &Y8, &S8}) t->amax = take(n8);
     S2.amax2 = CAT2.amax; S2T.amax2 = CAT2.amax;   // both halves of a concatenation feed its row maxima
     S4.amax2 = CAT4.amax; S4T.amax2 = CAT4.amax;
+  }
+
+  if (use_nbr && !getenv("DGR_NO_DSPLIT")) {
+    // the middle tensor of a residual block at the two finest levels goes from dense-tile kernel to dense-tile kernel:
+    // written as that kernel's operand pieces, and as nothing else (the conditions are those of `o.dense` in Fwd::conv)
+    static const bool os_f32 = getenv("DGR_EXACT_F32") != nullptr, os_lists = getenv("DGR_OS_LISTS") != nullptr;
+    auto dense_layer = [&](int l, int64_t rows) {
+      const DgrLayer &L = net->W->layers[l];
+      return L.w16b && L.w16d && !os_f32 && !os_lists && dgr_conv_dense_supported(L.cin, L.cin_pad, L.cout) &&
+             rows * (int64_t)L.cin * 4 < (1ll << 31);
+    };
+    struct { Tensor *t; int producer; int64_t rows; } mid[] = {{&Y1, 1, n1}, {&Y2, 4, n2}, {&V2, 16, n2}, {&V1, 19, n1}};
+    for (auto &e : mid)
+      if (dense_layer(e.producer, e.rows) && dense_layer(e.producer + 1, e.rows) && e.t->ld == net->W->layers[e.producer].cout) {
+        e.t->dsplit = reinterpret_cast<unsigned char *>(e.t->ptr);
+        e.t->dsplit_only = true;
+      }
   }
 
   int li = 0;
