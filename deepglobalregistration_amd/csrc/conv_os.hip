@@ -40,6 +40,19 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
+#ifdef DGR_OS_STAGE_CLK
+// tools/os_stage_clk.py (build with EXTRA=-DDGR_OS_STAGE_CLK): per-workgroup wall-clock sums of the kernel's stages --
+// [0] list compaction, [1] accumulator init + group list, [2] the phases, [3] epilogue, [4] workgroups, [5] phases
+__device__ unsigned long long dgr_os_stage_clk[8];
+#define DGR_OS_CLK(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); atomicAdd(&dgr_os_stage_clk[i], t_ - t_prev); t_prev = t_; } } while (0)
+extern "C" int dgr_debug_os_stage_clk(unsigned long long *out8, int reset) {
+  if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(dgr_os_stage_clk), 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(dgr_os_stage_clk), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#else
+#define DGR_OS_CLK(i) do { } while (0)
+#endif
 struct ConvOsArgs {
   const float *in;
   float *out;
@@ -114,6 +127,9 @@ __global__ void __launch_bounds__(CS * 4 * (TM / 16 / GW)) sparse_conv_os(ConvOs
   if (j >= per || blk >= nblocks) return;
   const int slice = blockIdx.y;
   const int64_t row0 = (int64_t)blk * MB;
+#ifdef DGR_OS_STAGE_CLK
+  unsigned long long t_prev = __builtin_amdgcn_s_memrealtime();
+#endif
 
   if constexpr (PM == 2)
     for (int e = tid; e < KV * MB; e += THREADS) (&in_scale[0][0])[e] = 1.f;   // slots past a list's end: a finite scale
@@ -141,6 +157,7 @@ __global__ void __launch_bounds__(CS * 4 * (TM / 16 / GW)) sparse_conv_os(ConvOs
       }
     }
   }
+  DGR_OS_CLK(0);
   // ---- 2. accumulators start from the folded batch-norm shift (+ residual)
   for (int e = tid; e < MB * (CS / 4); e += THREADS) {
     const int r = e / (CS / 4), c = (e % (CS / 4)) * 4;
@@ -178,6 +195,7 @@ __global__ void __launch_bounds__(CS * 4 * (TM / 16 / GW)) sparse_conv_os(ConvOs
   const int NG = n_grp;
   const int NT = (NG + GP - 1) / GP;
   const int NQ = NT * PPT;
+  DGR_OS_CLK(1);
 
   f32x4 Gr[NCH];
   // Requests only -- nothing here consumes a loaded value (see conv.hip).  A slot beyond its group's entries
@@ -326,6 +344,10 @@ __global__ void __launch_bounds__(CS * 4 * (TM / 16 / GW)) sparse_conv_os(ConvOs
     }
     __syncthreads();   // tile buffer q & 1 is free again; buffer (q + 1) & 1 is complete
   }
+  DGR_OS_CLK(2);
+#ifdef DGR_OS_STAGE_CLK
+  if (threadIdx.x == 0) { atomicAdd(&dgr_os_stage_clk[4], 1ull); atomicAdd(&dgr_os_stage_clk[5], (unsigned long long)NQ); }
+#endif
   // ---- 5. write the block's rows once (ReLU applied here when the tensor carries one: consumers that
   //         re-apply it see an idempotent max)
   //         ... and leave the rows' largest |x| behind for the split-operand consumers of this tensor (one integer
@@ -353,6 +375,7 @@ __global__ void __launch_bounds__(CS * 4 * (TM / 16 / GW)) sparse_conv_os(ConvOs
       }
     }
   }
+  DGR_OS_CLK(3);
 }
 
 template <int CP, int CS, int MB, int CK, int TM>

@@ -21,8 +21,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def dumps(tmp_path_factory):
     d = tmp_path_factory.mktemp('dense')
     out = {}
-    for name, env in (('dense', {}), ('lists', {'DGR_OS_LISTS': '1'})):
-        e = {k: v for k, v in os.environ.items() if k not in ('DGR_OS_LISTS', 'DGR_EXACT_F32')}
+    for name, env in (('dense', {}), ('lists', {'DGR_OS_LISTS': '1'}), ('nosplit', {'DGR_NO_DSPLIT': '1'})):
+        e = {k: v for k, v in os.environ.items() if k not in ('DGR_OS_LISTS', 'DGR_EXACT_F32', 'DGR_NO_DSPLIT')}
         e.update(env)
         path = str(d / f'{name}.npz')
         subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'aux', 'fcgf_dump.py'), path], env=e, check=True, timeout=900)
@@ -47,3 +47,19 @@ def test_every_tensor_agrees_with_the_list_based_kernel(dumps):
             err = float(np.abs(a.astype(np.float64) - b).max() / np.abs(b).max())
             print(f'{net} {n:6s} max |dense - lists| / max |lists| = {err:.1e}')
             assert err < 2e-6, (net, n, err)
+
+
+def test_middle_tensors_as_operand_pieces_change_no_bit(dumps):
+    """Round 6: the tensor between the two convs of a residual block is written by the first conv's epilogue as the
+    second conv's ready-made f16 operand pieces ("dense split rows") and as nothing else.  Same row scale, same pending
+    ReLU, same two roundings as the consumer-side split (split.h): every tensor of the forward keeps its bits against the
+    build-time switch that turns the hand-over off (DGR_NO_DSPLIT=1)."""
+    for net in ('k7', 'k3'):
+        kd, kn = dumps['dense'][net + '_kinds'].tolist(), dumps['nosplit'][net + '_kinds'].tolist()
+        # the second conv of block1, block2, block3_tr, block2_tr gathers pieces
+        assert sum(k.endswith(', ps>') for k in kd) == 4, kd
+        assert not any(k.endswith(', ps>') for k in kn), kn
+        for n in ('s1', 's2', 's4', 's8', 's4_tr', 's2_tr', 's1_tr', 'F'):
+            a, b = dumps['dense'][f'{net}_{n}'], dumps['nosplit'][f'{net}_{n}']
+            assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), (net, n)
+

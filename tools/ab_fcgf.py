@@ -21,6 +21,12 @@ if os.environ.get('AB_SORT'):
             key |= ((q[:, d] >> b) & 1) << (3 * b + d)
     key |= c[:, 0] << 40
     C = C[torch.from_numpy(np.argsort(key, kind='stable')).cuda()].contiguous()
+if os.environ.get('AB_PARITY'):
+    # rows grouped by the parity class of their voxel coordinates (what the transposed convs' row blocks would look like
+    # under a parity-sorted row permutation: a class uses 2^(odd dims) of the 27 offsets, all of its rows the same ones)
+    c = C.cpu().numpy().astype(np.int64)
+    key = (c[:, 1] & 1) | ((c[:, 2] & 1) << 1) | ((c[:, 3] & 1) << 2)
+    C = C[torch.from_numpy(np.argsort(key, kind='stable')).cuda()].contiguous()
 ones = torch.ones(len(C), 1, device='cuda')
 F = net.forward(C, ones)
 torch.cuda.synchronize()
@@ -28,7 +34,7 @@ t0 = time.time()
 for _ in range(10): F = net.forward(C, ones)
 torch.cuda.synchronize()
 tag = os.environ.get('AB_TAG', 'lists' if os.environ.get('DGR_OS_LISTS') else 'default')
-print('sorted' if os.environ.get('AB_SORT') else 'random-order', 'variant', tag, 'N', len(C), 'fwd ms', (time.time() - t0) * 100)
+print('sorted' if os.environ.get('AB_SORT') else 'parity-sorted' if os.environ.get('AB_PARITY') else 'random-order', 'variant', tag, 'N', len(C), 'fwd ms', (time.time() - t0) * 100)
 ops.set_profiling('cuda', True)
 F = net.forward(C, ones)
 t, g = ops.conv_launch_times('cuda'); kinds = ops.conv_launch_kinds('cuda')
