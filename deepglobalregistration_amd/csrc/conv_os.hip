@@ -398,6 +398,7 @@ static int launch_os(const ConvOsArgs &ka, int64_t n_out_cap, hipStream_t stream
 
 int dgr_conv_os_launch(const DgrConvOsLaunch &a, hipStream_t stream, const char **kernel_name) {
   if (a.dense) return dgr_conv_dense_launch(a, stream, kernel_name);
+  if (a.up) return dgr_conv_up_launch(a, stream, kernel_name);
   DGR_REQUIRE(a.nbr && a.nbr->built && a.nbr->K == 27, "output-stationary conv: no neighbour table");
   DGR_REQUIRE((a.cin & 3) == 0 && (a.in_ld & 3) == 0 && (a.out_ld & 3) == 0 && (a.res == nullptr || (a.res_ld & 3) == 0),
               "output-stationary conv: channel counts and row strides must be multiples of 4");

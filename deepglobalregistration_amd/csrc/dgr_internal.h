@@ -132,6 +132,13 @@ struct DgrNbrTable {
   int64_t n_pad = 0;
   int K = 27;
   bool built = false;
+  // Tables of the transposed convs (out rows = the fine map) only: the output rows grouped by the PARITY CLASS of their
+  // coordinates, bit d of the class = (coordinate d / tensor stride) & 1.  A fine row can only meet offsets whose
+  // component d is 0 where its coordinate is even and +-1 where it is odd (the coarse voxel f - delta ts must lie on the
+  // coarse lattice): 2^(odd dims) of the 27 offsets, the same ones for every row of a class (conv_up.hip).
+  // perm[c * cls_cap + i] = i-th row of class c (in no particular order), cls_count[c] = rows of class c.
+  int32_t *perm = nullptr, *cls_count = nullptr;
+  int64_t cls_cap = 0;
 };
 
 struct DgrMapSet {
@@ -244,6 +251,7 @@ struct DgrConvOsLaunch {
   int64_t n_out_cap;
   int cin, cin_pad, cout;
   bool dense = false;   // same-stride layer with C <= 64: the dense-tile kernel (conv_dense.hip) instead of the list-based one
+  bool up = false;      // transposed conv, Cin and Cout multiples of 64: the parity-class kernel (conv_up.hip)
   // dense-tile kernel only: the input / the output (also) as "dense split rows" -- the rows as ready-made f16 operand
   // pieces in that kernel's gather order (conv_dense.hip, ConvDenseArgs::in_ds); with out_dsplit, `out` may be null
   const unsigned char *in_dsplit = nullptr;
@@ -252,6 +260,8 @@ struct DgrConvOsLaunch {
 int dgr_conv_os_launch(const DgrConvOsLaunch &a, hipStream_t stream, const char **kernel_name = nullptr);
 bool dgr_conv_dense_supported(int cin, int cin_pad, int cout);
 int dgr_conv_dense_launch(const DgrConvOsLaunch &a, hipStream_t stream, const char **kernel_name = nullptr);
+bool dgr_conv_up_supported(int cin, int cin_pad, int cout);
+int dgr_conv_up_launch(const DgrConvOsLaunch &a, hipStream_t stream, const char **kernel_name = nullptr);
 int dgr_l2_normalize_rows(const float *in, int in_ld, float *out, int out_ld, int c, int relu,
                           const int32_t *n_dev, int64_t n_cap, hipStream_t stream);
 

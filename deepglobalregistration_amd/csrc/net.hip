@@ -244,7 +244,7 @@ static int make_layer_device(dgr_net *net, DgrLayer L, const float *src, const s
         pcs[ne + o] = dgr_f16_bits_dev(xs - dgr_f16_val_dev(xs));
       }));
       net->W->param_bytes += (size_t)2 * ne * sizeof(uint16_t);
-      if (net->D == 3 && K == 27 && dgr_conv_dense_supported(cin, L.cin_pad, cout)) {
+      if (net->D == 3 && K == 27 && (dgr_conv_dense_supported(cin, L.cin_pad, cout) || dgr_conv_up_supported(cin, L.cin_pad, cout))) {
         uint16_t *pd;
         DGR_HIP_CHECK(hipMalloc((void **)&pd, (size_t)2 * ne * sizeof(uint16_t)));
         L.w16d = pd;
@@ -457,7 +457,8 @@ static int make_layer(dgr_net *net, const dgr_weight_desc *descs, int nd, const 
       DGR_HIP_CHECK(hipMalloc(&L.w16b, pcs.size() * sizeof(uint16_t)));
       DGR_HIP_CHECK(hipMemcpy(L.w16b, pcs.data(), pcs.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
       net->W->param_bytes += pcs.size() * sizeof(uint16_t);
-      if (net->D == 3 && K == 27 && dgr_conv_dense_supported(cin, L.cin_pad, cout)) {
+      if (net->D == 3 && K == 27 && (dgr_conv_dense_supported(cin, L.cin_pad, cout) || dgr_conv_up_supported(cin, L.cin_pad, cout))) {
+        // (conv_up.hip, the transposed convs' kernel, gathers the same way)
         // conv_dense.hip reads its weight operands straight from memory: the quad-coalesced gather hands lane (col, lq)
         // the channels 4 lq .. + 3 and 16 + 4 lq .. + 3 of a 32-channel step, so its 16-byte operand is half (lq & 1) of the
         // natural fragments of lanes (col, lq >> 1) and (col, (lq >> 1) + 2)
@@ -717,6 +718,10 @@ struct Fwd {
       o.dense = same_stride && o.row_amax && o.wbd && !os_lists && dgr_conv_dense_supported(L.cin, L.cin_pad, L.cout) &&
                 cin_map.n_cap * (int64_t)in.ld * 4 < (1ll << 31);
       DGR_REQUIRE(o.dense || (!in.dsplit_only && !out.dsplit_only), "layer %s: dense split rows outside the dense-tile kernel", L.name.c_str());
+      // transposed convs (the strided map used swapped) with Cin, Cout multiples of 64: by parity class of the output rows
+      static const bool no_up = getenv("DGR_NO_UP") != nullptr;   // A/B
+      o.up = swapped && !o.dense && !no_up && !os_lists && o.row_amax && o.wbd && t->perm && res == nullptr &&
+             dgr_conv_up_supported(L.cin, L.cin_pad, L.cout) && cin_map.n_cap * (int64_t)in.ld * 4 < (1ll << 31);
       if (o.dense) {
         o.in_dsplit = in.dsplit;
         o.out_dsplit = out.dsplit;

@@ -4,7 +4,8 @@ offset), one product row from the same two-f16-piece operands with three MFMAs p
 back, in ascending offset order onto shift + residual (model/resunet.py:598-649).  The dense kernel feeds the input
 channels of a 32-channel step to the matrix unit in a different order (its quad-coalesced gather), so the f32 sums inside
 one MFMA round differently: the tensors of the FCGF forward must agree to a few f32 ulps of their scale, far below the
-1e-4 parity tolerance; the unit-norm output features to 2e-6.  The list-based kernel is held to the oracle and to f64 by
+1e-4 parity tolerance; the unit-norm output features to 4e-6 (2e-6 until the transposed convs, too, took the dense
+gather's channel order: conv_up.hip, round 6).  The list-based kernel is held to the oracle and to f64 by
 tests/test_gpu_resunet.py / test_gpu_split_f64.py, and so -- being the default -- is the dense one."""
 import os
 import subprocess
@@ -35,7 +36,9 @@ def test_each_variant_ran_its_kernels(dumps):
         kd, kl = dumps['dense'][net + '_kinds'].tolist(), dumps['lists'][net + '_kinds'].tolist()
         # block1 (32 -> 32 twice), block2 (64 -> 64 twice), block3_tr and block2_tr (64 -> 64 twice each): 8 layers
         assert sum(k.startswith('sparse_conv_dense_f16x2') for k in kd) == 8, kd
-        assert not any('dense' in k for k in kl) and sum(k.startswith('sparse_conv_os') for k in kl) >= 8
+        # conv4_tr, conv3_tr, conv2_tr: by parity class of the output rows (conv_up.hip)
+        assert sum(k.startswith('sparse_conv_up_f16x2') for k in kd) == 3, kd
+        assert not any('dense' in k or '_up_' in k for k in kl) and sum(k.startswith('sparse_conv_os') for k in kl) >= 11
 
 
 def test_every_tensor_agrees_with_the_list_based_kernel(dumps):
@@ -46,7 +49,7 @@ def test_every_tensor_agrees_with_the_list_based_kernel(dumps):
             assert np.isfinite(a).all() and np.abs(a).max() > 0 and a.shape == b.shape
             err = float(np.abs(a.astype(np.float64) - b).max() / np.abs(b).max())
             print(f'{net} {n:6s} max |dense - lists| / max |lists| = {err:.1e}')
-            assert err < 2e-6, (net, n, err)
+            assert err < 4e-6, (net, n, err)
 
 
 def test_middle_tensors_as_operand_pieces_change_no_bit(dumps):
