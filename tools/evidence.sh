@@ -28,6 +28,7 @@ if [ "$1" != nopmc ]; then
   python $R/tools/pmc_dominant.py "$K" "$W" $DBS > $O/dominant_pmc.json
   python $R/tools/pmc_dominant.py "sparse_conv_os<64, 64" "$W" $DBS > $O/os_conv_pmc.json
   python $R/tools/pmc_dominant.py "sparse_conv_dense_f16x2<64, 64" "$W" $DBS > $O/dense_conv_pmc.json
+  python $R/tools/pmc_dominant.py "sparse_conv_up_f16x2<128" "$W" $DBS > $O/up_conv_pmc.json
   python $R/tools/pmc_dominant.py "reduce_rows_kernel<64" "$W" $DBS > $O/reduce_rows_pmc.json
   python $R/tools/pmc_dominant.py "sparse_conv_wide_f16x2<64, 1, 2>" "$W" $DBS > $O/wide64_pmc.json
   python $R/tools/pmc_dominant.py "conv1_grid_mfma" "$W" $DBS > $O/conv1_pmc.json
