@@ -2,6 +2,8 @@
 CPU: with the oracle itself as the implementation under test the deviation is exactly zero; with an implementation
 that sums in another order (a row permutation of the same input) the deviation is what `reference_band` is meant to
 measure -- it must come out below the band the function reports for that family of perturbations."""
+import os
+
 import numpy as np
 
 from oracle import parity, registration as oreg
@@ -71,6 +73,7 @@ def test_bench_checker_legs_run_on_cpu(monkeypatch):
                                             break_threshold_ratio=ratio, quantization_size=q)
         return R, t, st
     monkeypatch.setattr(ops, 'se3_refine', se3_refine)
+    monkeypatch.setattr(os, 'cpu_count', lambda: 4)   # (the leg sets torch's thread count from it: see conftest.py)
     args = argparse.Namespace(voxel=voxel, no_refine=False)
     pair0 = {'xyz0': p0, 'coords0': c0, 'xyz1': p1, 'coords1': c1, 'idx1': idx1, 'F0': F0, 'F1': F1, 'logit': logit,
              'forced': forced, 'device': 'cpu'}
