@@ -812,6 +812,11 @@ def main():
             # the instrumented (wide-layer) kernels in the timed stream configuration: launches seen, mean execution span
             'kernel_us_timed_config': {k: {'launches': len(v), 'mean_us': round(float(np.mean(v)), 1)}
                                        for k, v in _group_launches(timed_cfg_launches).items()},
+            # every stamped span of the dominant kernel in that region, so that a profiler's per-launch table of the same
+            # process can be matched launch by launch (tools/evidence.sh): the region is a few of the process's launches, and
+            # what the other streams run next to the kernel differs from region to region
+            'dominant_spans_us_timed_config': ([round(float(u), 1) for u in _group_launches(timed_cfg_launches).get(dominant['name'], [])][:96]
+                                               if dominant else []),
         }
         out = {
             'metric': 'pair registrations/sec (FCGF x2 + 1-NN + 6-D inlier net + gate + weighted Procrustes + SE(3) refinement'

@@ -38,6 +38,27 @@ def test_fcgf_forward_matches_oracle(ks):
     assert len(stats) == 23 and stats[0]['K'] == ks ** 3 and stats[-1]['K'] == 1
 
 
+@pytest.mark.parametrize('n', [1, 2, 7, 40, 300])
+def test_fcgf_forward_on_tiny_clouds_with_negative_coordinates(n):
+    """Edge cases of the parity-class row lists of the transposed convs (conv_up.hip; round 6): clouds so small that
+    most of the eight classes are empty and every workgroup is partial, coordinates on both sides of zero (the class of a
+    row is the parity of coordinate / stride: floor-division semantics), two clouds of different size in one tensor."""
+    rng = np.random.default_rng(100 + n)
+    a = random_cloud_coords(rng, n, 6, 3, batch=0, surface=False)
+    a[:, 1:] -= 9                                   # all three coordinates negative
+    b = random_cloud_coords(rng, max(1, n // 2), 5, 3, batch=1, surface=False)
+    b[:, 1] -= 3                                    # mixed signs
+    coords = np.concatenate([a, b]).astype(np.int32)
+    feats = np.ones((len(coords), 1), np.float32)
+    net, out, ref = _check(3, 1, 32, 5, True, coords, feats, seed=31)
+    from deepglobalregistration_amd import ops
+    ops.set_profiling('cuda', True)
+    net.forward(torch.from_numpy(coords).cuda(), torch.from_numpy(feats).cuda())
+    kinds = ops.conv_launch_kinds('cuda')
+    ops.set_profiling('cuda', False)
+    assert sum(k.startswith('sparse_conv_up_f16x2') for k in kinds) == 3, kinds
+
+
 def test_fcgf_forward_general_input_features():
     rng = np.random.default_rng(42)
     coords = random_cloud_coords(rng, 2500, 16, 3)
