@@ -99,6 +99,34 @@ __global__ void mask_count_kernel(const uint32_t *__restrict__ mask, int KW, con
     }
   cnt[r] = c;
 }
+// the same for up to KM_JOBS6 bit matrices in ONE launch (blockIdx.y = matrix), the row's words requested together (the
+// loop above alternates loads and stores: 23 dependent round trips per row; three launches of 30 us per 6-D forward)
+constexpr int KM_MC_JOBS = 8;
+struct MaskCountJobs {
+  const uint32_t *mask[KM_MC_JOBS];
+  const int32_t *n_dev[KM_MC_JOBS];
+  long long n_cap[KM_MC_JOBS];
+  int32_t *cnt[KM_MC_JOBS];
+  unsigned short *wpre[KM_MC_JOBS];
+};
+template <int KW>
+__global__ void mask_count_multi(MaskCountJobs J) {
+  const int m = blockIdx.y;
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= J.n_cap[m]) return;
+  int c = 0;
+  if (r < *J.n_dev[m]) {
+    uint32_t w[KW];
+#pragma unroll
+    for (int i = 0; i < KW; ++i) w[i] = J.mask[m][r * KW + i];
+#pragma unroll
+    for (int i = 0; i < KW; ++i) {
+      J.wpre[m][r * KW + i] = (unsigned short)c;
+      c += __popc(w[i]);
+    }
+  }
+  J.cnt[m][r] = c;
+}
 // rank of offset k among the row's set offsets, with the per-word prefix of the row
 __device__ __forceinline__ int mask_rank_pre(const uint32_t *__restrict__ m, const unsigned short *__restrict__ pre, int k) {
   return pre[k >> 5] + __popc(m[k >> 5] & ((1u << (k & 31)) - 1u));
@@ -684,10 +712,20 @@ static int build_kernel_maps6(DgrArena &arena, const Kmap6Job *jobs, int nj, int
     }
     kmap_bits_pruned6<<<dim3((unsigned)max_sb, (unsigned)nj), KM_THREADS, 0, stream>>>(bj, KW);
     kmap_colmask<<<dim3((unsigned)max_rb, (unsigned)nj), KM_THREADS, 0, stream>>>(cj, K, KW);
-    for (int m = 0; m < nj; ++m)
-      if (jobs[m].need_in_csr)
-        mask_count_kernel<<<(int)dgr_ceil_div(t[m].n_in_cap + 1, 256), 256, 0, stream>>>(t[m].mask_in, KW, jobs[m].in->n_dev,
-                                                                                       t[m].n_in_cap + 1, t[m].cnt_in, t[m].wpre_in);
+    {
+      MaskCountJobs mj = {};
+      int nm = 0;
+      long long max_rows = 0;
+      for (int m = 0; m < nj; ++m)
+        if (jobs[m].need_in_csr) {
+          mj.mask[nm] = t[m].mask_in; mj.n_dev[nm] = jobs[m].in->n_dev; mj.n_cap[nm] = t[m].n_in_cap + 1;
+          mj.cnt[nm] = t[m].cnt_in; mj.wpre[nm] = t[m].wpre_in;
+          max_rows = std::max(max_rows, mj.n_cap[nm]);
+          ++nm;
+        }
+      static_assert(KM_MC_JOBS >= KM_MAXJOBS, "mask-count job table");
+      if (nm) mask_count_multi<KW><<<dim3((unsigned)dgr_ceil_div(max_rows, 256), (unsigned)nm), 256, 0, stream>>>(mj);
+    }
   }
   DGR_LAUNCH_CHECK();
   // ---- every scan of every map: CSR row pointers (out rows; in rows for maps used swapped) and the cell bases
