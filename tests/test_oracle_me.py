@@ -150,3 +150,34 @@ def test_stride_maps_and_their_transpose(seed, D, n):
     # each fine row reaches its own cell through the offset 0 or +1 per axis (floor semantics), so every fine
     # row appears at least once as an input of the strided conv
     assert set(i.tolist()) == set(range(len(fine)))
+
+
+def test_transposed_map_offsets_follow_the_parity_class_of_the_fine_row():
+    """What conv_up.hip (round 6) builds on, held to the oracle's transposed kernel maps: a fine row f
+    pairs with a coarse row c under offset delta only where c = f - delta ts lies on the coarse lattice, i.e. component d of
+    delta is 0 exactly where coordinate d of f is an EVEN multiple of the fine stride and +-1 where it is odd -- so the
+    set of offsets a fine row can use is a function of its parity class alone (2^(odd dims) of the 27), the classes
+    partition the rows, and no pair of the oracle's map falls outside its class's offsets.  Negative coordinates and
+    two tensor strides included."""
+    rng = np.random.default_rng(7)
+    for ts in (1, 2):
+        fine = np.unique(rng.integers(-9, 9, (400, 3)) * ts, axis=0)
+        fine = np.concatenate([np.zeros((len(fine), 1), np.int64), fine], axis=1).astype(np.int32)
+        coarse = me.stride_coords(fine, 2 * ts)
+        k, cin, fout = me.transposed_kernel_map(coarse, fine, 3, 3, ts)
+        assert len(k) > len(fine)                       # every fine row has its parent, most have more
+        offs = me.kernel_offsets(3, 3)
+        odd = (fine[fout, 1:].astype(np.int64) // ts) & 1           # [P, 3] parity of the OUTPUT (fine) row of every pair
+        np.testing.assert_array_equal(offs[k] != 0, odd == 1)       # delta_d != 0  <=>  coordinate d odd
+        # the coarse row really is f - delta ts, and it is on the coarse lattice
+        np.testing.assert_array_equal(coarse[cin, 1:], fine[fout, 1:] - offs[k] * ts)
+        assert (coarse[:, 1:] % (2 * ts) == 0).all()
+        # per class: the offsets used are a subset of the class's 2^(odd dims) offsets, and pairs per row <= that number
+        cls = odd[:, 0] | (odd[:, 1] << 1) | (odd[:, 2] << 2)
+        for c in range(8):
+            allowed = [j for j in range(27) if all((offs[j, d] != 0) == bool((c >> d) & 1) for d in range(3))]
+            assert len(allowed) == 1 << bin(c).count('1')
+            assert set(k[cls == c].tolist()) <= set(allowed)
+        rows, counts = np.unique(fout, return_counts=True)
+        row_cls = ((fine[rows, 1].astype(np.int64) // ts) & 1) | ((((fine[rows, 2].astype(np.int64) // ts) & 1)) << 1) | ((((fine[rows, 3].astype(np.int64) // ts) & 1)) << 2)
+        assert (counts <= (1 << np.array([bin(int(c)).count('1') for c in row_cls]))).all()
