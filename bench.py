@@ -325,8 +325,6 @@ def main():
                     'starts from the raw float64 host points (H2D copy + GPU voxelisation inside the timed region)')
     ap.add_argument('--streams', type=int, default=3, help='HIP streams per GPU, each driven by its own host '
                     'thread with its own library context and its own batches of pairs (independent units)')
-    ap.add_argument('--heavy-cus', type=int, default=0, help='role streams (dgr_ctx_create_role_streams): this many compute '
-                    'units (a multiple of 32) run the 6-D conv layers of every stream, the others everything else; 0 = off')
     ap.add_argument('--full-register', action='store_true', help='register() as the reference ships it: final ICP on '
                     '(use_icp = True, core/deep_global_registration.py:78,317-322); NOT the headline configuration')
     ap.add_argument('--force-safeguard', action='store_true', help='every pair takes the safeguard branch (RANSAC over its '
@@ -442,14 +440,6 @@ def main():
             self.wid, self.batch_ids = wid, batch_ids
             self.ctx = _lib.new_ctx(device) if S > 1 else None
             self.stream = torch.cuda.Stream(device) if S > 1 else torch.cuda.current_stream(device)
-            if args.heavy_cus:
-                # role streams: this context's 6-D conv layers on the GPU's heavy set of compute units, the rest of its
-                # work (this stream) on the light set -- the same two sets for every worker of the rank
-                if self.ctx is None:
-                    self.ctx = _lib.new_ctx(device)
-                _lib.use_ctx(self.ctx)
-                self.stream = ops.role_streams(device, args.heavy_cus)
-                _lib.use_ctx(None)
             self.results, self.result_ids, self.last_bt, self.k = [], [], None, 0
 
         def __enter__(self):

@@ -121,51 +121,7 @@ extern "C" int dgr_ctx_create(int device, dgr_ctx **out) {
   dgr_ctx *ctx = new dgr_ctx();
   ctx->device = device;
   ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  ctx->all_cus = ctx->num_cus;
   *out = ctx;
-  return DGR_OK;
-}
-
-static void drop_role_streams(dgr_ctx *ctx) {
-  if (ctx->heavy_stream) (void)hipStreamDestroy(ctx->heavy_stream);
-  if (ctx->light_stream) (void)hipStreamDestroy(ctx->light_stream);
-  for (auto &e : ctx->role_ev) {
-    if (e) (void)hipEventDestroy(e);
-    e = nullptr;
-  }
-  ctx->heavy_stream = ctx->light_stream = nullptr;
-  ctx->heavy_cus = 0;
-  ctx->num_cus = ctx->all_cus;
-}
-
-extern "C" int dgr_ctx_create_role_streams(dgr_ctx *ctx, int heavy_cus, dgr_stream *light_out) {
-  DGR_REQUIRE(ctx != nullptr && light_out != nullptr, "dgr_ctx_create_role_streams: NULL argument");
-  DGR_HIP_CHECK(hipSetDevice(ctx->device));
-  if (ctx->heavy_stream || ctx->light_stream) {
-    DGR_HIP_CHECK(hipDeviceSynchronize());
-    drop_role_streams(ctx);
-  }
-  *light_out = nullptr;
-  if (heavy_cus == 0) return DGR_OK;
-  // How a CU mask reaches the hardware on a multi-XCD part (amdkfd, mqd_symmetrically_map_cu_mask): bit b belongs to XCD
-  // b % 8 and is that XCD's slot b / 8; consecutive slots go round the XCD's four shader engines.  A set of whole groups
-  // of four slots per XCD therefore holds the same number of CUs in every shader engine of every XCD -- which a persistent
-  // one-workgroup-per-CU kernel needs: its workgroups are dealt to the shader engines in turn, and with an uneven set one
-  // of them waits for a whole round of the others (measured: 80 CUs = 10 slots per XCD ran the 6-D conv kernel 1.6x
-  // SLOWER than 64 CUs; tools/r06_runs/run37.sh, run38.sh).
-  const int n = ctx->all_cus, xcds = 8;
-  DGR_REQUIRE(n % (4 * xcds) == 0, "role streams: %d compute units are not 8 XCDs x 4 shader engines x k", n);
-  DGR_REQUIRE(heavy_cus % (4 * xcds) == 0 && heavy_cus >= 4 * xcds && heavy_cus <= n - 4 * xcds,
-              "role streams: heavy_cus = %d must be a multiple of %d in [%d, %d]", heavy_cus, 4 * xcds, 4 * xcds, n - 4 * xcds);
-  const int words = (n + 31) / 32, heavy_slots = heavy_cus / xcds;
-  std::vector<uint32_t> mh(words, 0u), ml(words, 0u);
-  for (int b = 0; b < n; ++b) (b / xcds < heavy_slots ? mh : ml)[b / 32] |= 1u << (b % 32);
-  DGR_HIP_CHECK(hipExtStreamCreateWithCUMask(&ctx->heavy_stream, (uint32_t)words, mh.data()));
-  DGR_HIP_CHECK(hipExtStreamCreateWithCUMask(&ctx->light_stream, (uint32_t)words, ml.data()));
-  for (auto &e : ctx->role_ev) DGR_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  ctx->heavy_cus = heavy_cus;
-  ctx->num_cus = n - heavy_cus;   // what the light stream's launches size themselves for
-  *light_out = (dgr_stream)ctx->light_stream;
   return DGR_OK;
 }
 
@@ -215,7 +171,6 @@ extern "C" void dgr_ctx_destroy(dgr_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
   if (ctx->wait_ev) (void)hipEventDestroy(ctx->wait_ev);
-  drop_role_streams(ctx);
   ctx->arena.release();
   ctx->events.release();
   delete ctx;

@@ -301,11 +301,6 @@ struct dgr_ctx {
   hipEvent_t wait_ev = nullptr; // the event dgr_ctx_wait polls (created on first use)
   long last_wait_ns = 0;        // how long the last dgr_ctx_wait of this context took
   double batch_ns_per_row = 0;  // dgr_register_batch: the previous call's wait per input row (predicts the next call's)
-  // role streams (dgr_ctx_create_role_streams): two CU-masked streams owned by the context; the 6-D conv layers run on
-  // `heavy_stream` (heavy_cus compute units), everything else on the caller's stream, which is `light_stream`
-  hipStream_t heavy_stream = nullptr, light_stream = nullptr;
-  int heavy_cus = 0, all_cus = 256;
-  hipEvent_t role_ev[2] = {nullptr, nullptr};   // light -> heavy, heavy -> light
 };
 
 // Wait for `stream` WITHOUT spinning: an event polled with naps in between, so that the host thread sleeps while its batch

@@ -750,8 +750,6 @@ struct Fwd {
     const char *kname = (L.cin == 6 && L.wq) ? "conv_cin6_quad_kernel" : L.cin == 1 ? "conv_small_cin_row_kernel" : "conv_small_cin_kernel";
     unsigned long long *clk = nullptr;
     const bool wide = L.wb && km;
-    // compute units the launch may count on: the heavy stream's share when the layers run there (role streams)
-    const int cus = (ctx->heavy_stream && stream == ctx->heavy_stream) ? ctx->heavy_cus : ctx->num_cus;
     if (small_cin)
       DGR_CHECK(dgr_conv_small_cin(in.ptr, in.ld, in.relu, L.cin, L.w, L.wq, L.shift, *km, cout_map.n_dev, cout_map.n_cap,
                                    out.ptr, out.ld, stream));
@@ -763,9 +761,9 @@ struct Fwd {
         DGR_HIP_CHECK(hipMemsetAsync(a.clk + 1, 0, sizeof(unsigned long long), stream));      // end: atomicMax
         clk = a.clk;
       }
-      DGR_CHECK(dgr_conv_wide_launch(a, in.split, L.wb, L.wb_piece, L.w_unscale, cus, stream, &kname));
+      DGR_CHECK(dgr_conv_wide_launch(a, in.split, L.wb, L.wb_piece, L.w_unscale, ctx->num_cus, stream, &kname));
     } else
-      DGR_CHECK(dgr_conv_launch(a, cus, stream, &kname));
+      DGR_CHECK(dgr_conv_launch(a, ctx->num_cus, stream, &kname));
     if (prof) DGR_HIP_CHECK(hipEventRecord(em, stream));   // end of the MFMA phase
     DGR_REQUIRE(!out.split.planes || (km && !small_cin), "layer %s: only a reduction can write split rows", L.name.c_str());
     if (km && !small_cin)
@@ -803,10 +801,8 @@ struct Fwd {
   }
 };
 
-// `stream`: the caller's; `ls`: the stream the conv layers run on -- the same, or the context's heavy stream (role streams,
-// dgr_ctx_create_role_streams: the 6-D net's conv layers on their own set of compute units)
-static int forward_body(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, const float *feats, int64_t N, float *out,
-                        hipStream_t stream, hipStream_t ls) {
+int dgr_resunet_forward_impl(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, const float *feats,
+                             int64_t N, float *out, hipStream_t stream) {
   DgrArena &A = ctx->arena;
   Fwd f;
   f.ctx = ctx; f.net = net; f.stream = stream; f.prof = ctx->profiling;
@@ -825,13 +821,6 @@ static int forward_body(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, const
   if (f.prof) {
     DGR_HIP_CHECK(hipEventRecord(m1, stream));
     (net->D == 3 ? ctx->map3_spans : ctx->map6_spans).push_back({m0, m1});
-  }
-  if (ls != stream) {
-    // the maps (and everything before them on the caller's stream) are complete before the first layer starts
-    DGR_HIP_CHECK(hipEventRecord(ctx->role_ev[0], stream));
-    DGR_HIP_CHECK(hipStreamWaitEvent(ls, ctx->role_ev[0], 0));
-    stream = ls;
-    f.stream = ls;
   }
   {
     // Y capacity: the largest (pair capacity x Cout) over the layers of this net
@@ -995,18 +984,6 @@ static int forward_body(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, const
   I["s1_tr"] = {cat1, 96, 64, ms.cm[0].n_dev};
 
   return DGR_OK;
-}
-
-int dgr_resunet_forward_impl(dgr_ctx *ctx, dgr_net *net, const int32_t *coords, const float *feats,
-                             int64_t N, float *out, hipStream_t stream) {
-  hipStream_t ls = (net->D == 6 && ctx->heavy_stream) ? ctx->heavy_stream : stream;
-  const int rc = forward_body(ctx, net, coords, feats, N, out, stream, ls);
-  if (ls != stream) {
-    // whatever happened: the caller's stream goes on (and the arena is reused) only after the heavy stream's work
-    DGR_HIP_CHECK(hipEventRecord(ctx->role_ev[1], ls));
-    DGR_HIP_CHECK(hipStreamWaitEvent(stream, ctx->role_ev[1], 0));
-  }
-  return rc;
 }
 
 void dgr_ctx_begin_profile(dgr_ctx *ctx) {

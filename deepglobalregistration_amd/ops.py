@@ -476,18 +476,6 @@ def batch_output(device, which):
     return out
 
 
-def role_streams(device, heavy_cus):
-    """Split the GPU's compute units between two CU-masked streams of the calling thread's context
-    (dgr_ctx_create_role_streams, include/dgr_hip.h): the conv layers of the 6-D inlier network run on the HEAVY one
-    (`heavy_cus` compute units, a multiple of 32), everything else on the LIGHT one, which is returned as a torch stream
-    -- make it the current stream (`with torch.cuda.stream(s):`) for every call of this context.  `heavy_cus = 0`
-    drops the pair again and returns None.  Worth it only with several contexts per GPU (one per host thread)."""
-    device = torch.device(device)
-    h = vp()
-    check(_lib.load().dgr_ctx_create_role_streams(get_ctx(device), int(heavy_cus), C.byref(h)))
-    return torch.cuda.ExternalStream(h.value, device) if h.value else None
-
-
 def set_profiling(device, enable):
     check(_lib.load().dgr_ctx_set_profiling(get_ctx(device), int(bool(enable))))
 

@@ -62,18 +62,6 @@ int dgr_ctx_create(int device, dgr_ctx **out);
 void dgr_ctx_destroy(dgr_ctx *ctx);
 /* bytes currently reserved by the grow-only workspace (diagnostics) */
 int64_t dgr_ctx_workspace_bytes(dgr_ctx *ctx);
-/* Role streams (no reference counterpart: the reference runs one pair at a time on torch's current stream,
- * core/deep_global_registration.py:238-324).  With several contexts per GPU (one per host thread, each registering its own
- * batches) every kernel competes for all compute units: a persistent 6-D conv kernel holds every CU for milliseconds and
- * another context's 10-us launch waits behind it.  This call splits the GPU's compute units into two sets by CU mask
- * (hipExtStreamCreateWithCUMask; `heavy_cus` of them, the same slots of every XCD, a multiple of 32 so that every shader
- * engine of every XCD holds the same number) and creates one stream on each, owned by the context:
- *   - the HEAVY stream runs the conv layers of the 6-D inlier network (memory-bound, persistent, sized to `heavy_cus`);
- *   - the LIGHT stream, returned in *light_out, is the stream the caller passes to every entry point from then on
- *     (FCGF, 1-NN, kernel maps, registration); dgr_resunet_forward / dgr_register_batch hand the 6-D conv layers over
- *     to the heavy stream and back through events.
- * Contexts that make the same call share the same two CU sets.  heavy_cus = 0: back to one stream (the caller's). */
-int dgr_ctx_create_role_streams(dgr_ctx *ctx, int heavy_cus, dgr_stream *light_out);
 
 /* ---- voxelisation: replaces ME.utils.sparse_quantize(xyz / voxel, return_index=True) and
  * ME.utils.batched_coordinates at core/deep_global_registration.py:152,158 (preprocess, :134-161).
