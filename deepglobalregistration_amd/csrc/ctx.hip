@@ -125,6 +125,19 @@ extern "C" int dgr_ctx_create(int device, dgr_ctx **out) {
   return DGR_OK;
 }
 
+int dgr_ctx_pinned(dgr_ctx *ctx, size_t bytes, unsigned char **out) {
+  if (bytes > ctx->pin_bytes) {
+    if (ctx->pin) DGR_HIP_CHECK(hipHostFree(ctx->pin));
+    ctx->pin = nullptr;
+    ctx->pin_bytes = 0;
+    const size_t want = bytes < 4096 ? 4096 : bytes * 2;
+    DGR_HIP_CHECK(hipHostMalloc((void **)&ctx->pin, want, hipHostMallocDefault));
+    ctx->pin_bytes = want;
+  }
+  *out = ctx->pin;
+  return DGR_OK;
+}
+
 int dgr_ctx_wait(dgr_ctx *ctx, hipStream_t stream, long predicted_ns) {
   static const bool spin = getenv("DGR_SPIN_SYNC") != nullptr;
   if (spin) {
@@ -171,6 +184,7 @@ extern "C" void dgr_ctx_destroy(dgr_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipDeviceSynchronize();
   if (ctx->wait_ev) (void)hipEventDestroy(ctx->wait_ev);
+  if (ctx->pin) (void)hipHostFree(ctx->pin);
   ctx->arena.release();
   ctx->events.release();
   delete ctx;

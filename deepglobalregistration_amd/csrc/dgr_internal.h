@@ -301,7 +301,18 @@ struct dgr_ctx {
   hipEvent_t wait_ev = nullptr; // the event dgr_ctx_wait polls (created on first use)
   long last_wait_ns = 0;        // how long the last dgr_ctx_wait of this context took
   double batch_ns_per_row = 0;  // dgr_register_batch: the previous call's wait per input row (predicts the next call's)
+  // pinned host landing buffer of the small device-to-host copies that end a call (error flag word at offset 0, result
+  // records from offset 64): a copy into PINNED memory is asynchronous, so it is enqueued BEFORE the call's one wait
+  // (dgr_ctx_wait) instead of blocking inside the runtime after it (a pageable copy + hipStreamSynchronize: ~100 us each)
+  unsigned char *pin = nullptr;
+  size_t pin_bytes = 0;
 };
+
+// at least `bytes` of pinned host memory owned by the context (grows; contents are not preserved across a growth -- ask
+// for everything a call needs before its first copy is enqueued)
+int dgr_ctx_pinned(dgr_ctx *ctx, size_t bytes, unsigned char **out);
+// error code (and message) of a kernel-map / coordinate flag word read back from the device; 0 -> DGR_OK
+int dgr_flag_error(int32_t flag);
 
 // Wait for `stream` WITHOUT spinning: an event polled with naps in between, so that the host thread sleeps while its batch
 // runs (hipStreamSynchronize busy-waits: with S streams x N ranks per node that is S x N cores pinned at 100 % for nothing;

@@ -1033,11 +1033,7 @@ int dgr_ctx_collect_profile(dgr_ctx *ctx) {
   return DGR_OK;
 }
 
-static int check_flag(dgr_ctx *ctx, const int32_t *flag_dev, hipStream_t stream) {
-  int32_t flag = 0;
-  DGR_CHECK(dgr_ctx_wait(ctx, stream));   // (before the pageable copy, which would otherwise busy-wait for the stream)
-  DGR_HIP_CHECK(hipMemcpyAsync(&flag, flag_dev, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-  DGR_HIP_CHECK(hipStreamSynchronize(stream));
+int dgr_flag_error(int32_t flag) {
   if (flag == 1) {
     dgr_set_error("duplicate coordinates in the sparse tensor input");
     return DGR_EINVAL;
@@ -1047,6 +1043,17 @@ static int check_flag(dgr_ctx *ctx, const int32_t *flag_dev, hipStream_t stream)
     return DGR_ENOMEM;
   }
   return DGR_OK;
+}
+
+static int check_flag(dgr_ctx *ctx, const int32_t *flag_dev, hipStream_t stream) {
+  // the flag word lands in pinned host memory: the copy is asynchronous and goes in FRONT of the call's one wait (a
+  // pageable destination made the copy block inside the runtime until the stream had drained, and a second
+  // synchronisation followed it)
+  unsigned char *pin;
+  DGR_CHECK(dgr_ctx_pinned(ctx, 64, &pin));
+  DGR_HIP_CHECK(hipMemcpyAsync(pin, flag_dev, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  DGR_CHECK(dgr_ctx_wait(ctx, stream));
+  return dgr_flag_error(*reinterpret_cast<volatile int32_t *>(pin));
 }
 
 int dgr_ctx_new_flag(dgr_ctx *ctx, hipStream_t stream) {

@@ -247,15 +247,19 @@ extern "C" int dgr_register_batch(dgr_ctx *ctx, dgr_net *fcgf, dgr_net *inlier, 
                                         prm->skip_refinement, 1, eps, weights, res_dev, stream));
   DGR_CHECK(tm.rec(4, 1));
 
-  std::vector<DgrRegResult> res(npairs);
-  // the batch's one wait, BEFORE the result copy: a device-to-host copy into pageable memory blocks inside the runtime
-  // (busy-waiting) until the stream has drained -- issued first it would BE the wait, and the thread would spin through the
-  // whole batch (measured, round 6: driver threads at 98 % of the wall time)
+  // The batch's results and its error flag land in PINNED host memory through two asynchronous copies enqueued in FRONT of
+  // the batch's one wait.  (Round 6, first half: the wait came before a pageable result copy, because a device-to-host copy
+  // into pageable memory blocks inside the runtime, busy-waiting, until the stream has drained -- issued first it WAS the
+  // wait, and the driver threads spun at 98 % of the wall time.  That left two blocking copies + two synchronisations
+  // behind the wait: ~0.2 ms per call with nothing on the GPU, profiles/r06_timeline_s1_b6.csv.gz.)
+  unsigned char *pin;
+  DGR_CHECK(dgr_ctx_pinned(ctx, 64 + (size_t)npairs * sizeof(DgrRegResult), &pin));
+  const DgrRegResult *res = reinterpret_cast<const DgrRegResult *>(pin + 64);
+  DGR_HIP_CHECK(hipMemcpyAsync(pin + 64, res_dev, (size_t)npairs * sizeof(DgrRegResult), hipMemcpyDeviceToHost, stream));
+  DGR_HIP_CHECK(hipMemcpyAsync(pin, ctx->flag_dev, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
   DGR_CHECK(dgr_ctx_wait(ctx, stream, (long)(ctx->batch_ns_per_row * (double)(n0 + n1))));
   ctx->batch_ns_per_row = (double)ctx->last_wait_ns / (double)(n0 + n1);
-  DGR_HIP_CHECK(hipMemcpyAsync(res.data(), res_dev, (size_t)npairs * sizeof(DgrRegResult), hipMemcpyDeviceToHost, stream));
-  DGR_HIP_CHECK(hipStreamSynchronize(stream));
-  DGR_CHECK(dgr_ctx_check_flag(ctx, stream));
+  DGR_CHECK(dgr_flag_error(*reinterpret_cast<volatile int32_t *>(pin)));
   for (int p = 0; p < npairs; ++p)
     if (res[p].status == DGR_STATUS_EXCHANGE_TIMEOUT) {
       dgr_set_error("registration of pair %d: the workgroups sharing the pair lost each other (exchange timed out)", p);
