@@ -8,7 +8,9 @@ weighted Procrustes -> SE(3) refinement; `dgr_register_batch`) over synthetic 3D
 (BASELINE.json configs[1]: 50k raw points per fragment, 5 cm voxels, conv1 k=7) whose voxelised
 coordinates are already resident in HBM.  Per GPU: S HIP streams, each driven by its own host thread
 with its own library context over ONE shared weight set, each registering batches of B pairs (pairs are independent
-units, streams never exchange data).  Defaults: S = 3, B = 6.
+units, streams never exchange data).  Defaults: S = 4, B = 6, every stream on its OWN quarter of the GPU's compute units
+(`dgr_ctx_create_partition_stream`: a CU-masked stream per context; `--no-cu-partition`: plain streams competing for all
+CUs, the configuration of rounds 1-5 with S = 3 -- 378 against 396 pairs/s on the same box, tools/r06_runs/run42.sh).
 
 * default (weak scaling): every rank registers its own S x B pairs per step;
 * `--total-pairs P` (strong scaling, BASELINE configs[3] with P = 512): P pairs are dealt over the
@@ -323,7 +325,9 @@ def main():
                     'timed region; it only runs together with the parity leg)')
     ap.add_argument('--from-host', action='store_true', help='PCIe-inclusive variant (NOT the headline): every step '
                     'starts from the raw float64 host points (H2D copy + GPU voxelisation inside the timed region)')
-    ap.add_argument('--streams', type=int, default=3, help='HIP streams per GPU, each driven by its own host '
+    ap.add_argument('--no-cu-partition', action='store_true', help='plain streams (every kernel of every stream competes for '
+                    'all compute units) instead of one CU-masked stream per context on its own share (S = 2 or 4 only)')
+    ap.add_argument('--streams', type=int, default=4, help='HIP streams per GPU, each driven by its own host '
                     'thread with its own library context and its own batches of pairs (independent units)')
     ap.add_argument('--full-register', action='store_true', help='register() as the reference ships it: final ICP on '
                     '(use_icp = True, core/deep_global_registration.py:78,317-322); NOT the headline configuration')
@@ -440,6 +444,16 @@ def main():
             self.wid, self.batch_ids = wid, batch_ids
             self.ctx = _lib.new_ctx(device) if S > 1 else None
             self.stream = torch.cuda.Stream(device) if S > 1 else torch.cuda.current_stream(device)
+            self.plain_stream, self.cus = self.stream, None
+            if partition:
+                # this context's own share of the compute units (a CU-masked stream owned by the library context)
+                _lib.use_ctx(self.ctx)
+                try:
+                    self.stream = ops.partition_stream(device, wid, S)
+                    self.cus = torch.cuda.get_device_properties(device).multi_processor_count // S
+                except Exception as e:   # a scheduling choice, not the product: say so and run on plain streams
+                    log(f'stream {wid}: no CU partition ({e!r}); plain stream')
+                _lib.use_ctx(None)
             self.results, self.result_ids, self.last_bt, self.k = [], [], None, 0
 
         def __enter__(self):
@@ -548,6 +562,7 @@ def main():
                         self.prof_launches += list(zip(kd, ku))
                 ops.set_profiling(device, False)
 
+    partition = S in (2, 4) and not args.no_cu_partition
     workers = [Worker(w, ids) for w, ids in enumerate(per_stream) if ids]
     for w in workers:
         w.prepare(shared_with=None if (w is workers[0] or os.environ.get('DGR_BENCH_PRIVATE_WEIGHTS')) else workers[0])
@@ -627,6 +642,12 @@ def main():
 
     # ---- profiled re-run of stream 0's first batch alone: HIP events around every sparse-conv launch ----
     _lib.use_ctx(w0.ctx)
+    cus_timed = w0.cus        # compute units a launch of the timed configuration ran on (None: all of them)
+    if w0.cus:
+        # ... alone on the WHOLE GPU: the per-kernel figures (frac_one_stream, by_kernel, the C <= 64 group, stage times,
+        # the PMC passes of tools/evidence.sh) are the kernels' own, not those of a quarter of the compute units
+        ops.partition_stream(device, 0, 1)
+        w0.stream, w0.cus = w0.plain_stream, None
     bt = w0.batches[0]
     with torch.cuda.stream(w0.stream):
         ops.set_profiling(device, True)
@@ -751,13 +772,18 @@ def main():
         alg_timed = gfl / (us_timed * 1e-6) / 1e3 if us_timed else alg        # TFLOP/s
         traffic = pmc.get('hbm_bytes_per_launch') if pmc else None
         alg_bytes = dominant['algorithmic_bytes_per_launch'] if dominant else byts / n_launch
+        ncu_all = torch.cuda.get_device_properties(device).multi_processor_count
+        share = (cus_timed / ncu_all) if cus_timed else 1.0   # a launch of the timed configuration runs on this share of the CUs
         roofline = {
-            'bound': 'mfma', 'achieved': products * alg_timed, 'peak': peak, 'unit': 'TFLOP/s',
-            'frac': products * alg_timed / peak,
+            # (timed configuration: `achieved` is ONE launch on its context's share of the compute units -- the other
+            # contexts run theirs next to it --, `peak` the dense MFMA peak of that share; whole-GPU figures: *_one_stream)
+            'bound': 'mfma', 'achieved': products * alg_timed, 'peak': peak * share, 'unit': 'TFLOP/s',
+            'frac': products * alg_timed / (peak * share),
+            'peak_whole_gpu': peak, 'cus_of_a_launch': cus_timed or ncu_all, 'cus_of_the_gpu': ncu_all,
             'traffic': traffic,
             'kernel': dominant['name'] if dominant else 'sparse conv (all variants)',
             # average duration of that kernel's launches in the timed configuration (S streams at once); the rocprofv3
-            # --kernel-trace average of the same command is profiles/r06_kernel_stats_s3_b6.csv (tools/evidence.sh checks
+            # --kernel-trace average of the same command is profiles/r06_kernel_stats_s4_b6.csv (tools/evidence.sh checks
             # that the two agree)
             'avg_launch_us': us_timed,
             'traffic_ratio': (traffic / alg_bytes) if traffic else None,           # PMC bytes / algorithmic bytes per launch
@@ -833,6 +859,8 @@ def main():
                                    f'{args.n_raw} raw pts/fragment, {args.kind}, voxel {args.voxel}, conv1 k={args.conv1_ks} '
                                    f'({cfg_label(args)})',
                        'streams_per_gpu': len(workers),
+                       'cu_partition': (f'{len(workers)} contexts, each on its own {cus_timed} of {ncu_all} compute units (CU-masked '
+                                        'stream, dgr_ctx_create_partition_stream)') if cus_timed else 'none (plain streams)',
                        'warmup_steps_run': workers[0].warmup_steps,
                        # weight sets resident per GPU (the streams share one: dgr_net_share) and their bytes
                        'weight_sets_per_gpu': (1 if workers[0].dgr.inlier_model._handle().sharers == len(workers) else len(workers)),
@@ -899,7 +927,8 @@ def main():
             try:
                 cmd = [sys.executable, os.path.abspath(__file__), '--steps', '8', '--warmup', '2', '--no-parity', '--no-exact-leg',
                        '--pairs-per-step', str(B), '--streams', str(S), '--n-raw', str(args.n_raw), '--voxel', str(args.voxel),
-                       '--kind', args.kind, '--conv1-ks', str(args.conv1_ks)] + (['--no-refine'] if args.no_refine else [])
+                       '--kind', args.kind, '--conv1-ks', str(args.conv1_ks)] + (['--no-refine'] if args.no_refine else []) \
+                    + (['--no-cu-partition'] if args.no_cu_partition else [])
                 cp = subprocess.run(cmd, env=dict(os.environ, DGR_EXACT_F32='1'), capture_output=True, text=True, timeout=300)
                 line = [l for l in cp.stdout.splitlines() if l.startswith('{')][-1]
                 ex = json.loads(line)

@@ -42,6 +42,7 @@ SIGNATURES = {
     'dgr_ctx_create': (C.c_int, [C.c_int, C.POINTER(vp)]),
     'dgr_ctx_destroy': (None, [vp]),
     'dgr_ctx_workspace_bytes': (C.c_int64, [vp]),
+    'dgr_ctx_create_partition_stream': (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(vp)]),
     'dgr_voxelize': (C.c_int, [vp, vp, C.c_int, C.c_int64, C.c_double, C.c_int32, vp, vp, vp, c_i64p, vp]),
     'dgr_net_create': (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.POINTER(WeightDesc), C.c_int, C.POINTER(vp)]),

@@ -121,7 +121,42 @@ extern "C" int dgr_ctx_create(int device, dgr_ctx **out) {
   dgr_ctx *ctx = new dgr_ctx();
   ctx->device = device;
   ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  ctx->all_cus = ctx->num_cus;
   *out = ctx;
+  return DGR_OK;
+}
+
+extern "C" int dgr_ctx_create_partition_stream(dgr_ctx *ctx, int part, int nparts, dgr_stream *out) {
+  DGR_REQUIRE(ctx != nullptr && out != nullptr, "dgr_ctx_create_partition_stream: NULL argument");
+  DGR_REQUIRE(nparts == 1 || nparts == 2 || nparts == 4, "partition stream: nparts = %d (1, 2 or 4)", nparts);
+  DGR_REQUIRE(part >= 0 && part < nparts, "partition stream: part %d of %d", part, nparts);
+  DGR_HIP_CHECK(hipSetDevice(ctx->device));
+  *out = nullptr;
+  if (ctx->part_stream) {
+    DGR_HIP_CHECK(hipDeviceSynchronize());
+    DGR_HIP_CHECK(hipStreamDestroy(ctx->part_stream));
+    ctx->part_stream = nullptr;
+    ctx->num_cus = ctx->all_cus;
+  }
+  if (nparts == 1) return DGR_OK;
+  // How a CU mask reaches a multi-XCD part (amdkfd, mqd_symmetrically_map_cu_mask): bit b is slot b / 8 of XCD b % 8.
+  // Share p = the slots with slot % nparts == p of every XCD: 16 or 8 CUs of each XCD (all eight L2s stay in use, and the
+  // wide conv kernel's "block b runs on XCD b % 8" still holds).  Shares of 8, 16 and 24 slots per XCD ran a persistent
+  // one-workgroup-per-CU kernel at the expected rate; shares of 10 and 6 slots ran it 1.6-2x SLOWER than 8 (tools/r06_runs/
+  // run37.sh, run38.sh) -- hence only halves and quarters here.
+  const int n = ctx->all_cus, xcds = 8;
+  DGR_REQUIRE(n % (xcds * 8) == 0, "partition stream: %d compute units are not 8 XCDs x 8 k slots", n);
+  const int words = (n + 31) / 32;
+  std::vector<uint32_t> mask(words, 0u);
+  int mine = 0;
+  for (int b = 0; b < n; ++b)
+    if ((b / xcds) % nparts == part) {
+      mask[b / 32] |= 1u << (b % 32);
+      ++mine;
+    }
+  DGR_HIP_CHECK(hipExtStreamCreateWithCUMask(&ctx->part_stream, (uint32_t)words, mask.data()));
+  ctx->num_cus = mine;   // what the context's persistent launches size themselves for
+  *out = (dgr_stream)ctx->part_stream;
   return DGR_OK;
 }
 
@@ -185,6 +220,7 @@ extern "C" void dgr_ctx_destroy(dgr_ctx *ctx) {
   (void)hipDeviceSynchronize();
   if (ctx->wait_ev) (void)hipEventDestroy(ctx->wait_ev);
   if (ctx->pin) (void)hipHostFree(ctx->pin);
+  if (ctx->part_stream) (void)hipStreamDestroy(ctx->part_stream);
   ctx->arena.release();
   ctx->events.release();
   delete ctx;

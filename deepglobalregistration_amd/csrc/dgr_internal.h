@@ -306,6 +306,9 @@ struct dgr_ctx {
   // (dgr_ctx_wait) instead of blocking inside the runtime after it (a pageable copy + hipStreamSynchronize: ~100 us each)
   unsigned char *pin = nullptr;
   size_t pin_bytes = 0;
+  // dgr_ctx_create_partition_stream: the context's own CU-masked stream; num_cus is then the share, all_cus the device
+  hipStream_t part_stream = nullptr;
+  int all_cus = 256;
 };
 
 // at least `bytes` of pinned host memory owned by the context (grows; contents are not preserved across a growth -- ask

@@ -476,6 +476,17 @@ def batch_output(device, which):
     return out
 
 
+def partition_stream(device, part, nparts):
+    """A stream of the calling thread's context on share `part` of `nparts` (2 or 4) equal shares of the GPU's compute
+    units (dgr_ctx_create_partition_stream, include/dgr_hip.h), as a torch stream: make it the current stream
+    (`with torch.cuda.stream(s):`) for every call of this context.  `nparts = 1` drops the partition and returns None.
+    Pays only when several contexts (one per host thread) keep the GPU busy at once; results do not depend on it."""
+    device = torch.device(device)
+    h = vp()
+    check(_lib.load().dgr_ctx_create_partition_stream(get_ctx(device), int(part), int(nparts), C.byref(h)))
+    return torch.cuda.ExternalStream(h.value, device) if h.value else None
+
+
 def set_profiling(device, enable):
     check(_lib.load().dgr_ctx_set_profiling(get_ctx(device), int(bool(enable))))
 

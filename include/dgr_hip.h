@@ -62,6 +62,18 @@ int dgr_ctx_create(int device, dgr_ctx **out);
 void dgr_ctx_destroy(dgr_ctx *ctx);
 /* bytes currently reserved by the grow-only workspace (diagnostics) */
 int64_t dgr_ctx_workspace_bytes(dgr_ctx *ctx);
+/* A stream on its own share of the GPU's compute units (no reference counterpart: the reference registers one pair at a
+ * time on torch's current stream, core/deep_global_registration.py:238-324).  A process that keeps several contexts busy
+ * (one per host thread, each with its own batches) lets every kernel of every context compete for all CUs: a persistent
+ * 6-D conv kernel of one context holds every CU for milliseconds and another context's 10-us launch waits behind it.
+ * This call creates a stream whose kernels run on share `part` of `nparts` (2 or 4) equal shares of the CUs
+ * (hipExtStreamCreateWithCUMask; mask bit b is slot b / 8 of XCD b % 8, share p takes the slots with slot % nparts == p
+ * of EVERY XCD, so each share keeps all eight L2s), sizes the context's persistent launches for that share, and returns
+ * the stream in *out: pass it to every entry point called with this context.  The stream belongs to the context
+ * (destroyed with it; a second call replaces it after a device synchronisation).  nparts = 1 drops the partition
+ * (*out = NULL).  Results do not depend on it (grids only).  Measured on MI355X, BASELINE configs[1]: four contexts on
+ * four shares 396 pairs/s against 378 for three contexts on the whole GPU and 360 for four (tools/r06_runs/run42.sh). */
+int dgr_ctx_create_partition_stream(dgr_ctx *ctx, int part, int nparts, dgr_stream *out);
 
 /* ---- voxelisation: replaces ME.utils.sparse_quantize(xyz / voxel, return_index=True) and
  * ME.utils.batched_coordinates at core/deep_global_registration.py:152,158 (preprocess, :134-161).

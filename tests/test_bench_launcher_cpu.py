@@ -35,7 +35,7 @@ def test_gpus_8_starts_eight_ranks_weak_and_strong():
     registered once; strong mode: BASELINE configs[3], 512 pairs dealt 64 per rank by cost."""
     out = _run('--gpus', '8')
     assert out['n_gpus'] == 8 and out['requested_gpus'] == 8
-    assert out['pairs'] == 8 * 3 * 6 and out['all_pairs_covered_once']     # the defaults: 3 streams x batches of 6 per rank
+    assert out["pairs"] == 8 * 4 * 6 and out["all_pairs_covered_once"]     # the defaults: 4 streams x batches of 6 per rank
     assert out['max_over_ranks'] == 8.0 and out['weights_broadcast_keys'] > 100
     out = _run('--gpus', '8', '--total-pairs', '512')
     assert out['n_gpus'] == 8 and out['pairs'] == 512 and out['all_pairs_covered_once']

@@ -41,9 +41,12 @@ P
   rm -rf $O/pmc
   cp $O/dominant_pmc.json $R/profiles/${RND}_dominant_pmc.json    # the lines below quote it (roofline.traffic)
 fi
-# the driver's command: no flags (3 streams x 6 pairs, 5 warm-up + 100 timed steps, two input sets taken in turn, parity + CPU baseline)
+# the driver's command: no flags (4 contexts x 6 pairs, each context on its own quarter of the compute units; 5 warm-up + 100
+# timed steps, two input sets taken in turn, parity + CPU baseline)
 timeout 900 $B > $O/bench_c1_default.json 2> $O/bench_c1_default.err
-timeout 300 $B --pairs-per-step 4 --no-parity > $O/bench_c1_s3_b4.json 2> $O/bench_c1_s3_b4.err   # the default of rounds 1-4
+# the default of rounds 5-6 until the CU partition: three plain streams x 6 pairs competing for all compute units; and 3 x 4 (rounds 1-4)
+timeout 300 $B --streams 3 --no-cu-partition --no-parity > $O/bench_c1_s3_b6_plain.json 2> $O/bench_c1_s3_b6_plain.err
+timeout 300 $B --streams 3 --no-cu-partition --pairs-per-step 4 --no-parity > $O/bench_c1_s3_b4.json 2> $O/bench_c1_s3_b4.err
 timeout 300 $B --streams 1 --pairs-per-step 4 --no-parity > $O/bench_c1_s1_b4.json 2> $O/bench_c1_s1_b4.err
 timeout 300 $B --streams 1 --pairs-per-step 1 --no-parity > $O/bench_c1_s1_b1.json 2> $O/bench_c1_s1_b1.err
 # BASELINE configs[2] (KITTI-shaped, 13 k voxels per scan): batches of 4 and 8 pairs per stream
@@ -67,9 +70,14 @@ timeout 300 rocprofv3 --kernel-trace -d $O/kt6 -o kt -- $B --streams 1 --no-pari
 python $R/tools/rocpd_summary.py $O/kt6/kt_results.db $O/kernel_stats_s1_b6.csv
 grep '^{' $O/kt6.log | tail -1 > $O/bench_c1_s1_b6_under_rocprof.json
 timeout 300 rocprofv3 --kernel-trace -d $O/kt3 -o kt -- $B --no-parity --steps 5 > $O/kt3.log 2>&1
-python $R/tools/rocpd_summary.py $O/kt3/kt_results.db $O/kernel_stats_s3_b6.csv --trace sparse_conv_wide_f16x2 $O/wide_trace_s3_b6.csv
+python $R/tools/rocpd_summary.py $O/kt3/kt_results.db $O/kernel_stats_s4_b6.csv --trace sparse_conv_wide_f16x2 $O/wide_trace_s4_b6.csv
+grep '^{' $O/kt3.log | tail -1 > $O/bench_c1_s4_b6_under_rocprof.json
+# every launch of that run with its stream, and of the one-stream run: what the contexts do with the GPU's time (tools/timeline_stats.py)
+python $R/tools/timeline_dump.py $O/kt3/kt_results.db $O/timeline_s4_b6.csv.gz 2> /dev/null
+python $R/tools/timeline_dump.py $O/kt6/kt_results.db $O/timeline_s1_b6.csv.gz 2> /dev/null
+python $R/tools/timeline_stats.py $O/timeline_s4_b6.csv.gz $O/timeline_s1_b6.csv.gz > $O/timeline_s4_vs_s1.txt 2>&1
 # the line printed INSIDE that profiled run against the profiler's own table (round-5 verdict, task 1b).  The line's
-# roofline.avg_launch_us is the mean of the spans the kernel stamped in the 3-stream region AFTER the timed steps -- a few of
+# roofline.avg_launch_us is the mean of the spans the kernel stamped in the multi-stream region AFTER the timed steps -- a few of
 # the process's launches, next to whatever the other two streams happened to run (3.2 - 6 ms from region to region) --, so
 # it is held to the profiler LAUNCH BY LAUNCH: every stamped span must have its own rocprofv3 record of the same duration
 # (order-preserving assignment of the sorted spans to the sorted records); the two plain averages are printed next to it
@@ -77,11 +85,11 @@ python - <<P | tee $O/line_vs_rocprof.txt
 import csv, json
 line = [l for l in open('$O/kt3.log') if l.startswith('{')][-1]
 d = json.loads(line); k = d['roofline']['kernel']; us = d['roofline']['avg_launch_us']
-rows = [r for r in csv.DictReader(open('$O/kernel_stats_s3_b6.csv')) if k in r['Name']]
+rows = [r for r in csv.DictReader(open('$O/kernel_stats_s4_b6.csv')) if k in r['Name']]
 avg = float(rows[0]['AverageNs']) / 1e3
 S = sorted(d['roofline_detail'].get('dominant_spans_us_timed_config', []))
-Rr = sorted(float(r['DurationNs']) / 1e3 for r in csv.DictReader(open('$O/wide_trace_s3_b6.csv')) if k in r['Name'])
-msg = f'commit $COMMIT: {k}: bench line (3 streams, under rocprofv3) mean of {len(S)} stamped spans {us:.1f} us; rocprofv3 --kernel-trace average over ALL {rows[0]["Calls"]} calls of the process {avg:.1f} us'
+Rr = sorted(float(r['DurationNs']) / 1e3 for r in csv.DictReader(open('$O/wide_trace_s4_b6.csv')) if k in r['Name'])
+msg = f'commit $COMMIT: {k}: bench line (timed stream configuration, under rocprofv3) mean of {len(S)} stamped spans {us:.1f} us; rocprofv3 --kernel-trace average over ALL {rows[0]["Calls"]} calls of the process {avg:.1f} us'
 if S and len(Rr) >= len(S):
     INF = float('inf')
     cost = [[INF] * (len(Rr) + 1) for _ in range(len(S) + 1)]
