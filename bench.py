@@ -773,13 +773,15 @@ def main():
         traffic = pmc.get('hbm_bytes_per_launch') if pmc else None
         alg_bytes = dominant['algorithmic_bytes_per_launch'] if dominant else byts / n_launch
         ncu_all = torch.cuda.get_device_properties(device).multi_processor_count
-        share = (cus_timed / ncu_all) if cus_timed else 1.0   # a launch of the timed configuration runs on this share of the CUs
+        # a launch of the timed configuration runs on this share of the CUs -- when its duration there is known (the kernel
+        # stamped it); otherwise `us_timed` is the one-stream, whole-GPU duration and so is the peak
+        share = (cus_timed / ncu_all) if (cus_timed and tc) else 1.0
         roofline = {
             # (timed configuration: `achieved` is ONE launch on its context's share of the compute units -- the other
             # contexts run theirs next to it --, `peak` the dense MFMA peak of that share; whole-GPU figures: *_one_stream)
             'bound': 'mfma', 'achieved': products * alg_timed, 'peak': peak * share, 'unit': 'TFLOP/s',
             'frac': products * alg_timed / (peak * share),
-            'peak_whole_gpu': peak, 'cus_of_a_launch': cus_timed or ncu_all, 'cus_of_the_gpu': ncu_all,
+            'peak_whole_gpu': peak, 'cus_of_a_launch': int(round(share * ncu_all)), 'cus_of_the_gpu': ncu_all,
             'traffic': traffic,
             'kernel': dominant['name'] if dominant else 'sparse conv (all variants)',
             # average duration of that kernel's launches in the timed configuration (S streams at once); the rocprofv3

@@ -205,7 +205,15 @@ int dgr_ctx_wait(dgr_ctx *ctx, hipStream_t stream, long predicted_ns) {
     if (e == hipSuccess) break;
     if (e != hipErrorNotReady) DGR_HIP_CHECK(e);
     const long el = elapsed_ns();
-    if (predicted_ns > 300000 && el < predicted_ns + predicted_ns / 10) continue;   // the last stretch: poll
+    if (predicted_ns > 300000 && el < predicted_ns + predicted_ns / 10) {   // the last stretch: poll ...
+      // ... without naps when the call is short (a nap costs >= 60 us of timer slack: latency of a single pair), with
+      // 30-us naps when it is long (a 60-ms batch of a 4-context process kept four threads spinning for 12 ms each)
+      if (predicted_ns > 8000000) {
+        struct timespec nap = {0, 30000};
+        nanosleep(&nap, nullptr);
+      }
+      continue;
+    }
     long ns = el / 64;
     struct timespec nap = {0, ns < 10000 ? 10000 : ns > 200000 ? 200000 : ns};
     nanosleep(&nap, nullptr);

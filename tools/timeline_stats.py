@@ -48,15 +48,26 @@ def main():
     bs = np.sort(st[sel])
     # every batch has 2 launches of it; the steady state = the last 2/3 of them
     lo, hi = bs[len(bs) // 3], bs[-1]
-    streams = [s for s in sorted(set(q.tolist())) if (sel & (q == s)).sum() > 4]
+    cnt = {s_: int((sel & (q == s_)).sum()) for s_ in sorted(set(q.tolist()))}
+    streams = [s_ for s_, c in cnt.items() if c > 4 and 2 * c >= max(cnt.values())]   # (not the stream of a short extra leg)
     if len(streams) > 1:
         # the multi-stream region: where EVERY stream that runs the big kernel is active; its first 30 % is warm-up
-        # (each stream also has earlier launches of its own: start-up, its single-stream warm-up -- skip anything before
-        # the last gap of more than 0.5 s in the merged launch sequence of the secondary streams)
-        sec = np.sort(np.concatenate([st[sel & (q == s)] for s in streams[1:]]))
-        gaps = np.nonzero(np.diff(sec) > 500_000_000)[0]
-        a = sec[gaps[-1] + 1] if len(gaps) else sec[0]
-        b = min(st[sel & (q == s)].max() for s in streams)
+        # (each stream also has earlier launches of its own: start-up, its single-stream warm-up) -- the longest run of
+        # 100-ms bins in which EVERY one of these streams launches the big kernel
+        t0 = st.min()
+        nb = int((st.max() - t0) // 100_000_000) + 1
+        every = np.ones(nb, bool)
+        for s_ in streams:
+            h = np.zeros(nb, bool)
+            h[((st[sel & (q == s_)] - t0) // 100_000_000).astype(int)] = True
+            every &= h
+        best, cur, best_end = 0, 0, 0
+        for i, v in enumerate(every):
+            cur = cur + 1 if v else 0
+            if cur > best:
+                best, best_end = cur, i
+        a = t0 + (best_end - best + 1) * 100_000_000
+        b = t0 + (best_end + 1) * 100_000_000
         lo, hi = a + int(0.3 * (b - a)), b
     m = (st >= lo) & (en <= hi)
     print(f'{sys.argv[1]}: window {1e-6 * (hi - lo):.1f} ms, {m.sum()} launches, streams {sorted(set(q[m].tolist()))}')
