@@ -916,8 +916,12 @@ def main():
                 if wi == 0:
                     out['cpu_baseline'] = base
                 log(f'parity (stream {wi}, pair {qi}): {par}')
+            # (a pair whose R / t exceed 1e-4 carries the arbiter's numbers that decided it)
             out['parity'] = dict(checks[0], per_stream=[{k: c.get(k) for k in ('stream', 'pair', 'voxels', 'dF', 'dlogit_rel', 'dR', 'dt',
-                                                                              'refinement_iterations', 'within_1e-4', 'ok')}
+                                                                              'refinement_iterations', 'within_1e-4', 'ok',
+                                                                              'rt_not_farther_from_f64_than_reference', 'window_accuracy')
+                                                         + (('f64_arbiter',) if not c.get('rt_within_1e-4', True) else ())
+                                                         if k in c}
                                                         for c in checks])
             # the stated tolerance next to the verdict that also accepts the reference's own chaos (f64 arbiter)
             out['config']['parity_within_1e-4'] = bool(all(c.get('within_1e-4') for c in checks))

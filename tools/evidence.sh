@@ -51,6 +51,12 @@ timeout 300 $B --streams 1 --pairs-per-step 4 --no-parity > $O/bench_c1_s1_b4.js
 timeout 300 $B --streams 1 --pairs-per-step 1 --no-parity > $O/bench_c1_s1_b1.json 2> $O/bench_c1_s1_b1.err
 # BASELINE configs[2] (KITTI-shaped, 13 k voxels per scan): batches of 4 and 8 pairs per stream
 timeout 600 $B --kind outdoor --n-raw 120000 --voxel 0.3 --conv1-ks 5 --pairs-per-step 4 > $O/bench_c3.json 2> $O/bench_c3.err
+# ... and the configurations the CU partition does NOT help (small batches: configs[2]; one big pair per batch: configs[4]) on
+# three plain streams next to their partitioned lines
+P3="--streams 3 --no-cu-partition --no-parity"
+timeout 600 $B --kind outdoor --n-raw 120000 --voxel 0.3 --conv1-ks 5 --pairs-per-step 4 $P3 > $O/bench_c3_plain.json 2> $O/bench_c3_plain.err
+timeout 600 $B --kind outdoor --n-raw 120000 --voxel 0.3 --conv1-ks 5 --pairs-per-step 8 $P3 > $O/bench_c3_b8_plain.json 2> $O/bench_c3_b8_plain.err
+timeout 600 $B --n-raw 200000 --voxel 0.025 --pairs-per-step 1 $P3 > $O/bench_c5_plain.json 2> $O/bench_c5_plain.err
 timeout 600 $B --kind outdoor --n-raw 120000 --voxel 0.3 --conv1-ks 5 --pairs-per-step 8 --no-parity > $O/bench_c3_b8.json 2> $O/bench_c3_b8.err
 timeout 600 $B --n-raw 200000 --voxel 0.025 --pairs-per-step 1 --no-parity > $O/bench_c5.json 2> $O/bench_c5.err
 timeout 600 $B --n-raw 200000 --voxel 0.025 --pairs-per-step 1 --no-parity --no-refine > $O/bench_c5_norefine.json 2> $O/bench_c5_norefine.err
