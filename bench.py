@@ -325,6 +325,8 @@ def main():
                     'timed region; it only runs together with the parity leg)')
     ap.add_argument('--from-host', action='store_true', help='PCIe-inclusive variant (NOT the headline): every step '
                     'starts from the raw float64 host points (H2D copy + GPU voxelisation inside the timed region)')
+    ap.add_argument('--cu-shares', type=int, default=0, help='number of equal shares of the compute units (2 or 4) the contexts are '
+                    'dealt over, context w on share w mod N; 0 = one share per context when S is 2 or 4 (the default)')
     ap.add_argument('--no-cu-partition', action='store_true', help='plain streams (every kernel of every stream competes for '
                     'all compute units) instead of one CU-masked stream per context on its own share (S = 2 or 4 only)')
     ap.add_argument('--streams', type=int, default=4, help='HIP streams per GPU, each driven by its own host '
@@ -449,8 +451,8 @@ def main():
                 # this context's own share of the compute units (a CU-masked stream owned by the library context)
                 _lib.use_ctx(self.ctx)
                 try:
-                    self.stream = ops.partition_stream(device, wid, S)
-                    self.cus = torch.cuda.get_device_properties(device).multi_processor_count // S
+                    self.stream = ops.partition_stream(device, wid % partition, partition)
+                    self.cus = torch.cuda.get_device_properties(device).multi_processor_count // partition
                 except Exception as e:   # a scheduling choice, not the product: say so and run on plain streams
                     log(f'stream {wid}: no CU partition ({e!r}); plain stream')
                 _lib.use_ctx(None)
@@ -562,7 +564,10 @@ def main():
                         self.prof_launches += list(zip(kd, ku))
                 ops.set_profiling(device, False)
 
-    partition = S in (2, 4) and not args.no_cu_partition
+    # shares of the compute units the contexts are dealt over (0: plain streams)
+    partition = 0 if (args.no_cu_partition or S == 1) else (args.cu_shares or (S if S in (2, 4) else 0))
+    if partition not in (0, 2, 4):
+        raise SystemExit(f'bench.py: --cu-shares {partition}: 2 or 4 (dgr_ctx_create_partition_stream)')
     workers = [Worker(w, ids) for w, ids in enumerate(per_stream) if ids]
     for w in workers:
         w.prepare(shared_with=None if (w is workers[0] or os.environ.get('DGR_BENCH_PRIVATE_WEIGHTS')) else workers[0])
@@ -861,8 +866,8 @@ def main():
                                    f'{args.n_raw} raw pts/fragment, {args.kind}, voxel {args.voxel}, conv1 k={args.conv1_ks} '
                                    f'({cfg_label(args)})',
                        'streams_per_gpu': len(workers),
-                       'cu_partition': (f'{len(workers)} contexts, each on its own {cus_timed} of {ncu_all} compute units (CU-masked '
-                                        'stream, dgr_ctx_create_partition_stream)') if cus_timed else 'none (plain streams)',
+                       'cu_partition': (f'{len(workers)} contexts on {partition} shares of {cus_timed} of {ncu_all} compute units each '
+                                        '(CU-masked streams, dgr_ctx_create_partition_stream)') if cus_timed else 'none (plain streams)',
                        'warmup_steps_run': workers[0].warmup_steps,
                        # weight sets resident per GPU (the streams share one: dgr_net_share) and their bytes
                        'weight_sets_per_gpu': (1 if workers[0].dgr.inlier_model._handle().sharers == len(workers) else len(workers)),
@@ -934,7 +939,7 @@ def main():
                 cmd = [sys.executable, os.path.abspath(__file__), '--steps', '8', '--warmup', '2', '--no-parity', '--no-exact-leg',
                        '--pairs-per-step', str(B), '--streams', str(S), '--n-raw', str(args.n_raw), '--voxel', str(args.voxel),
                        '--kind', args.kind, '--conv1-ks', str(args.conv1_ks)] + (['--no-refine'] if args.no_refine else []) \
-                    + (['--no-cu-partition'] if args.no_cu_partition else [])
+                    + (['--no-cu-partition'] if args.no_cu_partition else []) + ['--cu-shares', str(args.cu_shares)]
                 cp = subprocess.run(cmd, env=dict(os.environ, DGR_EXACT_F32='1'), capture_output=True, text=True, timeout=300)
                 line = [l for l in cp.stdout.splitlines() if l.startswith('{')][-1]
                 ex = json.loads(line)
