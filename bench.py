@@ -787,6 +787,12 @@ def main():
             'bound': 'mfma', 'achieved': products * alg_timed, 'peak': peak * share, 'unit': 'TFLOP/s',
             'frac': products * alg_timed / (peak * share),
             'peak_whole_gpu': peak, 'cus_of_a_launch': int(round(share * ncu_all)), 'cus_of_the_gpu': ncu_all,
+            # the same launch against the WHOLE GPU's peak (= frac x the share): what one context's launch reaches while the
+            # other contexts run theirs on the other shares -- not comparable with frac_one_stream, which had all CUs
+            'frac_vs_whole_gpu_peak': products * alg_timed / peak,
+            'frac_note': (f'a launch of the timed configuration runs on {int(round(share * ncu_all))} of {ncu_all} compute units '
+                          f'(its context\'s share, {len(workers)} contexts side by side): achieved / (peak_whole_gpu x share)')
+                         if share < 1.0 else 'whole GPU',
             'traffic': traffic,
             'kernel': dominant['name'] if dominant else 'sparse conv (all variants)',
             # average duration of that kernel's launches in the timed configuration (S streams at once); the rocprofv3
