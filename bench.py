@@ -278,7 +278,7 @@ def launch_check(args, rank, world, backend):
     from deepglobalregistration_amd import dist as ddist, synth
     ck = synth.synth_checkpoint(seed=0, feat_conv1_kernel_size=3, with_inlier=False) if rank == 0 else None
     ck = ddist.broadcast_checkpoint(ck, src=0, device=torch.device('cpu'))
-    P = args.total_pairs or world * args.streams * args.pairs_per_step
+    P = args.total_pairs or world * (args.streams or 4) * args.pairs_per_step
     lo, hi = ddist.shard_range(P, rank, world)
     rng = np.random.default_rng(1234)
     all_cost = rng.uniform(1.0, 2.0, P)                     # stand-in for N0 * N1 of the provisional block
@@ -329,7 +329,7 @@ def main():
                     'dealt over, context w on share w mod N; 0 = one share per context when S is 2 or 4 (the default)')
     ap.add_argument('--no-cu-partition', action='store_true', help='plain streams (every kernel of every stream competes for '
                     'all compute units) instead of one CU-masked stream per context on its own share (S = 2 or 4 only)')
-    ap.add_argument('--streams', type=int, default=4, help='HIP streams per GPU, each driven by its own host '
+    ap.add_argument('--streams', type=int, default=None, help='(default 4; 3 where the CU partition is not available) ''HIP streams per GPU, each driven by its own host '
                     'thread with its own library context and its own batches of pairs (independent units)')
     ap.add_argument('--full-register', action='store_true', help='register() as the reference ships it: final ICP on '
                     '(use_icp = True, core/deep_global_registration.py:78,317-322); NOT the headline configuration')
@@ -390,7 +390,21 @@ def main():
     from deepglobalregistration_amd.core.deep_global_registration import DeepGlobalRegistration
 
     B = args.pairs_per_step
-    S = max(1, args.streams)
+    S = max(1, args.streams if args.streams is not None else 4)
+    if args.streams is None and not args.no_cu_partition and not args.cu_shares:
+        # the default rests on CU-masked streams: where the runtime refuses one, three plain streams are the better default
+        # (378 against 360 pairs/s for four; a scheduling choice -- the kernels and their results are the same)
+        probe = _lib.new_ctx(device)
+        _lib.use_ctx(probe)
+        try:
+            ops.partition_stream(device, 0, 4)
+            ops.partition_stream(device, 0, 1)
+        except Exception as e:
+            log(f'no CU partition on this system ({e!r}): 3 plain streams')
+            S, args.no_cu_partition = 3, True
+        finally:
+            _lib.use_ctx(None)
+            _lib.load().dgr_ctx_destroy(probe)
     ck = synth.synth_checkpoint(seed=0, voxel_size=args.voxel, feat_conv1_kernel_size=args.conv1_ks) if rank == 0 else None
     coll_dev = device if backend == 'nccl' else torch.device('cpu')
     torch.cuda.synchronize()
